@@ -1,0 +1,186 @@
+/*
+ * kimi_hip.h -- C ABI of libkimi_hip.so, the MI355X (gfx950) implementation of the
+ * kimimaro TEASAR hot path.
+ *
+ * Conventions
+ *   - every entry point returns an int status (KH_OK == 0); kh_last_error() gives text.
+ *     Nothing throws across the boundary (the reference's C++ `throw` at
+ *     ext/skeletontricks/dijkstra_invalidation.hpp:54-58 would abort the process).
+ *   - all volume pointers are DEVICE pointers (HBM resident), Fortran ordered:
+ *     linear index = x + sx*(y + sy*z)  (ext/skeletontricks/skeletontricks.pyx:398).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous unless stated; the caller synchronises.
+ *   - caller allocates everything; the library never frees caller memory.
+ *   - labels are "connected component ids" 1..N (0 = background) as produced by
+ *     kimimaro/utility.py:58-83; label_bytes is 2 or 4.
+ *
+ * The whole-volume design: because connected components are disjoint, the per-label
+ * fields of the reference (DAF, PDRF, parents/dist, the invalidation mask -- all
+ * per-crop numpy arrays in kimimaro/trace.py) live in ONE set of whole-volume arrays
+ * shared by all labels, and the per-label kernels run one workgroup per label.
+ */
+#ifndef KIMI_HIP_H
+#define KIMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KH_OK 0
+#define KH_EINVAL 1      /* bad argument */
+#define KH_EHIP 2        /* a HIP runtime call failed */
+#define KH_ENODEVICE 3   /* no gfx950 device visible */
+
+/* per-label status bits written by the device kernels (kh_label_t.status) */
+#define KH_ST_OK 0u
+#define KH_ST_QUEUE_OVERFLOW 1u   /* search work list overflow (scratch too small) */
+#define KH_ST_HEAP_OVERFLOW 2u    /* invalidation heap overflow */
+#define KH_ST_PATH_OVERFLOW 4u    /* path output buffer overflow */
+#define KH_ST_NO_RAIL 8u          /* railroad: no rail reachable from a target */
+#define KH_ST_PLATEAU 16u         /* float-absorption plateau met while back-tracking */
+#define KH_ST_BAD_TARGET 32u      /* a target / root outside the label */
+
+int kh_version(void);
+/* copies the last error message of the calling thread, returns its length */
+int kh_last_error(char* buf, int len);
+/* number of visible devices whose arch is gfx950; 0 => every compute entry point fails loudly */
+int kh_device_count(void);
+
+/* ---- a1: edt.edt(labels, anisotropy, black_border) ---------------------------------
+ * replaces: edt.edt as called at kimimaro/intake.py:178-183 and kimimaro/trace.py:112-117.
+ * labels: u16/u32 [sx,sy,sz]; out: f32 same shape; workspace: f32 same shape (ping-pong).
+ * Squared distances are accumulated exactly as documented in oracle/kimi_oracle.c (ko_edt). */
+int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
+           float wx, float wy, float wz, int black_border,
+           float* workspace, float* out, void* stream);
+
+/* ---- preamble statistics on the device (fastremap.unique counts intake.py:198,
+ * np.max(DBF) trace.py:100, first_label skeletontricks.pyx:307-326, x extent of
+ * scipy.ndimage.find_objects utility.py:85-102) ------------------------------------
+ * For every label id in [0, nlabels]: voxel count, max DBF, smallest linear index,
+ * min/max x.  All outputs are device arrays of nlabels+1 entries, zero/identity
+ * initialised by the call.                                                            */
+int kh_label_stats(const void* labels, int label_bytes, const float* dbf, int64_t nvox, int64_t sx,
+                   int64_t nlabels, uint32_t* counts, float* dbf_max, uint32_t* first_index,
+                   uint32_t* xmin, uint32_t* xmax, void* stream);
+
+/* scatter the voxel indices of the selected labels into per-label lists.
+ * slot_of_label: device int32[nlabels+1], -1 = label not selected, else its slot;
+ * offsets: device u32[nslots] start of each slot's list in `lists`;
+ * cursors: device u32[nslots] scratch (zeroed by the call).  Order inside a list is
+ * unspecified (every consumer is order independent).                                  */
+int kh_scatter_lists(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
+                     int64_t nslots, const uint32_t* offsets, uint32_t* cursors, uint32_t* lists, void* stream);
+
+/* 26-bit same-label connectivity mask per voxel (bit i = neighbour i of the order in
+ * dijkstra_invalidation.hpp:60-124 is inside the volume and has the same non-zero
+ * label).  The optional voxel_graph of the reference is ANDed in by the caller (NULL
+ * in every config).                                                                   */
+int kh_neighbor_mask(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
+                     uint32_t* nbrmask, void* stream);
+
+/* ---- per-label task descriptor (device array, one per selected label) -------------- */
+typedef struct kh_label_t {
+  uint32_t segid;        /* connected component id */
+  uint32_t list_offset;  /* start of its voxel list */
+  uint32_t count;        /* Nf */
+  uint32_t xmin, xmax;   /* x extent of its bounding box (heap-order quirk, see paths.hip) */
+  uint32_t source;       /* in: search source (linear index) for kh_edf_batch */
+  uint32_t max_loc;      /* out: location of the farthest voxel */
+  float max_val;         /* out: its distance */
+  float M;               /* f32(1/dbf_max**1.01), kimimaro/trace.py:336 (host numpy) */
+  uint32_t root;         /* root voxel (linear index) */
+  uint32_t q_offset;     /* start of its slice of the work-list scratch (entries) */
+  uint32_t q_capacity;   /* entries per work list */
+  uint32_t heap_offset;  /* start of its invalidation heap slice (nodes) */
+  uint32_t heap_capacity;
+  uint32_t path_offset;  /* start of its slice of the path vertex buffer */
+  uint32_t path_capacity;
+  uint32_t tgt_offset;   /* manual targets: [tgt_offset, +n_before) before, then n_after after */
+  uint32_t n_before, n_after;
+  uint32_t max_paths;    /* 0 = unlimited (trace.py:214-215) */
+  uint32_t n_paths;      /* out */
+  uint32_t n_vertices;   /* out: vertices written to the path buffer */
+  uint32_t status;       /* out: KH_ST_* bits */
+  uint32_t stat_settled; /* out: sum of voxels touched by the railroad searches */
+  uint32_t stat_heap_pushes; /* out (low 32 bits) */
+  uint32_t pad;
+} kh_label_t;
+
+/* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
+ * replaces the calls at kimimaro/trace.py:139-145 and :302-307.  For every task: the
+ * distance field from task.source over its label (26-connected, anisotropic edge
+ * lengths, f32 accumulation) is written into `field` at the label's voxels (other
+ * voxels untouched); task.max_loc / max_val receive the farthest voxel (ties ->
+ * smallest linear index).  queues: device u64[...] scratch addressed by q_offset (4 lists
+ * of q_capacity entries per task).
+ * mode 0: source = task.source.
+ * mode 1 (find_root, trace.py:291-308): only tasks with root == 0xFFFFFFFF run; afterwards
+ *         task.root = max_loc.   mode 2 (DAF, trace.py:139-145): source = task.root.         */
+int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint32_t* lists, const uint32_t* nbrmask,
+                 int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                 float* field, uint64_t* queues, void* stream);
+
+/* ---- a3+a5: zero2inf / inf2zero / compute_pdrf fused, whole volume ------------------
+ * replaces kimimaro/trace.py:138,146,148 (skeletontricks.pyx:177-224, trace.py:315-356).
+ * For every voxel of a selected label: daf *= 1/max_daf (max_daf = task.max_val, skipped
+ * when 0), pdrf = ((1 - dbf*M)^(2^log2_exponent)) * scale + daf, each op rounded to f32.
+ * Voxels of unselected labels / background get pdrf = +inf.                           */
+int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
+            const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale,
+            float* pdrf, void* stream);
+
+/* ---- a6..a11: the per-label TEASAR path loop ---------------------------------------
+ * replaces kimimaro/trace.py:196-267 (compute_paths) with its callees
+ * CachedTargetFinder.find_target (skeletontricks.pyx:1008-1045), dijkstra3d.railroad
+ * (trace.py:240-242), roll_invalidation_ball_inside_component (skeletontricks.pyx:373-418
+ * -> dijkstra_invalidation.hpp:239-332) and the rail edits trace.py:220,261-263.
+ * alive: u8 per voxel, 1 for the voxels of selected labels (mutated: invalidation);
+ * pdrf: mutated (rails are zeroed); dist: f32 scratch volume, must be +inf on entry and
+ * is +inf again on exit; list_daf: DAF gathered in list order (target finder keys).
+ * Paths are written as linear indices, rail end first, into path_vertices with
+ * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).       */
+int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
+                   const uint32_t* nbrmask, const void* labels, int label_bytes,
+                   int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                   const float* dbf, float* pdrf, float* dist, uint8_t* alive,
+                   const uint32_t* manual_targets, float scale, float constant,
+                   uint64_t* queues, float* heap_keys, uint64_t* heap_payload,
+                   uint32_t* path_vertices, uint32_t* path_lengths, void* stream);
+
+/* small helpers used by the host mirror */
+int kh_fill_f32(float* p, int64_t n, float v, void* stream);
+int kh_fill_u8(uint8_t* p, int64_t n, int v, void* stream);
+int kh_gather_f32(const float* src, const uint32_t* idx, int64_t n, float* out, void* stream);
+/* alive[v] = 1 where slot_of_label[label[v]] >= 0 else 0 */
+int kh_init_alive(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
+                  uint8_t* alive, void* stream);
+
+/* ---- a10: roll_invalidation_cube (skeletontricks.pyx:766-836 -> skeletontricks.hpp:42-155)
+ * not on the reference's own skeletonize() call graph, exported and tested there
+ * (automated_test.py:632-825).  mask: u8 device [sx,sy,sz], mutated; path: device u64
+ * linear indices; *invalidated (device int64) receives the count.                      */
+int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, int64_t sy, int64_t sz,
+                       float wx, float wy, float wz, const uint64_t* path, int64_t npath,
+                       float scale, float constant, int64_t* invalidated, void* stream);
+
+/* ---- preamble row f1 (host side for now): 26-connected multi-label CCL on HOST memory,
+ * restating cc3d.connected_components as called at kimimaro/utility.py:74-77.
+ * Returns the number of components (ids 1..N by first appearance in F-order raster).   */
+int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
+                      uint32_t* out);
+
+/* ---- row f2 (host side): skeletontricks.find_border_targets (skeletontricks.pyx:591-647 with
+ * compute_centroids :528-588 and compute_tiebreaker_maxima :650-760) on HOST memory.
+ * dt (f32) and cc (u32) are [sx,sy] Fortran ordered planes; for each component id with a maximum
+ * out_xy[2*id..2*id+1] receives (x, y) and `order` the ids in dict-insertion order.
+ * Returns the number of ids, -1 on allocation failure.                                  */
+int64_t kh_host_find_border_targets(const float* dt, const uint32_t* cc, int64_t sx, int64_t sy,
+                                    float wx, float wy, int64_t nlab, float* out_xy, int32_t* order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""ctypes binding of libkimi_hip.so (include/kimi_hip.h).
+
+There is NO CPU fallback: if the library is missing, cannot be loaded, or no gfx950 device is
+visible, every compute entry point raises ``HipUnavailableError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
+
+# every symbol include/kimi_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_label_stats", "kh_scatter_lists",
+    "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
+    "kh_gather_f32", "kh_init_alive", "kh_invalidate_cube", "kh_host_ccl26", "kh_host_find_border_targets",
+]
+
+
+class HipUnavailableError(RuntimeError):
+    """libkimi_hip.so (or an MI355X) is not available; the product has no CPU path."""
+
+
+class KimiHipError(RuntimeError):
+    pass
+
+
+# kh_label_t  (include/kimi_hip.h) -- 26 x 4 bytes
+LABEL_T = np.dtype([
+    ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
+    ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
+    ("q_offset", "<u4"), ("q_capacity", "<u4"), ("heap_offset", "<u4"), ("heap_capacity", "<u4"),
+    ("path_offset", "<u4"), ("path_capacity", "<u4"), ("tgt_offset", "<u4"), ("n_before", "<u4"),
+    ("n_after", "<u4"), ("max_paths", "<u4"), ("n_paths", "<u4"), ("n_vertices", "<u4"),
+    ("status", "<u4"), ("stat_settled", "<u4"), ("stat_heap_pushes", "<u4"), ("pad", "<u4"),
+])
+assert LABEL_T.itemsize == 104
+
+ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
+           8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",
+           32: "target outside the label"}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipUnavailableError(
+            "kimimaro_amd: %s is missing. Build it with `python -m kimimaro_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch is the device-memory plumbing and bundles its own HIP runtime: load it FIRST so that
+        # libkimi_hip.so binds to the same libamdhip64 (two runtimes in one process cannot share a GPU).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise HipUnavailableError("kimimaro_amd: cannot load %s: %s" % (LIB_PATH, e)) from e
+    i64, f32, vp, ci = C.c_int64, C.c_float, C.c_void_p, C.c_int
+    L.kh_version.restype = ci
+    L.kh_last_error.argtypes = [C.c_char_p, ci]
+    L.kh_device_count.restype = ci
+    L.kh_edt.argtypes = [vp, ci, i64, i64, i64, f32, f32, f32, ci, vp, vp, vp]
+    L.kh_label_stats.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.kh_scatter_lists.argtypes = [vp, ci, i64, vp, i64, vp, vp, vp, vp]
+    L.kh_neighbor_mask.argtypes = [vp, ci, i64, i64, i64, vp, vp]
+    L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp]
+    L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
+    L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, vp, ci, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp,
+                                 f32, f32, vp, vp, vp, vp, vp, vp]
+    L.kh_fill_f32.argtypes = [vp, i64, f32, vp]
+    L.kh_fill_u8.argtypes = [vp, i64, ci, vp]
+    L.kh_gather_f32.argtypes = [vp, vp, i64, vp, vp]
+    L.kh_init_alive.argtypes = [vp, ci, i64, vp, vp, vp]
+    L.kh_invalidate_cube.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, vp, i64, f32, f32, vp, vp]
+    L.kh_host_ccl26.argtypes = [vp, ci, i64, i64, i64, vp]
+    L.kh_host_ccl26.restype = i64
+    L.kh_host_find_border_targets.argtypes = [vp, vp, i64, i64, f32, f32, i64, vp, vp]
+    L.kh_host_find_border_targets.restype = i64
+    for name in SYMBOLS:
+        getattr(L, name)
+        if name not in ("kh_version", "kh_device_count", "kh_host_ccl26", "kh_last_error",
+                        "kh_host_find_border_targets"):
+            getattr(L, name).restype = ci
+    _lib = L
+    return L
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().kh_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == 3:
+        raise HipUnavailableError(msg)
+    raise KimiHipError("libkimi_hip error %d: %s" % (rc, msg))
+
+
+def require_gpu():
+    """Raise unless the library loads AND a gfx950 device is visible."""
+    L = lib()
+    if L.kh_device_count() <= 0:
+        raise HipUnavailableError(
+            "kimimaro_amd: no gfx950 (MI355X) device visible; the product path has no CPU fallback.")
+    return L
+
+
+def describe_status(bits):
+    return ", ".join(v for k, v in ST_BITS.items() if bits & k) or "ok"

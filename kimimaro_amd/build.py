@@ -1,0 +1,39 @@
+"""Build recipe for the product library: hipcc --offload-arch=gfx950 -> kimimaro_amd/libkimi_hip.so.
+
+In-tree build (the .so travels to the GPU box with the snapshot; it is git-ignored).
+-ffp-contract=off: no FMA contraction anywhere -- squared distances, PDRF and Dijkstra sums must be
+rounded op by op exactly like numpy / the reference's g++ build / the oracle.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libkimi_hip.so")
+SOURCES = ["common.hip", "edt.hip", "prep.hip", "trace.hip"]
+DEPS = SOURCES + ["common.h", os.path.join("..", "..", "include", "kimi_hip.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force=True, verbose="-v" in sys.argv))

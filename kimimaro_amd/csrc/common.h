@@ -1,0 +1,61 @@
+// common.h -- shared host/device helpers for libkimi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/kimi_hip.h"
+
+namespace kh {
+
+void set_error(const char* fmt, ...);
+
+#define KH_HIP_CHECK(expr)                                                         \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      kh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return KH_EHIP;                                                              \
+    }                                                                              \
+  } while (0)
+
+#define KH_LAUNCH_CHECK()                                                          \
+  do {                                                                             \
+    hipError_t _e = hipGetLastError();                                             \
+    if (_e != hipSuccess) {                                                        \
+      kh::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return KH_EHIP;                                                              \
+    }                                                                              \
+  } while (0)
+
+int require_device();  // KH_OK or KH_ENODEVICE (+message); cached after the first success
+
+static constexpr float KH_INF = __builtin_huge_valf();
+
+// 26-neighbourhood in the order of dijkstra_invalidation.hpp:60-124
+__host__ __device__ inline void dir_delta(int i, int& dx, int& dy, int& dz) {
+  // packed table: 2 bits per component (0 -> -1, 1 -> 0, 2 -> +1)
+  constexpr int8_t T[26][3] = {
+      {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+      {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0},
+      {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
+      {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1},
+      {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, 1, -1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
+  dx = T[i][0];
+  dy = T[i][1];
+  dz = T[i][2];
+}
+
+struct Geometry {
+  int32_t sx, sy, sz;
+  int32_t sxy;          // sx*sy (volumes are < 2^32 voxels, slices < 2^31)
+  int32_t off[26];      // linear offset of neighbour i
+  float w[26];          // centre-to-centre length of neighbour i (f32, no contraction)
+  float wx, wy, wz;
+};
+
+// host: fill a Geometry (edge lengths as dijkstra_invalidation.hpp:45-52)
+void make_geometry(Geometry& g, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz);
+
+}  // namespace kh

@@ -1,0 +1,271 @@
+// prep.hip -- whole-volume streaming kernels around the per-label searches (gfx950).
+//
+//   kh_label_stats    fastremap.unique counts (kimimaro/intake.py:198), np.max(DBF) per label
+//                     (kimimaro/trace.py:100), first_label (skeletontricks.pyx:307-326) and the
+//                     x extent of find_objects (kimimaro/utility.py:85-102), in ONE pass.
+//   kh_scatter_lists  per-label voxel index lists (the flatnonzero of skeletontricks.pyx:1001).
+//   kh_neighbor_mask  26-bit same-label connectivity (replaces the per-crop bounds + mask tests
+//                     of dijkstra_invalidation.hpp:60-124 / dijkstra3d's neighbourhood code).
+//   kh_pdrf           zero2inf + inf2zero + compute_pdrf fused (kimimaro/trace.py:138,146,315-356).
+//
+// All are HBM-bound sweeps: lanes along x, wave-aggregated atomics (one atomic per run of equal
+// labels inside a wave instead of one per voxel).
+#include "common.h"
+
+namespace kh {
+
+template <typename LT>
+__device__ __forceinline__ uint32_t ld_label(const LT* p, int64_t i) { return (uint32_t)p[i]; }
+
+// run structure of a wave: lanes hold consecutive voxels; a run = maximal lane interval with the
+// same label that does not cross an x == 0 row start.
+struct WaveRun {
+  int start;   // first lane of my run
+  int end;     // last lane of my run
+};
+
+__device__ __forceinline__ WaveRun wave_runs(uint32_t label, bool valid, bool row_start) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t prev = __shfl_up(label, 1);
+  const bool pvalid = __shfl_up((int)valid, 1) != 0;
+  const bool leader = (lane == 0) || (label != prev) || row_start || (valid != pvalid);
+  const unsigned long long lead = __ballot(leader);
+  // start = highest leader bit <= lane ; end = (next leader bit > lane) - 1
+  const unsigned long long below = lead & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  WaveRun r;
+  r.start = 63 - __clzll((long long)below);
+  const unsigned long long above = (lane == 63) ? 0ull : (lead & ~((2ull << lane) - 1ull));
+  r.end = above ? (__ffsll((long long)above) - 2) : 63;
+  return r;
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void label_stats_kernel(const LT* __restrict__ lab, const float* __restrict__ dbf,
+                                                          int64_t nvox, int sx, uint32_t* counts, uint32_t* dbf_max_bits,
+                                                          uint32_t* first_index, uint32_t* xmin, uint32_t* xmax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nchunks = (nvox + 255) / 256;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t i = c * 256 + threadIdx.x;
+    const bool valid = i < nvox;
+    const uint32_t L = valid ? ld_label(lab, i) : 0u;
+    const int x = valid ? (int)(i % sx) : 0;
+    float v = valid ? dbf[i] : 0.0f;
+    const WaveRun r = wave_runs(L, valid, x == 0);
+    // segmented max scan of v over the run
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(v, d);
+      if (lane - d >= r.start) v = fmaxf(v, o);
+    }
+    if (valid && L != 0 && lane == r.end) {
+      const int len = r.end - r.start + 1;
+      atomicAdd(&counts[L], (uint32_t)len);
+      atomicMax(&dbf_max_bits[L], __float_as_uint(v));  // v >= 0
+      atomicMin(&first_index[L], (uint32_t)(i - (len - 1)));
+      atomicMin(&xmin[L], (uint32_t)(x - (len - 1)));
+      atomicMax(&xmax[L], (uint32_t)x);
+    }
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void scatter_lists_kernel(const LT* __restrict__ lab, int64_t nvox,
+                                                            const int32_t* __restrict__ slot_of_label,
+                                                            const uint32_t* __restrict__ offsets, uint32_t* cursors,
+                                                            uint32_t* __restrict__ lists) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nchunks = (nvox + 255) / 256;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t i = c * 256 + threadIdx.x;
+    const bool valid = i < nvox;
+    const uint32_t L = valid ? ld_label(lab, i) : 0u;
+    const int slot = (valid && L != 0) ? slot_of_label[L] : -1;
+    const WaveRun r = wave_runs(L, valid, false);
+    uint32_t base = 0;
+    if (slot >= 0 && lane == r.end) base = offsets[slot] + atomicAdd(&cursors[slot], (uint32_t)(r.end - r.start + 1));
+    base = __shfl(base, r.end);
+    if (slot >= 0) lists[base + (uint32_t)(lane - r.start)] = (uint32_t)i;
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void neighbor_mask_kernel(const LT* __restrict__ lab, int sx, int sy, int sz,
+                                                            uint32_t* __restrict__ out) {
+  // grid: x tiles of 256, y, z folded into blockIdx.x (1-D grid, row major)
+  const int xt = (sx + 255) >> 8;
+  const int64_t ntiles = (int64_t)xt * sy * sz;
+  const int64_t sxy = (int64_t)sx * sy;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int x = (int)(t % xt) * 256 + threadIdx.x;
+    const int64_t r = t / xt;
+    const int y = (int)(r % sy), z = (int)(r / sy);
+    if (x >= sx) continue;
+    const int64_t i = x + (int64_t)sx * y + sxy * z;
+    const uint32_t L = ld_label(lab, i);
+    uint32_t m = 0;
+    if (L != 0) {
+#pragma unroll
+      for (int k = 0; k < 26; k++) {
+        int dx, dy, dz;
+        dir_delta(k, dx, dy, dz);
+        const int nx = x + dx, ny = y + dy, nz = z + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
+        if (ld_label(lab, i + dx + (int64_t)sx * dy + sxy * dz) == L) m |= (1u << k);
+      }
+    }
+    out[i] = m;
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void pdrf_kernel(const LT* __restrict__ lab, int64_t nvox,
+                                                   const int32_t* __restrict__ slot_of_label,
+                                                   const kh_label_t* __restrict__ tasks, const float* __restrict__ dbf,
+                                                   float* __restrict__ daf, int nsq, float scale, float* __restrict__ pdrf) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * 256) {
+    const uint32_t L = ld_label(lab, i);
+    const int slot = L ? slot_of_label[L] : -1;
+    float p = KH_INF;
+    if (slot >= 0) {
+      const float M = tasks[slot].M;
+      const float max_daf = tasks[slot].max_val;
+      p = dbf[i] * M;        // np.multiply(DBF, M)            trace.py:341
+      p = 1.0f - p;          // np.subtract(f(1), PDRF)        trace.py:342
+      for (int s = 0; s < nsq; s++) p = p * p;  //             trace.py:343-345
+      p = p * scale;         // PDRF *= f(pdrf_scale)          trace.py:349
+      float d = daf[i];
+      if (d == KH_INF) d = 0.0f;  // inf2zero                  trace.py:146
+      if (max_daf != 0.0f) {
+        const float inv = 1.0f / max_daf;  // (1 / max_daf) in float32 (numpy 2 scalar)  trace.py:353
+        d = d * inv;
+        p = p + d;           //                                trace.py:354
+      }
+      daf[i] = d;
+    }
+    pdrf[i] = p;
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void init_alive_kernel(const LT* __restrict__ lab, int64_t nvox,
+                                                         const int32_t* __restrict__ slot_of_label, uint8_t* __restrict__ alive) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * 256) {
+    const uint32_t L = ld_label(lab, i);
+    alive[i] = (L != 0 && slot_of_label[L] >= 0) ? 1 : 0;
+  }
+}
+
+__global__ void fill_f32_kernel(float* p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_u8_kernel(uint8_t* p, int64_t n, uint8_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void gather_f32_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = src[idx[i]];
+}
+
+static inline unsigned grid_for(int64_t n, int per_block, int64_t cap = 8192) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace kh
+
+using namespace kh;
+
+#define KH_DISPATCH_LT(bytes, CALL)                          \
+  switch (bytes) {                                           \
+    case 1: { typedef uint8_t LT; CALL; } break;             \
+    case 2: { typedef uint16_t LT; CALL; } break;            \
+    case 4: { typedef uint32_t LT; CALL; } break;            \
+    default: set_error("label_bytes must be 1, 2 or 4"); return KH_EINVAL; \
+  }
+
+extern "C" int kh_label_stats(const void* labels, int label_bytes, const float* dbf, int64_t nvox, int64_t sx,
+                              int64_t nlabels, uint32_t* counts, float* dbf_max, uint32_t* first_index, uint32_t* xmin,
+                              uint32_t* xmax, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n1 = nlabels + 1;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, counts, n1, 0u);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, (uint32_t*)dbf_max, n1, 0u);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, first_index, n1, 0xFFFFFFFFu);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, xmin, n1, 0xFFFFFFFFu);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, xmax, n1, 0u);
+  KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((label_stats_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
+                                                 (const LT*)labels, dbf, nvox, (int)sx, counts, (uint32_t*)dbf_max,
+                                                 first_index, xmin, xmax));
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_scatter_lists(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
+                                int64_t nslots, const uint32_t* offsets, uint32_t* cursors, uint32_t* lists, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, st, cursors, nslots, 0u);
+  KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((scatter_lists_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
+                                                 (const LT*)labels, nvox, slot_of_label, offsets, cursors, lists));
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_neighbor_mask(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, uint32_t* nbrmask,
+                                void* stream) {
+  if (int rc = require_device()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = ((sx + 255) / 256) * sy * sz;
+  KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((neighbor_mask_kernel<LT>), dim3(grid_for(ntiles, 1, 1 << 20)), dim3(256), 0,
+                                                 st, (const LT*)labels, (int)sx, (int)sy, (int)sz, nbrmask));
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
+                       const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale, float* pdrf,
+                       void* stream) {
+  if (int rc = require_device()) return rc;
+  if (log2_exponent < 0 || log2_exponent > 15) { set_error("kh_pdrf: exponent must be a power of two < 2^16"); return KH_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((pdrf_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
+                                                 (const LT*)labels, nvox, slot_of_label, tasks, dbf, daf, log2_exponent, scale,
+                                                 pdrf));
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_init_alive(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label, uint8_t* alive,
+                             void* stream) {
+  if (int rc = require_device()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((init_alive_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
+                                                 (const LT*)labels, nvox, slot_of_label, alive));
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_fill_f32(float* p, int64_t n, float v, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_fill_u8(uint8_t* p, int64_t n, int v, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipLaunchKernelGGL(fill_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, (uint8_t)v);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_gather_f32(const float* src, const uint32_t* idx, int64_t n, float* out, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipLaunchKernelGGL(gather_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, n, out);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}

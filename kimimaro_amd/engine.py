@@ -1,0 +1,238 @@
+"""Host orchestration of the HIP kernels (one process = one GPU).
+
+PyTorch is used ONLY as plumbing: device allocations (caching allocator), H2D/D2H copies and the
+current HIP stream.  Every computation is a hand-written kernel in libkimi_hip.so reached through the
+C ABI of include/kimi_hip.h.
+
+The engine works on whole-volume, Fortran-ordered 1-D device arrays.  Because connected components
+are disjoint, all labels share one DAF / PDRF / dist / alive volume and every label is processed by
+its own workgroup (kimimaro/intake.py:434-517 runs them one after the other on cropped copies).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+NONE32 = 0xFFFFFFFF
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _abi.HipUnavailableError("kimimaro_amd: torch sees no GPU; the product path has no CPU fallback.")
+    return torch
+
+
+class Engine:
+    def __init__(self, device=None):
+        self.lib = _abi.require_gpu()
+        self.torch = _torch()
+        self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
+
+    # -- plumbing -----------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, n, dtype):
+        return self.torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def to_device(self, arr):
+        """numpy (any shape, F order expected) -> 1-D device tensor in memory order."""
+        flat = np.ascontiguousarray(arr.reshape(-1, order="F"))
+        if flat.dtype == np.uint16:
+            flat = flat.view(np.int16)
+        elif flat.dtype == np.uint32:
+            flat = flat.view(np.int32)
+        elif flat.dtype == np.uint64:
+            flat = flat.view(np.int64)
+        return self.torch.from_numpy(flat).to(self.device)
+
+    @staticmethod
+    def ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    # -- a1 -------------------------------------------------------------------
+    def edt(self, d_labels, label_bytes, shape, anisotropy, black_border, out=None, workspace=None):
+        sx, sy, sz = shape
+        n = sx * sy * sz
+        t = self.torch
+        if out is None:
+            out = self.empty(n, t.float32)
+        if workspace is None:
+            workspace = self.empty(n, t.float32)
+        _abi.check(self.lib.kh_edt(self.ptr(d_labels), label_bytes, sx, sy, sz, float(anisotropy[0]),
+                                   float(anisotropy[1]), float(anisotropy[2]), int(bool(black_border)),
+                                   self.ptr(workspace), self.ptr(out), self.stream()))
+        return out
+
+    def label_stats(self, d_labels, label_bytes, d_dbf, shape, nlabels):
+        t = self.torch
+        n1 = nlabels + 1
+        counts = self.empty(n1, t.int32)
+        dmax = self.empty(n1, t.float32)
+        first = self.empty(n1, t.int32)
+        xmin = self.empty(n1, t.int32)
+        xmax = self.empty(n1, t.int32)
+        nvox = shape[0] * shape[1] * shape[2]
+        _abi.check(self.lib.kh_label_stats(self.ptr(d_labels), label_bytes, self.ptr(d_dbf), nvox, shape[0], nlabels,
+                                           self.ptr(counts), self.ptr(dmax), self.ptr(first), self.ptr(xmin),
+                                           self.ptr(xmax), self.stream()))
+        u32 = lambda x: x.cpu().numpy().view(np.uint32)
+        return u32(counts), dmax.cpu().numpy(), u32(first), u32(xmin), u32(xmax)
+
+    # -- the per-label pipeline -------------------------------------------------
+    def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
+                   xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,
+                   return_fields=False, timings=None):
+        """Run find_root -> DAF -> PDRF -> path loop for the connected components `segids`.
+
+        segids/counts/...: host arrays indexed by position (same order).  roots: array of linear indices or
+        NONE32.  targets_before/after: list (per label) of lists of linear indices (LIFO stacks as in
+        kimimaro/trace.py:225-228).  Returns a dict with per-label path arrays.
+        """
+        if not fix_branching:
+            raise NotImplementedError("fix_branching=False (parental_field path) is not wired into the HIP path yet")
+        t = self.torch
+        lib = self.lib
+        st = self.stream()
+        sx, sy, sz = shape
+        nvox = sx * sy * sz
+        nl = len(segids)
+        if nl == 0:
+            return {"order": np.zeros(0, np.int64), "tasks": np.zeros(0, _abi.LABEL_T), "paths": []}
+        segids = np.asarray(segids, dtype=np.int64)
+        counts = np.asarray(counts, dtype=np.int64)
+        order = np.argsort(-counts, kind="stable")  # big labels first: their workgroups start first
+        slot_of_label = -np.ones(nlabels + 1, dtype=np.int32)
+        slot_of_label[segids[order]] = np.arange(nl, dtype=np.int32)
+
+        cnt = counts[order]
+        list_off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        total = int(cnt.sum())
+        qcap = 2 * cnt + 256
+        q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
+        hcap = 4 * cnt + 1024
+        h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
+        pcap = np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536))
+        p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
+        if max(total, int(qcap.sum()), int(hcap.sum()), int(pcap.sum())) >= 2 ** 32:
+            raise ValueError("kimimaro_amd: scratch offsets exceed 32 bits; shard the labels")
+
+        tasks = np.zeros(nl, dtype=_abi.LABEL_T)
+        tasks["segid"] = segids[order]
+        tasks["list_offset"] = list_off
+        tasks["count"] = cnt
+        tasks["xmin"] = np.asarray(xmin)[order]
+        tasks["xmax"] = np.asarray(xmax)[order]
+        tasks["source"] = np.asarray(first_index)[order]
+        tasks["root"] = np.asarray(roots, dtype=np.uint32)[order]
+        f = np.float32
+        dm = np.asarray(dbf_max, dtype=np.float32)[order]
+        # M = f32(1 / dbf_max ** 1.01) with numpy scalar semantics, kimimaro/trace.py:335-336
+        tasks["M"] = np.array([f(1 / (f(v) ** 1.01)) if v > 0 else f(0) for v in dm], dtype=np.float32)
+        tasks["q_offset"] = q_off
+        tasks["q_capacity"] = qcap
+        tasks["heap_offset"] = h_off
+        tasks["heap_capacity"] = hcap
+        tasks["path_offset"] = p_off
+        tasks["path_capacity"] = pcap
+        tasks["max_paths"] = 0 if max_paths is None else int(max_paths)
+        tgt = []
+        tgt_off = np.zeros(nl, dtype=np.int64)
+        for s, o in enumerate(order):
+            tgt_off[s] = len(tgt)
+            b = list(targets_before[o]) if targets_before is not None else []
+            a = list(targets_after[o]) if targets_after is not None else []
+            tasks["n_before"][s] = len(b)
+            tasks["n_after"][s] = len(a)
+            tgt.extend(b)
+            tgt.extend(a)
+        tasks["tgt_offset"] = tgt_off
+        tgt_arr = np.asarray(tgt + [0], dtype=np.uint32)
+
+        d_tasks = t.from_numpy(tasks.view(np.uint8).reshape(-1)).to(self.device)
+        d_slot = t.from_numpy(slot_of_label).to(self.device)
+        d_off = t.from_numpy(list_off.astype(np.uint32).view(np.int32)).to(self.device)
+        d_cur = self.empty(nl, t.int32)
+        d_lists = self.empty(max(total, 1), t.int32)
+        d_tgt = t.from_numpy(tgt_arr.view(np.int32)).to(self.device)
+        d_nbr = self.empty(nvox, t.int32)
+        d_field = self.empty(nvox, t.float32)
+        d_queues = self.empty(4 * int(qcap.sum()), t.int64)
+        P = self.ptr
+        wx, wy, wz = (float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]))
+
+        def mark(name):
+            if timings is not None:
+                self.sync()
+                import time
+                timings.append((name, time.perf_counter()))
+
+        mark("setup")
+        _abi.check(lib.kh_scatter_lists(P(d_cc), label_bytes, nvox, P(d_slot), nl, P(d_off), P(d_cur), P(d_lists), st))
+        _abi.check(lib.kh_neighbor_mask(P(d_cc), label_bytes, sx, sy, sz, P(d_nbr), st))
+        mark("lists+nbrmask")
+        # find_root (trace.py:291-308) then DAF (trace.py:139-145)
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_queues), st))
+        mark("edf_root")
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_queues), st))
+        mark("edf_daf")
+        d_ldaf = self.empty(max(total, 1), t.float32)
+        _abi.check(lib.kh_gather_f32(P(d_field), P(d_lists), total, P(d_ldaf), st))
+        # PDRF (trace.py:148)
+        expo = int(params["pdrf_exponent"])
+        if expo <= 0 or (expo & (expo - 1)) != 0 or expo >= 2 ** 16:
+            raise NotImplementedError("pdrf_exponent must be a power of two < 2**16 on the HIP path")
+        d_pdrf = self.empty(nvox, t.float32)
+        _abi.check(lib.kh_pdrf(P(d_cc), label_bytes, nvox, P(d_slot), P(d_tasks), P(d_dbf), P(d_field),
+                               expo.bit_length() - 1, np.float32(params["pdrf_scale"]), P(d_pdrf), st))
+        mark("pdrf")
+        d_dist = self.empty(nvox, t.float32)
+        _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
+        d_alive = self.empty(nvox, t.uint8)
+        _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
+        d_hkeys = self.empty(int(hcap.sum()), t.float32)
+        d_hpay = self.empty(int(hcap.sum()), t.int64)
+        d_pverts = self.empty(int(pcap.sum()), t.int32)
+        d_plens = self.empty(int(pcap.sum()), t.int32)
+        _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), P(d_cc), label_bytes, sx, sy, sz,
+                                      wx, wy, wz, P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_tgt),
+                                      np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_hkeys),
+                                      P(d_hpay), P(d_pverts), P(d_plens), st))
+        mark("paths")
+        out_tasks = d_tasks.cpu().numpy().view(_abi.LABEL_T).copy()
+        bad = np.flatnonzero(out_tasks["status"])
+        if bad.size:
+            s = int(bad[0])
+            raise _abi.KimiHipError("label %d (cc id): %s" % (int(out_tasks["segid"][s]),
+                                                               _abi.describe_status(int(out_tasks["status"][s]))))
+        # gather the used part of the path buffers: build a flat index on the host (small), gather on device
+        nverts = out_tasks["n_vertices"].astype(np.int64)
+        npaths = out_tasks["n_paths"].astype(np.int64)
+        vidx = np.concatenate([p_off[s] + np.arange(nverts[s]) for s in range(nl)] + [np.zeros(0, np.int64)])
+        lidx = np.concatenate([p_off[s] + np.arange(npaths[s]) for s in range(nl)] + [np.zeros(0, np.int64)])
+        d_vidx = t.from_numpy(vidx).to(self.device)
+        d_lidx = t.from_numpy(lidx).to(self.device)
+        verts_dev = d_pverts[d_vidx]
+        verts = verts_dev.cpu().numpy().view(np.uint32)
+        lens = d_plens[d_lidx].cpu().numpy().view(np.uint32)
+        d_radii = self.empty(max(verts.size, 1), t.float32)
+        if verts.size:
+            _abi.check(lib.kh_gather_f32(P(d_dbf), P(verts_dev.contiguous()), verts.size, P(d_radii), st))
+        radii = d_radii.cpu().numpy()[: verts.size]
+        mark("d2h")
+        voff = np.concatenate([[0], np.cumsum(nverts)])
+        loff = np.concatenate([[0], np.cumsum(npaths)])
+        res = {"order": order, "tasks": out_tasks, "verts": verts, "radii": radii, "lens": lens,
+               "voff": voff, "loff": loff}
+        if return_fields:
+            res["daf"] = d_field.cpu().numpy()
+            res["pdrf"] = d_pdrf.cpu().numpy()
+            res["alive"] = d_alive.cpu().numpy()
+        return res

@@ -1,0 +1,267 @@
+"""kimimaro_amd.skeletonize -- host-side mirror of kimimaro.skeletonize (kimimaro/intake.py:58-221)
+driving the HIP kernels.  Same signature, same defaults, same return type ({label: Skeleton}).
+
+What runs where
+  host (numpy)         format_labels / object mask / early outs (intake.py:147-160), connected
+                       components (row f1, host C++ for now), border targets (row f2), Skeleton assembly.
+  MI355X (libkimi_hip) whole-volume EDT (intake.py:174-185), per-label statistics, and for every
+                       connected component the complete TEASAR trace (kimimaro/trace.py:36-267):
+                       find_root, DAF, PDRF, target finder, railroad, rolling invalidation.
+
+There is no CPU fallback: without libkimi_hip.so + an MI355X this raises HipUnavailableError.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import numpy as np
+
+from . import _abi
+from .engine import Engine, NONE32
+from .skeleton import Skeleton
+
+DEFAULT_TEASAR_PARAMS = {  # kimimaro/intake.py:47-56
+    "scale": 1.5,
+    "const": 300,
+    "pdrf_scale": 100000,
+    "pdrf_exponent": 4,
+    "soma_acceptance_threshold": 3500,
+    "soma_detection_threshold": 750,
+    "soma_invalidation_const": 300,
+    "soma_invalidation_scale": 2,
+}
+
+# kimimaro/trace.py:38-43 -- the defaults trace() falls back to for keys missing from teasar_params
+TRACE_DEFAULTS = {
+    "scale": 10, "const": 10, "soma_detection_threshold": 1100, "soma_acceptance_threshold": 4000,
+    "pdrf_scale": 5000, "pdrf_exponent": 16, "soma_invalidation_scale": 0.5, "soma_invalidation_const": 0,
+    "max_paths": None,
+}
+
+
+class DimensionError(Exception):
+    pass
+
+
+def format_labels(labels, in_place=False):
+    """kimimaro/intake.py:315-342."""
+    if in_place:
+        labels = np.asfortranarray(labels)
+    else:
+        labels = np.copy(labels, order="F")
+    if labels.dtype == bool:
+        labels = labels.view(np.uint8)
+    original_shape = labels.shape
+    while labels.ndim < 3:
+        labels = labels[..., np.newaxis]
+    while labels.ndim > 3:
+        if labels.shape[-1] == 1:
+            labels = labels[..., 0]
+        else:
+            raise DimensionError(
+                "Input labels may be no more than three non-trivial dimensions. Got: {}".format(original_shape))
+    return labels
+
+
+def apply_object_mask(all_labels, object_ids):
+    """kimimaro/intake.py:519-535."""
+    if object_ids is None:
+        return all_labels
+    keep = np.isin(all_labels, np.asarray(list(object_ids), dtype=all_labels.dtype))
+    all_labels[~keep] = 0
+    return all_labels
+
+
+def compute_cc_labels(all_labels):
+    """kimimaro/utility.py:58-83 -> (cc_labels uint32 F-order, N, {cc id: original id}).
+    Row f1: 26-connected multi-label CCL, host C++ helper in libkimi_hip.so for now."""
+    lib = _abi.lib()
+    lab = all_labels
+    if lab.dtype.kind not in "ui" or lab.dtype.itemsize not in (1, 2, 4, 8):
+        lab = lab.astype(np.uint64)
+    lab = np.asfortranarray(lab)
+    cc = np.zeros(lab.shape, dtype=np.uint32, order="F")
+    import ctypes as C
+    n = lib.kh_host_ccl26(lab.ctypes.data_as(C.c_void_p), lab.dtype.itemsize, lab.shape[0], lab.shape[1],
+                          lab.shape[2], cc.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        raise MemoryError("kh_host_ccl26 failed")
+    flat_cc = cc.reshape(-1, order="F")
+    idx = np.flatnonzero(flat_cc)
+    uniq, first_idx = np.unique(flat_cc[idx], return_index=True)
+    orig = all_labels.reshape(-1, order="F")[idx[first_idx]]
+    remap = {int(u): orig[i].item() for i, u in enumerate(uniq)}  # skeletontricks.get_mapping :490-525
+    return cc, int(n), remap
+
+
+def _points_to_labels(pts, cc_labels):
+    mapping = defaultdict(list)
+    for pt in pts:
+        pt = tuple(int(v) for v in pt)
+        mapping[int(cc_labels[pt])].append(pt)
+    return mapping
+
+
+def _loc(pt, shape):
+    return int(pt[0]) + shape[0] * (int(pt[1]) + shape[1] * int(pt[2]))
+
+
+def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 1, 1),
+                object_ids=None, dust_threshold=1000, progress=True, fix_branching=True,
+                in_place=False, fix_borders=True, parallel=1, parallel_chunk_size=100,
+                extra_targets_before=[], extra_targets_after=[], fill_holes=False,
+                fix_avocados=False, voxel_graph=None, _timings=None, _engine=None):
+    """Skeletonize all non-zero labels of a 2D/3D label image on the MI355X.
+
+    Arguments and return value as kimimaro.skeletonize (kimimaro/intake.py:58-141).  `parallel` and
+    `parallel_chunk_size` (process pool of the reference, intake.py:344-408) have no meaning here:
+    one process drives one GPU; multi-GPU runs shard the connected components round robin over the
+    ranks of torch.distributed (see kimimaro_amd.distributed).
+    """
+    if fill_holes or fix_avocados or voxel_graph is not None:
+        raise NotImplementedError("fill_holes / fix_avocados / voxel_graph: optional pre-passes outside the "
+                                  "MI355X hot-path scope (SURVEY.md section 8, rows out of scope)")
+    eng = _engine or Engine()  # raises HipUnavailableError without a GPU: no CPU fallback
+    anisotropy = np.array(anisotropy, dtype=np.float32)
+
+    all_labels = format_labels(all_labels, in_place=in_place)
+    all_labels = apply_object_mask(all_labels, object_ids)
+    if all_labels.size <= dust_threshold:
+        return {}
+    minlabel, maxlabel = all_labels.min(), all_labels.max()
+    if minlabel == 0 and maxlabel == 0:
+        return {}
+
+    cc_labels, nlabels, remapping = compute_cc_labels(all_labels)
+    shape = cc_labels.shape
+    before = _points_to_labels(extra_targets_before, cc_labels)
+    after = _points_to_labels(extra_targets_after, cc_labels)
+
+    return skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
+                          fix_branching, fix_borders, before, after, black_border=(minlabel == maxlabel),
+                          timings=_timings)
+
+
+def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
+                   fix_branching, fix_borders, before, after, black_border, timings=None,
+                   rank=0, world=1):
+    """Everything after the connected components (intake.py:174-221 + skeletonize_subset :434-517)."""
+    shape = cc_labels.shape
+    label_bytes = 4
+    d_cc = eng.to_device(cc_labels)
+    d_dbf = eng.edt(d_cc, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
+    counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, label_bytes, d_dbf, shape, nlabels)
+
+    # intake.py:198-201
+    cc_segids = [sid for sid in range(1, nlabels + 1) if counts[sid] > dust_threshold]
+    border_targets = defaultdict(list)
+    if fix_borders:
+        from .border import compute_border_targets
+        border_targets = compute_border_targets(cc_labels, anisotropy, eng=eng)  # intake.py:207
+
+    params = dict(TRACE_DEFAULTS)
+    params.update(teasar_params)
+    if world > 1:
+        cc_segids = cc_segids[rank::world]  # intake.py:388-389 round robin
+
+    lazy_slices = {}
+    segids, roots, tb, ta = [], [], [], []
+    for segid in cc_segids:
+        # intake.py:454-456: bounding boxes of volume <= 1 are skipped (never true above dust_threshold >= 1)
+        if counts[segid] <= 1 and dust_threshold < 1:
+            continue
+        if dbf_max[segid] > params["soma_detection_threshold"]:
+            _soma_probe(cc_labels, segid, remapping, float(dbf_max[segid]), params, lazy_slices)
+        mtb, mta, root = [], [], NONE32
+        if len(border_targets[segid]) > 0:                      # intake.py:486-488
+            mtb = [_loc(p, shape) for p in border_targets[segid]]
+            root = mtb.pop()
+        if segid in before and len(before[segid]) > 0:
+            mtb.extend(_loc(p, shape) for p in before[segid])
+        if segid in after and len(after[segid]) > 0:
+            mta.extend(_loc(p, shape) for p in after[segid])
+        segids.append(segid)
+        roots.append(root)
+        tb.append(mtb)
+        ta.append(mta)
+
+    sel = np.asarray(segids, dtype=np.int64)
+    res = eng.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],
+                         dbf_max[sel] if len(sel) else [], first_index[sel] if len(sel) else [],
+                         xmin[sel] if len(sel) else [], xmax[sel] if len(sel) else [], roots, tb, ta, params,
+                         fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings)
+    return assemble(res, shape, anisotropy, remapping)
+
+
+def _soma_probe(cc_labels, segid, remapping, dbf_max, params, cache):
+    """kimimaro/trace.py:108-119 for a label whose DBF max exceeds soma_detection_threshold.
+
+    Row f3 (next): the reference fills internal voids (fill_voids.fill) and, only if something was
+    filled, recomputes the DBF; soma mode proper starts above soma_acceptance_threshold.  Until the GPU
+    flood fill lands, the void test is a host stand-in (scipy.ndimage.binary_fill_holes on the crop,
+    6-connected background like fill_voids); a label without voids continues on the HIP path unchanged,
+    which is exactly what the reference does."""
+    import scipy.ndimage
+    if dbf_max > params["soma_acceptance_threshold"]:
+        raise NotImplementedError(
+            "label %r: DBF max %.1f exceeds soma_acceptance_threshold %.1f -- soma mode "
+            "(kimimaro/trace.py:119-134,160-168,246-251; row f3) is not on the HIP path yet" % (
+                remapping[segid], dbf_max, params["soma_acceptance_threshold"]))
+    if "slices" not in cache:
+        cache["slices"] = scipy.ndimage.find_objects(cc_labels.T)
+    slc = cache["slices"][segid - 1][::-1]
+    crop = cc_labels[slc] == segid
+    filled = scipy.ndimage.binary_fill_holes(crop)
+    if np.count_nonzero(filled) != np.count_nonzero(crop):
+        raise NotImplementedError(
+            "label %r has internal voids and DBF max above soma_detection_threshold: the void fill + "
+            "crop re-EDT (kimimaro/trace.py:109-117; row f3) is not on the HIP path yet" % (remapping[segid],))
+
+
+def paths_of(res, slot, shape):
+    """list of (n,3) integer voxel paths of task `slot`."""
+    sx, sy = shape[0], shape[1]
+    v0, l0, l1 = res["voff"][slot], res["loff"][slot], res["loff"][slot + 1]
+    out = []
+    pos = v0
+    for n in res["lens"][l0:l1]:
+        locs = res["verts"][pos:pos + n].astype(np.int64)
+        out.append(np.stack([locs % sx, (locs // sx) % sy, locs // (sx * sy)], axis=1))
+        pos += n
+    return out
+
+
+def assemble(res, shape, anisotropy, remapping):
+    """Skeleton assembly: kimimaro/trace.py:182-192 + intake.py:506-517, 587-593."""
+    sx, sy = shape[0], shape[1]
+    tasks = res["tasks"]
+    skeletons = defaultdict(list)
+    an = np.asarray(anisotropy, dtype=np.float32)
+    transform = np.array([[an[0], 0, 0, 0], [0, an[1], 0, 0], [0, 0, an[2], 0]], dtype=np.float32)
+    for slot in range(len(tasks)):
+        v0, v1 = res["voff"][slot], res["voff"][slot + 1]
+        if v1 == v0:
+            continue
+        locs = res["verts"][v0:v1].astype(np.int64)
+        lens = res["lens"][res["loff"][slot]:res["loff"][slot + 1]].astype(np.int64)
+        verts = np.stack([locs % sx, (locs // sx) % sy, locs // (sx * sy)], axis=1).astype(np.float32)
+        # Skeleton.from_path per path + simple_merge: consecutive edges inside each path
+        starts = np.concatenate([[0], np.cumsum(lens)])
+        eidx = np.arange(verts.shape[0] - 1)
+        is_break = np.zeros(verts.shape[0] - 1, dtype=bool)
+        is_break[starts[1:-1] - 1] = True
+        eidx = eidx[~is_break]
+        edges = np.stack([eidx, eidx + 1], axis=1).astype(np.uint32)
+        skel = Skeleton(verts, edges, radii=res["radii"][v0:v1]).consolidate()
+        if skel.empty():
+            continue
+        skel.transform = transform
+        orig = remapping[int(tasks["segid"][slot])]
+        skel.id = orig
+        skel.vertices = np.multiply(skel.vertices, an, dtype=np.float32)  # intake.py:513
+        skel.space = "physical"
+        skeletons[orig].append(skel)
+    merged = {}
+    for segid, skels in skeletons.items():
+        merged[segid] = Skeleton.simple_merge(skels).consolidate()
+    return merged

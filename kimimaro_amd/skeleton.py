@@ -1,0 +1,190 @@
+"""Minimal Skeleton container, attribute compatible with ``osteoid.Skeleton`` /
+``cloudvolume.Skeleton`` (the type ``kimimaro.skeletonize`` returns; reference
+kimimaro/trace.py:34,182-192 and kimimaro/intake.py:506-517,587-593).
+
+``osteoid`` is a third-party package that is not in the reference tree; the
+semantics below restate what the reference relies on:
+
+* ``from_path``     vertices = the path, edges = consecutive pairs.
+* ``simple_merge``  concatenate, offsetting edge indices.
+* ``consolidate``   ``np.unique(vertices, axis=0)`` (lexicographically sorted
+                    vertices), edges remapped, each edge sorted, rows sorted and
+                    uniqued, self loops dropped, radii / vertex_types taken from
+                    the first occurrence of each vertex.
+
+When ``osteoid`` is importable ``to_osteoid()`` hands back the real class.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Skeleton:
+    def __init__(self, vertices=None, edges=None, radii=None, vertex_types=None,
+                 segid=None, transform=None, space="voxel", extra_attributes=None):
+        self.id = segid
+        self.space = space
+        if vertices is None:
+            self.vertices = np.zeros((0, 3), dtype=np.float32)
+        else:
+            self.vertices = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
+        if edges is None:
+            self.edges = np.zeros((0, 2), dtype=np.uint32)
+        else:
+            self.edges = np.asarray(edges, dtype=np.uint32).reshape(-1, 2)
+        n = self.vertices.shape[0]
+        if radii is None:
+            self.radii = -1 * np.ones(n, dtype=np.float32)
+        else:
+            self.radii = np.asarray(radii, dtype=np.float32)
+        if vertex_types is None:
+            self.vertex_types = np.zeros(n, dtype=np.uint8)
+        else:
+            self.vertex_types = np.asarray(vertex_types, dtype=np.uint8)
+        if transform is None:
+            self.transform = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], dtype=np.float32)
+        else:
+            self.transform = np.asarray(transform, dtype=np.float32).reshape(3, 4)
+        self.extra_attributes = extra_attributes if extra_attributes is not None else [
+            {"id": "radius", "data_type": "float32", "num_components": 1},
+            {"id": "vertex_types", "data_type": "uint8", "num_components": 1},
+        ]
+
+    # -- construction -------------------------------------------------------
+    @classmethod
+    def from_path(cls, path):
+        path = np.asarray(path, dtype=np.float32).reshape(-1, 3)
+        if path.shape[0] == 0:
+            return cls()
+        n = path.shape[0]
+        edges = np.zeros((n - 1, 2), dtype=np.uint32)
+        edges[:, 0] = np.arange(n - 1)
+        edges[:, 1] = np.arange(1, n)
+        return cls(path, edges)
+
+    @classmethod
+    def simple_merge(cls, skeletons):
+        skeletons = list(skeletons)
+        if len(skeletons) == 0:
+            return cls()
+        if type(skeletons[0]) is np.ndarray:
+            skeletons = [skeletons]
+        ct = 0
+        edges = []
+        for skel in skeletons:
+            edges.append(skel.edges.astype(np.uint32) + np.uint32(ct))
+            ct += skel.vertices.shape[0]
+        return cls(
+            vertices=np.concatenate([s.vertices for s in skeletons], axis=0),
+            edges=np.concatenate(edges, axis=0),
+            radii=np.concatenate([s.radii for s in skeletons], axis=0),
+            vertex_types=np.concatenate([s.vertex_types for s in skeletons], axis=0),
+            segid=skeletons[0].id,
+            transform=skeletons[0].transform,
+            space=skeletons[0].space,
+        )
+
+    # -- queries ------------------------------------------------------------
+    def empty(self):
+        return self.vertices.size == 0 or self.edges.size == 0
+
+    def clone(self):
+        return Skeleton(self.vertices.copy(), self.edges.copy(), self.radii.copy(),
+                        self.vertex_types.copy(), self.id, self.transform.copy(), self.space)
+
+    def cable_length(self):
+        v1 = self.vertices[self.edges[:, 0]]
+        v2 = self.vertices[self.edges[:, 1]]
+        d = (v2 - v1).astype(np.float32)
+        d *= d
+        return float(np.sum(np.sqrt(np.sum(d, axis=1))))
+
+    def consolidate(self):
+        if self.empty():
+            return Skeleton(segid=self.id, transform=self.transform, space=self.space)
+        eff_nodes, uniq_idx, inverse = np.unique(
+            self.vertices, axis=0, return_index=True, return_inverse=True)
+        inverse = np.asarray(inverse).reshape(-1)
+        eff_edges = inverse[self.edges.astype(np.int64)]
+        eff_edges = np.sort(eff_edges, axis=1)
+        eff_edges = np.unique(eff_edges, axis=0)
+        eff_edges = eff_edges[eff_edges[:, 0] != eff_edges[:, 1]]
+        return Skeleton(eff_nodes, eff_edges.astype(np.uint32), self.radii[uniq_idx],
+                        self.vertex_types[uniq_idx], self.id, self.transform, self.space)
+
+    def components(self):
+        """Connected components as a list of Skeletons (used by tests)."""
+        n = self.vertices.shape[0]
+        parent = np.arange(n)
+
+        def find(i):
+            while parent[i] != i:
+                parent[i] = parent[parent[i]]
+                i = parent[i]
+            return i
+
+        for a, b in self.edges:
+            ra, rb = find(int(a)), find(int(b))
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+        roots = np.array([find(i) for i in range(n)])
+        out = []
+        for r in np.unique(roots):
+            sel = np.flatnonzero(roots == r)
+            remap = -np.ones(n, dtype=np.int64)
+            remap[sel] = np.arange(sel.size)
+            emask = roots[self.edges[:, 0]] == r
+            out.append(Skeleton(self.vertices[sel], remap[self.edges[emask]], self.radii[sel],
+                                self.vertex_types[sel], self.id, self.transform, self.space))
+        return out
+
+    def to_swc(self):
+        """SWC text (row f4, the format kimimaro_cli writes)."""
+        n = self.vertices.shape[0]
+        parent = -np.ones(n, dtype=np.int64)
+        adj = [[] for _ in range(n)]
+        for a, b in self.edges:
+            adj[int(a)].append(int(b))
+            adj[int(b)].append(int(a))
+        seen = np.zeros(n, dtype=bool)
+        order = []
+        for s in range(n):
+            if seen[s]:
+                continue
+            stack = [s]
+            seen[s] = True
+            while stack:
+                u = stack.pop()
+                order.append(u)
+                for v in adj[u]:
+                    if not seen[v]:
+                        seen[v] = True
+                        parent[v] = u
+                        stack.append(v)
+        newid = np.zeros(n, dtype=np.int64)
+        newid[order] = np.arange(1, n + 1)
+        lines = ["# SWC generated by kimimaro_amd", "# id type x y z radius parent"]
+        for u in order:
+            p = -1 if parent[u] < 0 else newid[parent[u]]
+            x, y, z = self.vertices[u]
+            lines.append("%d %d %.6f %.6f %.6f %.6f %d" % (
+                newid[u], int(self.vertex_types[u]), x, y, z, self.radii[u], p))
+        return "\n".join(lines) + "\n"
+
+    def to_osteoid(self):
+        try:
+            import osteoid
+        except ImportError:
+            return self
+        return osteoid.Skeleton(self.vertices, self.edges, self.radii, self.vertex_types,
+                                segid=self.id, transform=self.transform, space=self.space)
+
+    def __eq__(self, other):
+        return (isinstance(other, Skeleton) and self.id == other.id
+                and np.array_equal(self.vertices, other.vertices)
+                and np.array_equal(self.edges, other.edges)
+                and np.array_equal(self.radii, other.radii))
+
+    def __repr__(self):
+        return "Skeleton(segid=%r, vertices=%d, edges=%d, space=%r)" % (
+            self.id, self.vertices.shape[0], self.edges.shape[0], self.space)

@@ -1,0 +1,56 @@
+"""kimimaro_amd.trace.trace -- mirror of kimimaro.trace.trace (kimimaro/trace.py:36-194) for ONE
+binary object, running on the MI355X.  Used by the parity tests: same arguments, same return value
+(a Skeleton in voxel space with radii and the anisotropy transform)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import Engine, NONE32
+from .intake import TRACE_DEFAULTS, paths_of
+from .skeleton import Skeleton
+
+
+def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
+          soma_detection_threshold=1100, soma_acceptance_threshold=4000,
+          pdrf_scale=5000, pdrf_exponent=16, soma_invalidation_scale=0.5, soma_invalidation_const=0,
+          fix_branching=True, manual_targets_before=None, manual_targets_after=None, root=None,
+          max_paths=None, voxel_graph=None, return_paths=False, _engine=None, _return_raw=False):
+    if voxel_graph is not None:
+        raise NotImplementedError("voxel_graph is not supported on the HIP path")
+    eng = _engine or Engine()
+    labels = np.asarray(labels)
+    while labels.ndim < 3:
+        labels = labels[..., np.newaxis]
+        DBF = np.asarray(DBF)[..., np.newaxis]
+    shape = labels.shape
+    cc = np.asfortranarray((labels != 0).astype(np.uint32))
+    dbf = np.asfortranarray(DBF, dtype=np.float32)
+    d_cc = eng.to_device(cc)
+    d_dbf = eng.to_device(dbf)
+    counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, 4, d_dbf, shape, 1)
+    if counts[1] == 0:
+        return [] if return_paths else Skeleton()
+    if dbf_max[1] > soma_detection_threshold:
+        raise NotImplementedError("soma mode (kimimaro/trace.py:108-134) is not on the HIP path yet")
+    loc = lambda p: int(p[0]) + shape[0] * (int(p[1]) + shape[1] * int(p[2]))
+    tb = [[loc(p) for p in (manual_targets_before or [])]]
+    ta = [[loc(p) for p in (manual_targets_after or [])]]
+    r = [NONE32 if root is None else loc(root)]
+    params = dict(TRACE_DEFAULTS)
+    params.update(scale=scale, const=const, pdrf_scale=pdrf_scale, pdrf_exponent=pdrf_exponent)
+    res = eng.run_labels(d_cc, 4, d_dbf, shape, anisotropy, 1, [1], counts[1:2], dbf_max[1:2], first_index[1:2],
+                         xmin[1:2], xmax[1:2], r, tb, ta, params, fix_branching=fix_branching, max_paths=max_paths,
+                         return_fields=_return_raw)
+    if _return_raw:
+        return res
+    paths = paths_of(res, 0, shape)
+    if return_paths:
+        return paths
+    skel = Skeleton.simple_merge([Skeleton.from_path(p) for p in paths if len(p) > 0]).consolidate()
+    verts = skel.vertices.flatten().astype(np.uint32)
+    dz = dbf.copy(order="F")
+    dz[dz == 0] = np.inf  # zero2inf, trace.py:138 (radii are read from the inf-patched DBF)
+    skel.radii = dz[verts[::3], verts[1::3], verts[2::3]]
+    skel.transform = np.array([[anisotropy[0], 0, 0, 0], [0, anisotropy[1], 0, 0], [0, 0, anisotropy[2], 0]],
+                              dtype=np.float32)
+    return skel

@@ -1,0 +1,298 @@
+"""oracle.pipeline -- CPU restatement of kimimaro.trace.trace / kimimaro.skeletonize
+on top of oracle/libkimi_oracle.so.   TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows kimimaro/trace.py:36-267 and kimimaro/intake.py:58-221,434-517 line by
+line (same control flow, same per-label crop + mask, same LIFO target stacks),
+so that the HIP product path -- which works on whole-volume arrays and batches
+labels -- is checked against an independently structured implementation.
+
+Not restated (rows f2/f3 of SURVEY.md section 8 are handled where noted):
+soma mode needs fill_voids (scipy.ndimage.binary_fill_holes stand-in) and
+free_space_radius; voxel_graph, fill_holes, fix_avocados raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import numpy as np
+import scipy.ndimage
+
+import oracle as K
+from kimimaro_amd.skeleton import Skeleton
+
+DEFAULT_TEASAR_PARAMS = {  # kimimaro/intake.py:47-56
+    "scale": 1.5,
+    "const": 300,
+    "pdrf_scale": 100000,
+    "pdrf_exponent": 4,
+    "soma_acceptance_threshold": 3500,
+    "soma_detection_threshold": 750,
+    "soma_invalidation_const": 300,
+    "soma_invalidation_scale": 2,
+}
+
+
+class DimensionError(Exception):
+    pass
+
+
+def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
+          soma_detection_threshold=1100, soma_acceptance_threshold=4000,
+          pdrf_scale=5000, pdrf_exponent=16,
+          soma_invalidation_scale=0.5, soma_invalidation_const=0,
+          fix_branching=True, manual_targets_before=None, manual_targets_after=None,
+          root=None, max_paths=None, voxel_graph=None, stats=None, return_paths=False):
+    """kimimaro/trace.py:36-194."""
+    if voxel_graph is not None:
+        raise NotImplementedError("voxel_graph is not restated in the oracle")
+    manual_targets_before = list(manual_targets_before or [])
+    manual_targets_after = list(manual_targets_after or [])
+    dbf_max = np.max(DBF)
+    labels = np.asfortranarray(labels)
+    if labels.dtype == bool:
+        labels = labels.view(np.uint8)
+    labels = np.asfortranarray(labels, dtype=np.uint8).copy(order="F")
+    DBF = np.asfortranarray(DBF, dtype=np.float32).copy(order="F")
+
+    if dbf_max > soma_detection_threshold:  # trace.py:108-119
+        filled = scipy.ndimage.binary_fill_holes(labels)  # stand-in for fill_voids.fill (6-connected background)
+        num_voxels_filled = int(np.count_nonzero(filled)) - int(np.count_nonzero(labels))
+        if num_voxels_filled > 0:
+            labels = np.asfortranarray(filled.astype(np.uint8))
+            DBF = K.edt(labels, anisotropy, black_border=bool(np.all(labels)))
+        dbf_max = np.max(DBF)
+        if dbf_max > soma_acceptance_threshold:
+            raise NotImplementedError("soma mode (row f3) is not restated in the oracle yet")
+
+    if root is None:
+        root = find_root(labels, anisotropy)
+    if root is None:
+        return Skeleton() if not return_paths else []
+    root = tuple(int(v) for v in root)
+
+    DBF = K.zero2inf(DBF)  # trace.py:138
+    DAF, target = K.euclidean_distance_field(labels, root, anisotropy)  # :139-145
+    DAF = K.inf2zero(DAF)  # :146
+    order = K.target_order(labels, DAF)  # CachedTargetFinder.__init__ :147
+    finder = _TargetFinder(order, labels.shape)
+    PDRF = K.compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, DAF[target])  # :148
+
+    if not fix_branching:
+        parents = K.parental_field(PDRF, root)  # :155
+    else:
+        parents = PDRF
+
+    if len(manual_targets_before) == 0:  # :171-172
+        manual_targets_before.append(target)
+
+    paths = compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
+                          fix_branching, manual_targets_before, manual_targets_after,
+                          max_paths, stats)
+    if return_paths:
+        return paths
+
+    skel = Skeleton.simple_merge([Skeleton.from_path(p) for p in paths if len(p) > 0]).consolidate()
+    verts = skel.vertices.flatten().astype(np.uint32)
+    skel.radii = DBF[verts[::3], verts[1::3], verts[2::3]]
+    skel.transform = np.array([[anisotropy[0], 0, 0, 0], [0, anisotropy[1], 0, 0],
+                               [0, 0, anisotropy[2], 0]], dtype=np.float32)
+    return skel
+
+
+class _TargetFinder:
+    """CachedTargetFinder.find_target, skeletontricks.pyx:1008-1045."""
+
+    def __init__(self, order, shape):
+        self.order = order
+        self.head = 0
+        self.shape = shape
+
+    def find_target(self, labels):
+        flat = labels.ravel(order="F")
+        o = self.order
+        h = self.head
+        n = o.size
+        # chunked scan for the first index whose mask byte is still set
+        while h < n:
+            chunk = o[h:h + 4096]
+            hit = np.flatnonzero(flat[chunk])
+            if hit.size:
+                h += int(hit[0])
+                self.head = h
+                return K.pt_of(o[h], self.shape)
+            h += chunk.size
+        self.head = n
+        return None
+
+
+def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
+                  fix_branching, manual_targets_before, manual_targets_after, max_paths, stats=None):
+    """kimimaro/trace.py:196-267 (non-soma branch)."""
+    paths = []
+    valid_labels = int(np.count_nonzero(labels))
+    root = tuple(root)
+    if max_paths is None:
+        max_paths = valid_labels
+    if len(manual_targets_before) + len(manual_targets_after) >= max_paths:
+        return []
+    parents[root] = 0  # initial rail, :220
+    while (valid_labels > 0 or manual_targets_before or manual_targets_after) and len(paths) < max_paths:
+        if manual_targets_before:
+            target = manual_targets_before.pop()
+        elif valid_labels == 0:
+            target = manual_targets_after.pop()
+        else:
+            target = finder.find_target(labels)
+        target = tuple(int(v) for v in target)
+        if fix_branching:
+            path, settled = K.railroad(parents, target, return_stats=True)
+        else:
+            path = K.path_from_parents(parents, target)
+            settled = 0
+        ops = 0
+        if valid_labels > 0:
+            invalidated, labels, ops = K.roll_invalidation_ball_inside_component(
+                labels, DBF, scale, const, anisotropy, path, return_stats=True)
+            valid_labels -= invalidated
+        if fix_branching:
+            parents[path[:, 0], path[:, 1], path[:, 2]] = 0.0  # :261-263
+        if stats is not None:
+            stats["paths"] = stats.get("paths", 0) + 1
+            stats["settled"] = stats.get("settled", 0) + int(settled)
+            stats["heap_pushes"] = stats.get("heap_pushes", 0) + int(ops)
+            stats["path_vertices"] = stats.get("path_vertices", 0) + int(len(path))
+        paths.append(path)
+    return paths
+
+
+def find_root(labels, anisotropy):
+    """kimimaro/trace.py:291-308."""
+    any_voxel = K.first_label(labels)
+    if any_voxel is None:
+        return None
+    _, target = K.euclidean_distance_field(labels, any_voxel, anisotropy)
+    return target
+
+
+# ---------------------------------------------------------------------------
+# intake.py restatement
+
+
+def format_labels(labels):
+    """kimimaro/intake.py:315-342."""
+    labels = np.copy(labels, order="F")
+    if labels.dtype == bool:
+        labels = labels.view(np.uint8)
+    original_shape = labels.shape
+    while labels.ndim < 3:
+        labels = labels[..., np.newaxis]
+    while labels.ndim > 3:
+        if labels.shape[-1] == 1:
+            labels = labels[..., 0]
+        else:
+            raise DimensionError(
+                "Input labels may be no more than three non-trivial dimensions. Got: {}".format(original_shape))
+    return labels
+
+
+def compute_cc_labels(all_labels):
+    """kimimaro/utility.py:58-83: returns (cc_labels, {cc id: original id})."""
+    cc, n = K.connected_components(all_labels)
+    first = np.zeros(n + 1, dtype=np.int64)
+    flat_cc = cc.ravel(order="F")
+    idx = np.flatnonzero(flat_cc)
+    # first occurrence of each component -> original label there
+    uniq, first_idx = np.unique(flat_cc[idx], return_index=True)
+    orig = all_labels.ravel(order="F")[idx[first_idx]]
+    remap = {int(u): orig[i].item() for i, u in enumerate(uniq)}
+    return cc, remap
+
+
+def find_objects(cc_labels):
+    """kimimaro/utility.py:85-102."""
+    all_slices = scipy.ndimage.find_objects(cc_labels.T)
+    return [(s and s[::-1]) for s in all_slices]
+
+
+def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 1, 1),
+                object_ids=None, dust_threshold=1000, progress=False, fix_branching=True,
+                in_place=False, fix_borders=True, parallel=1, parallel_chunk_size=100,
+                extra_targets_before=[], extra_targets_after=[], fill_holes=False,
+                fix_avocados=False, voxel_graph=None, stats=None):
+    """kimimaro/intake.py:58-221 + skeletonize_subset :434-517 (serial path)."""
+    if fill_holes or fix_avocados or voxel_graph is not None:
+        raise NotImplementedError("fill_holes / fix_avocados / voxel_graph are out of the restated scope")
+    anisotropy = np.array(anisotropy, dtype=np.float32)
+    all_labels = format_labels(all_labels)
+    if object_ids is not None:
+        all_labels = all_labels * np.isin(all_labels, list(object_ids)).astype(all_labels.dtype)
+    if all_labels.size <= dust_threshold:
+        return {}
+    minlabel, maxlabel = all_labels.min(), all_labels.max()
+    if minlabel == 0 and maxlabel == 0:
+        return {}
+    cc_labels, remapping = compute_cc_labels(all_labels)
+
+    before = _points_to_labels(extra_targets_before, cc_labels)
+    after = _points_to_labels(extra_targets_after, cc_labels)
+
+    all_dbf = K.edt(cc_labels, anisotropy, black_border=(minlabel == maxlabel))  # intake.py:174-185
+
+    counts = np.bincount(cc_labels.ravel(order="F"))
+    cc_segids = [i for i in range(1, counts.size) if counts[i] > dust_threshold]
+    all_slices = find_objects(cc_labels)
+
+    border_targets = defaultdict(list)
+    if fix_borders:
+        from kimimaro_amd.border import compute_border_targets
+        border_targets = compute_border_targets(cc_labels, anisotropy, edt2d=K.edt)
+
+    skeletons = defaultdict(list)
+    for segid in cc_segids:
+        slices = all_slices[segid - 1]
+        if slices is None:
+            continue
+        minpt = np.array([s.start for s in slices], dtype=np.int64)
+        vol = np.prod([s.stop - s.start for s in slices])
+        if vol <= 1:
+            continue
+        labels = (cc_labels[slices] == segid)
+        dbf = np.where(labels, all_dbf[slices], 0.0)
+        mtb, mta, root = [], [], None
+
+        def translate(targets):
+            t = np.array(targets, dtype=np.int64).reshape(-1, 3) - minpt
+            return [tuple(int(v) for v in p) for p in t]
+
+        if len(border_targets[segid]) > 0:
+            mtb = translate(border_targets[segid])
+            root = mtb.pop()
+        if segid in before and len(before[segid]) > 0:
+            mtb.extend(translate(before[segid]))
+        if segid in after and len(after[segid]) > 0:
+            mta.extend(translate(after[segid]))
+
+        skel = trace(labels, dbf, anisotropy=anisotropy, fix_branching=fix_branching,
+                     manual_targets_before=mtb, manual_targets_after=mta, root=root,
+                     stats=stats, **teasar_params)
+        if skel.empty():
+            continue
+        skel.vertices += minpt.astype(skel.vertices.dtype)
+        orig = remapping[segid]
+        skel.id = orig
+        skel.vertices = np.multiply(skel.vertices, anisotropy, dtype=np.float32)
+        skel.space = "physical"
+        skeletons[orig].append(skel)
+
+    merged = {}
+    for segid, skels in skeletons.items():  # intake.py:587-593
+        merged[segid] = Skeleton.simple_merge(skels).consolidate()
+    return merged
+
+
+def _points_to_labels(pts, cc_labels):
+    mapping = defaultdict(list)
+    for pt in pts:
+        pt = tuple(int(v) for v in pt)
+        mapping[int(cc_labels[pt])].append(pt)
+    return mapping

@@ -1,0 +1,45 @@
+"""Deterministic synthetic shapes shared by the tests (numpy only)."""
+import numpy as np
+
+
+def random_walk_tube(shape, seed, steps=40, step=3.0, radius=(1.5, 4.0)):
+    """A blobby random-walk tube: union of balls along a random walk (uint8 mask, F order)."""
+    rng = np.random.default_rng(seed)
+    sx, sy, sz = shape
+    mask = np.zeros(shape, dtype=np.uint8, order="F")
+    p = np.array([sx / 2, sy / 2, sz / 2], dtype=np.float64)
+    gx, gy, gz = np.meshgrid(np.arange(sx), np.arange(sy), np.arange(sz), indexing="ij")
+    d = rng.normal(size=3)
+    for _ in range(steps):
+        d = d + 0.7 * rng.normal(size=3)
+        d /= np.linalg.norm(d) + 1e-9
+        p = np.clip(p + step * d, 1, np.array(shape) - 2)
+        r = rng.uniform(*radius)
+        mask[(gx - p[0]) ** 2 + (gy - p[1]) ** 2 + (gz - p[2]) ** 2 <= r * r] = 1
+    return mask
+
+
+def voronoi_labels(shape, nlabels, seed, pts_per_label=4, step=6.0, anisotropy=(1, 1, 1), dtype=np.uint32):
+    """Dense 'neurite' tessellation (SURVEY.md 8d recipe, small): every voxel gets the label of
+    the nearest point of `nlabels` random-walk chains under the anisotropic metric."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    an = np.asarray(anisotropy, dtype=np.float64)
+    shp = np.asarray(shape, dtype=np.float64)
+    pts, owner = [], []
+    for l in range(nlabels):
+        p = rng.uniform(0, 1, 3) * shp
+        for _ in range(pts_per_label):
+            pts.append(p.copy())
+            owner.append(l)
+            stepv = rng.normal(size=3)
+            stepv /= np.linalg.norm(stepv) + 1e-9
+            p = np.clip(p + step * stepv * (an.min() / an), 0, shp - 1)
+    pts = np.asarray(pts) * an
+    tree = cKDTree(pts)
+    gx, gy, gz = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    q = np.stack([gx.ravel(order="F"), gy.ravel(order="F"), gz.ravel(order="F")], axis=1) * an
+    _, idx = tree.query(q)
+    ids = 1000 + rng.permutation(nlabels)
+    lab = ids[np.asarray(owner)[idx]].astype(dtype)
+    return lab.reshape(shape, order="F")

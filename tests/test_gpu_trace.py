@@ -1,0 +1,79 @@
+"""GPU parity: the per-label TEASAR trace on the MI355X vs the oracle pipeline (paths bit exact)."""
+import numpy as np
+import pytest
+
+from shapes import random_walk_tube, voronoi_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from kimimaro_amd.engine import Engine
+    return Engine()
+
+
+def biggest_component(mask):
+    import oracle
+    cc, n = oracle.connected_components(mask)
+    big = np.argmax(np.bincount(cc.ravel())[1:]) + 1
+    return np.asfortranarray((cc == big).astype(np.uint8))
+
+
+TUBES = [
+    (0, (1, 1, 1), dict(scale=1.5, const=2, pdrf_scale=100000, pdrf_exponent=4)),
+    (1, (16, 16, 40), dict(scale=4, const=8, pdrf_scale=100000, pdrf_exponent=4)),
+    (2, (4, 4, 40), dict(scale=0.5, const=24, pdrf_scale=5000, pdrf_exponent=16)),
+    (3, (1, 1, 1), dict(scale=1.5, const=0.5, pdrf_scale=100000, pdrf_exponent=4)),
+    (4, (16, 16, 40), dict(scale=1.5, const=300, pdrf_scale=100000, pdrf_exponent=4)),
+    (5, (2, 3, 5), dict(scale=2, const=4, pdrf_scale=100000, pdrf_exponent=8)),
+]
+
+
+@pytest.mark.parametrize("seed,an,params", TUBES)
+def test_trace_paths_match_oracle(eng, seed, an, params):
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    m = biggest_component(random_walk_tube((48, 44, 40), 2000 + seed, steps=60, step=3.0, radius=(1.2, 5.0)))
+    dbf = oracle.edt(m, an)
+    want = P.trace(m, dbf, anisotropy=an, return_paths=True, **params)
+    got = trace(m, dbf, anisotropy=an, return_paths=True, _engine=eng, **params)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
+
+
+def test_trace_skeleton_fields(eng):
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    an = (16, 16, 40)
+    m = biggest_component(random_walk_tube((40, 40, 40), 77, steps=50))
+    dbf = oracle.edt(m, an)
+    params = dict(scale=1.5, const=30, pdrf_scale=100000, pdrf_exponent=4)
+    a = trace(m, dbf, anisotropy=an, _engine=eng, **params)
+    b = P.trace(m, dbf, anisotropy=an, **params)
+    np.testing.assert_array_equal(a.vertices, b.vertices)
+    np.testing.assert_array_equal(a.edges, b.edges)
+    np.testing.assert_array_equal(a.radii, b.radii)
+    np.testing.assert_array_equal(a.transform, b.transform)
+
+
+@pytest.mark.parametrize("an,nlab,shape", [((1, 1, 1), 8, (64, 64, 64)), ((16, 16, 40), 20, (96, 96, 40))])
+def test_skeletonize_matches_oracle(eng, an, nlab, shape):
+    import kimimaro_amd
+    from oracle import pipeline as P
+    lab = voronoi_labels(shape, nlab, seed=11, pts_per_label=5, step=10.0, anisotropy=an)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 4 * an[0]
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=False,
+                                   progress=False, _engine=eng)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=False)
+    assert sorted(got.keys()) == sorted(want.keys())
+    assert len(got) > 0
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+        assert got[k].space == "physical" and got[k].id == k
