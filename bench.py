@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py -- labels/s of the MI355X TEASAR hot path on BASELINE.json's workload.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over the synthetic volume with the connected-component labels
+ALREADY RESIDENT IN HBM: whole-volume EDT -> per-label statistics -> (border targets) -> find_root ->
+DAF -> PDRF -> TEASAR path loop for every component -> D2H of the paths -> Skeleton assembly ->
+(N > 1) all-gather-v of the skeletons.  Host-side work that precedes it in kimimaro.skeletonize
+(format_labels, connected components: SURVEY.md section 8 row f1, still host code) is outside the
+timed region and reported separately (`preamble_s`).
+
+Workload (config.workload): "c3" = 512x512x512, 2124 chains, anisotropy (16,16,40), default
+teasar_params, dust_threshold=1000, fix_borders=True, fix_branching=True  (BASELINE.json configs[2],
+the configuration the metric is quoted on).  "c2" = 512x512x100 / 333 labels (configs[1]).
+The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
+so the volume is synthetic: data = "synthetic".
+
+Extra objects on the JSON line:
+  roofline      EDT pass kernel (the kernel BASELINE.json's metric names): algorithmic bytes / the
+                pass duration measured with HIP events on the launch stream (kh_edt_timed).
+  roofline_trace  the per-label path kernel (where the wall clock goes): SURVEY 8d per-label bytes.
+  cpu_baseline  the oracle (CPU restatement, 1 core) on a bounded sample of the same labels.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (shape, chains, points per chain, seed, anisotropy)
+    "c1": ((64, 64, 64), 8, 4, 1, (1, 1, 1)),
+    "c2": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
+    "c3": ((512, 512, 512), 2124, 16, 3, (16, 16, 40)),
+    "mini": ((128, 128, 64), 40, 8, 4, (16, 16, 40)),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_volume(name):
+    """SURVEY.md 8d recipe: dense 'neurite' tessellation = nearest chain point under the anisotropic
+    metric, label ids 1000 + perm(i).  Deterministic (np.random.default_rng(seed))."""
+    from scipy.spatial import cKDTree
+    shape, nchains, npts, seed, an = WORKLOADS[name]
+    rng = np.random.default_rng(seed)
+    anf = np.asarray(an, dtype=np.float64)
+    shp = np.asarray(shape, dtype=np.float64)
+    step = np.array([24.0, 24.0, 24.0 * anf[0] / anf[2]]) if name != "c1" else np.array([10.0, 10.0, 10.0])
+    pts, owner = [], []
+    for l in range(nchains):
+        p = rng.uniform(0, 1, 3) * shp
+        for _ in range(npts):
+            pts.append(p.copy())
+            owner.append(l)
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d) + 1e-9
+            p = np.clip(p + step * d, 0, shp - 1)
+    tree = cKDTree(np.asarray(pts) * anf)
+    ids = (1000 + rng.permutation(nchains)).astype(np.uint32)
+    owner = np.asarray(owner)
+    lab = np.empty(shape, dtype=np.uint32, order="F")
+    gx, gy = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+    base = np.stack([gx.ravel(order="F") * anf[0], gy.ravel(order="F") * anf[1]], axis=1)
+    for z in range(shape[2]):  # per slab: bounded host memory
+        q = np.concatenate([base, np.full((base.shape[0], 1), z * anf[2])], axis=1)
+        _, idx = tree.query(q, workers=-1)
+        lab[:, :, z] = ids[owner[idx]].reshape(shape[0], shape[1], order="F")
+    return lab, an
+
+
+def cpu_baseline(cc_labels, remapping, an, params, dust_threshold, budget_s=15.0):
+    """The oracle (oracle/kimi_oracle.c via oracle.pipeline.trace) on one core, label by label on the
+    label's bounding box grown by one voxel (the EDT of the label's own voxels is exact there), until
+    `budget_s` seconds of CPU work are spent.  Reported baseline only -- never the thing measured."""
+    import scipy.ndimage
+    import oracle
+    from oracle import pipeline as P
+    counts = np.bincount(cc_labels.ravel(order="K"))
+    segids = [i for i in range(1, counts.size) if counts[i] > dust_threshold]
+    rng = np.random.default_rng(0)
+    rng.shuffle(segids)
+    slices = scipy.ndimage.find_objects(cc_labels.T)
+    t0 = time.perf_counter()
+    done = 0
+    vox = 0
+    for sid in segids:
+        slc = slices[sid - 1][::-1]
+        grown = tuple(slice(max(0, s.start - 1), min(n, s.stop + 1)) for s, n in zip(slc, cc_labels.shape))
+        crop = np.asfortranarray(cc_labels[grown])
+        dbf = oracle.edt(crop, an, black_border=False)
+        mask = crop == sid
+        dbf = np.where(mask, dbf, 0.0).astype(np.float32)
+        P.trace(mask, dbf, anisotropy=an, fix_branching=True, **params)
+        done += 1
+        vox += int(counts[sid])
+        if time.perf_counter() - t0 > budget_s and done >= 4:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "labels/s", "cores": 1, "kind": "port",
+            "sample": "%d of %d labels (%d voxels), EDT on bbox+1 and full trace per label, %.1f s of CPU, "
+                      "seeded shuffle" % (done, len(segids), vox, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("KIMI_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fix-borders", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import kimimaro_amd
+    from kimimaro_amd import _abi, intake
+    from kimimaro_amd.engine import Engine
+    from kimimaro_amd.distributed import gather_skeletons
+
+    eng = Engine()
+    lab, an = make_volume(args.workload)
+    shape = lab.shape
+    an = np.asarray(an, dtype=np.float32)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    dust = 1000
+    fix_borders = not args.no_fix_borders
+
+    t = time.perf_counter()
+    lab = intake.format_labels(lab, in_place=True)
+    cc_labels, nlabels, remapping = intake.compute_cc_labels(lab)
+    preamble_s = time.perf_counter() - t
+    d_cc = eng.to_device(cc_labels)  # resident in HBM before the timed region
+    from collections import defaultdict
+    empty = defaultdict(list)
+
+    result = {}
+
+    def step():
+        local = intake.skeletonize_cc(eng, cc_labels, nlabels, remapping, params, an, dust, True, fix_borders,
+                                      empty, empty, black_border=False, rank=rank, world=world, d_cc=d_cc)
+        if world > 1:
+            local = gather_skeletons(local, device=eng.device)
+        result["skels"] = local
+        return local
+
+    for _ in range(args.warmup):
+        step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    nskel = len(result["skels"])
+    counts = np.bincount(cc_labels.ravel(order="K"))
+    ncomp = int((counts[1:] > dust).sum())
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    value = ncomp / (ms_per_step / 1e3)
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the EDT pass kernels: HIP events on the launch stream (kh_edt_timed)
+    import ctypes as C
+    nvox = int(np.prod(shape))
+    out = eng.empty(nvox, torch.float32)
+    ws = eng.empty(nvox, torch.float32)
+    ms3 = (C.c_float * 3)()
+    acc = np.zeros(3)
+    reps = 10
+    for i in range(reps + 2):
+        _abi.check(eng.lib.kh_edt_timed(eng.ptr(d_cc), 4, shape[0], shape[1], shape[2], float(an[0]), float(an[1]),
+                                        float(an[2]), 0, eng.ptr(ws), eng.ptr(out), eng.stream(), ms3))
+        if i >= 2:
+            acc += np.array(list(ms3))
+    pass_ms = acc / reps
+    L = 4
+    pass_bytes = np.array([(L + 4) * nvox, (L + 8) * nvox, (L + 8) * nvox], dtype=np.float64)
+    k = int(np.argmax(pass_ms))
+    names = ["edt_x_kernel<uint32>", "edt_axis_kernel<uint32> (y pass)", "edt_axis_kernel<uint32> (z pass)"]
+    achieved = pass_bytes[k] / (pass_ms[k] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
+                "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
+                "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
+
+    # ---- the path kernel: per-label algorithmic bytes of SURVEY 8d with Vc := Nf (no crops here)
+    import kimimaro_amd.engine as E
+    tk = E.LAST_TASKS
+    timings = []
+    intake.skeletonize_cc(eng, cc_labels, nlabels, remapping, params, an, dust, True, fix_borders, empty, empty,
+                          black_border=False, d_cc=d_cc, timings=timings)
+    phases = {}
+    prev = None
+    for name, ts in timings:
+        if prev is not None:
+            phases[name] = round(ts - prev, 4)
+        prev = ts
+    tk = E.LAST_TASKS
+    nf = tk["count"].astype(np.float64).sum()
+    settled = tk["stat_settled"].astype(np.float64).sum()
+    trace_bytes = (4 + 9) * nf + 10 * nf + 12 * nf + 12 * nf + 12 * settled + 2 * nf
+    tr_s = phases.get("paths", float("nan"))
+    roofline_trace = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / tr_s / 1e9, 3),
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / tr_s / 1e9 / HBM_PEAK_GBS, 6),
+                      "traffic": None, "seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
+                      "note": "latency bound: exact emulation of the reference's sequential heap flood per label"}
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            cpu = cpu_baseline(cc_labels, remapping, an, params, dust)
+        except Exception as e:  # the baseline must never take the bench line down
+            cpu = {"value": None, "unit": "labels/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    line = {
+        "metric": "labels/sec on a dense connectomics-shaped volume (skeletonize hot path, labels resident in HBM)",
+        "value": round(value, 3), "unit": "labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "
+                               "default teasar_params, fix_branching=True, fix_borders=%s, dust_threshold=%d"
+                               % (args.workload, shape[0], shape[1], shape[2], WORKLOADS[args.workload][1], ncomp,
+                                  tuple(float(a) for a in an), fix_borders, dust),
+                   "parallelism": "labels round-robin over %d GPU(s), skeleton all-gather-v" % world},
+        "skeletons": nskel, "preamble_s": round(preamble_s, 3), "phases_s": phases,
+        "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

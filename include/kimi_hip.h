@@ -56,6 +56,12 @@ int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t 
            float wx, float wy, float wz, int black_border,
            float* workspace, float* out, void* stream);
 
+/* kh_edt with each pass bracketed by HIP events on `stream`; ms3 (HOST pointer) receives the
+ * x / y / z pass durations in milliseconds.  Synchronises the stream (measurement only).       */
+int kh_edt_timed(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
+                 float wx, float wy, float wz, int black_border,
+                 float* workspace, float* out, void* stream, float* ms3);
+
 /* ---- preamble statistics on the device (fastremap.unique counts intake.py:198,
  * np.max(DBF) trace.py:100, first_label skeletontricks.pyx:307-326, x extent of
  * scipy.ndimage.find_objects utility.py:85-102) ------------------------------------
@@ -106,7 +112,12 @@ typedef struct kh_label_t {
   uint32_t status;       /* out: KH_ST_* bits */
   uint32_t stat_settled; /* out: sum of voxels touched by the railroad searches */
   uint32_t stat_heap_pushes; /* out (low 32 bits) */
-  uint32_t pad;
+  uint32_t cyc_target;   /* out: shader kilo-cycles spent in the target finder */
+  uint32_t cyc_rail;     /* out: ... in railroad search + back-track */
+  uint32_t cyc_inval;    /* out: ... in the invalidation flood, of which: */
+  uint32_t cyc_pop;      /* out:   heap pops */
+  uint32_t cyc_push;     /* out:   heap pushes */
+  uint32_t cyc_fire;     /* out:   neighbour evaluation of live pops */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
@@ -114,14 +125,15 @@ typedef struct kh_label_t {
  * distance field from task.source over its label (26-connected, anisotropic edge
  * lengths, f32 accumulation) is written into `field` at the label's voxels (other
  * voxels untouched); task.max_loc / max_val receive the farthest voxel (ties ->
- * smallest linear index).  queues: device u64[...] scratch addressed by q_offset (4 lists
- * of q_capacity entries per task).
+ * smallest linear index).  queues: device u32[...] scratch addressed by q_offset (4 lists
+ * of q_capacity >= count entries per task); qstate: u8 per voxel, all zero on entry and on exit
+ * (two membership bits per voxel keep every work list bounded by the label size).
  * mode 0: source = task.source.
  * mode 1 (find_root, trace.py:291-308): only tasks with root == 0xFFFFFFFF run; afterwards
  *         task.root = max_loc.   mode 2 (DAF, trace.py:139-145): source = task.root.         */
 int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint32_t* lists, const uint32_t* nbrmask,
                  int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
-                 float* field, uint64_t* queues, void* stream);
+                 float* field, uint8_t* qstate, uint32_t* queues, void* stream);
 
 /* ---- a3+a5: zero2inf / inf2zero / compute_pdrf fused, whole volume ------------------
  * replaces kimimaro/trace.py:138,146,148 (skeletontricks.pyx:177-224, trace.py:315-356).
@@ -141,14 +153,16 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * pdrf: mutated (rails are zeroed); dist: f32 scratch volume, must be +inf on entry and
  * is +inf again on exit; list_daf: DAF gathered in list order (target finder keys).
  * Paths are written as linear indices, rail end first, into path_vertices with
- * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).       */
+ * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).
+ * qstate as for kh_edf_batch.  lds_heap_nodes: how many top nodes of each label's invalidation heap
+ * live in LDS (12 bytes each; trades occupancy against heap latency).                         */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
-                   const uint32_t* nbrmask, const void* labels, int label_bytes,
+                   const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
-                   const float* dbf, float* pdrf, float* dist, uint8_t* alive,
+                   const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                    const uint32_t* manual_targets, float scale, float constant,
-                   uint64_t* queues, float* heap_keys, uint64_t* heap_payload,
-                   uint32_t* path_vertices, uint32_t* path_lengths, void* stream);
+                   uint32_t* queues, float* heap_keys, uint64_t* heap_payload,
+                   uint32_t* path_vertices, uint32_t* path_lengths, int lds_heap_nodes, void* stream);
 
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
 
 # every symbol include/kimi_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_label_stats", "kh_scatter_lists",
+    "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
     "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
     "kh_gather_f32", "kh_init_alive", "kh_invalidate_cube", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
@@ -29,16 +29,18 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 26 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 31 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
     ("q_offset", "<u4"), ("q_capacity", "<u4"), ("heap_offset", "<u4"), ("heap_capacity", "<u4"),
     ("path_offset", "<u4"), ("path_capacity", "<u4"), ("tgt_offset", "<u4"), ("n_before", "<u4"),
     ("n_after", "<u4"), ("max_paths", "<u4"), ("n_paths", "<u4"), ("n_vertices", "<u4"),
-    ("status", "<u4"), ("stat_settled", "<u4"), ("stat_heap_pushes", "<u4"), ("pad", "<u4"),
+    ("status", "<u4"), ("stat_settled", "<u4"), ("stat_heap_pushes", "<u4"),
+    ("cyc_target", "<u4"), ("cyc_rail", "<u4"), ("cyc_inval", "<u4"),
+    ("cyc_pop", "<u4"), ("cyc_push", "<u4"), ("cyc_fire", "<u4"),
 ])
-assert LABEL_T.itemsize == 104
+assert LABEL_T.itemsize == 124
 
 ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
            8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",
@@ -70,13 +72,14 @@ def lib():
     L.kh_last_error.argtypes = [C.c_char_p, ci]
     L.kh_device_count.restype = ci
     L.kh_edt.argtypes = [vp, ci, i64, i64, i64, f32, f32, f32, ci, vp, vp, vp]
+    L.kh_edt_timed.argtypes = [vp, ci, i64, i64, i64, f32, f32, f32, ci, vp, vp, vp, vp]
     L.kh_label_stats.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.kh_scatter_lists.argtypes = [vp, ci, i64, vp, i64, vp, vp, vp, vp]
     L.kh_neighbor_mask.argtypes = [vp, ci, i64, i64, i64, vp, vp]
-    L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp]
+    L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp]
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
-    L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, vp, ci, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp,
-                                 f32, f32, vp, vp, vp, vp, vp, vp]
+    L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
+                                 f32, f32, vp, vp, vp, vp, vp, ci, vp]
     L.kh_fill_f32.argtypes = [vp, i64, f32, vp]
     L.kh_fill_u8.argtypes = [vp, i64, ci, vp]
     L.kh_gather_f32.argtypes = [vp, vp, i64, vp, vp]

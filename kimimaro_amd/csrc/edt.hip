@@ -157,7 +157,7 @@ __global__ void edt_finish_kernel(const float* __restrict__ in, float* __restric
 
 template <typename LT>
 static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
-                    int black_border, float* ws, float* out, hipStream_t st) {
+                    int black_border, float* ws, float* out, hipStream_t st, hipEvent_t* ev = nullptr) {
   const int64_t nrows = sy * sz;
   const int64_t nvox = sx * nrows;
   const bool do_y = (sy > 1) || black_border;
@@ -169,15 +169,17 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
   {
     const int nwords = (int)((sx + 63) >> 6);
     int64_t grid = nrows < 8192 ? nrows : 8192;
-    if (grid < 1) grid = 1;
+    grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
+    if (ev) KH_HIP_CHECK(hipEventRecord(ev[0], st));
     hipLaunchKernelGGL((edt_x_kernel<LT>), dim3((unsigned)grid), dim3(256), nwords * 8, st, lab, bufs[cur],
                        (int)sx, nrows, wx, black_border);
     KH_LAUNCH_CHECK();
+    if (ev) KH_HIP_CHECK(hipEventRecord(ev[1], st));
   }
   auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last) -> int {
     const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + 3) / 4) * m;
     int64_t grid = ntiles < 16384 ? ntiles : 16384;
-    if (grid < 1) grid = 1;
+    grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];
     float* fout = bufs[cur ^ 1];
     if (last)
@@ -191,7 +193,9 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
     return KH_OK;
   };
   if (do_y) { int rc = axis((int)sy, sx, (int)sz, sx * sy, wy, !do_z); if (rc) return rc; }
+  if (ev) KH_HIP_CHECK(hipEventRecord(ev[2], st));
   if (do_z) { int rc = axis((int)sz, sx * sy, (int)sy, sx, wz, true); if (rc) return rc; }
+  if (ev) KH_HIP_CHECK(hipEventRecord(ev[3], st));
   if (!do_y && !do_z) {
     // 1-D input: x pass wrote `out` un-rooted; take the root in place
     hipLaunchKernelGGL((edt_finish_kernel<true>), dim3(1024), dim3(256), 0, st, out, out, nvox);
@@ -216,4 +220,32 @@ extern "C" int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t s
     case 4: return kh::edt_impl<uint32_t>((const uint32_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
     default: kh::set_error("kh_edt: label_bytes must be 1, 2 or 4"); return KH_EINVAL;
   }
+}
+
+// Same as kh_edt, but brackets each pass with HIP events on `stream` and returns the three pass
+// durations in milliseconds (x, y, z; 0 for a skipped pass).  Synchronises the stream.  Used by
+// bench.py for the roofline line (the events sit on the stream the kernels are launched on).
+extern "C" int kh_edt_timed(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                            float wz, int black_border, float* workspace, float* out, void* stream, float* ms3) {
+  if (int rc = kh::require_device()) return rc;
+  if (!labels || !out || !workspace || !ms3 || sx <= 0 || sy <= 0 || sz <= 0 || sx * sy * sz >= (1ll << 32)) {
+    kh::set_error("kh_edt_timed: bad arguments");
+    return KH_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; i++) KH_HIP_CHECK(hipEventCreate(&ev[i]));
+  int rc;
+  switch (label_bytes) {
+    case 1: rc = kh::edt_impl<uint8_t>((const uint8_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
+    case 2: rc = kh::edt_impl<uint16_t>((const uint16_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
+    case 4: rc = kh::edt_impl<uint32_t>((const uint32_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
+    default: kh::set_error("kh_edt_timed: label_bytes must be 1, 2 or 4"); rc = KH_EINVAL;
+  }
+  if (rc == KH_OK) {
+    KH_HIP_CHECK(hipEventSynchronize(ev[3]));
+    for (int i = 0; i < 3; i++) { ms3[i] = 0.0f; (void)hipEventElapsedTime(&ms3[i], ev[i], ev[i + 1]); }
+  }
+  for (int i = 0; i < 4; i++) (void)hipEventDestroy(ev[i]);
+  return rc;
 }

@@ -1,4 +1,5 @@
-// trace.hip -- the per-label TEASAR searches for gfx950: one workgroup (256 threads) per label.
+// trace.hip -- the per-label TEASAR searches for gfx950: one workgroup per label (256 threads for the
+// distance fields, one 64-lane wave for the path loop).
 //
 //   kh_edf_batch    a4  dijkstra3d.euclidean_distance_field   (kimimaro/trace.py:139-145, 302-307)
 //   kh_trace_paths  a6-a11 compute_paths loop                 (kimimaro/trace.py:196-267):
@@ -40,6 +41,11 @@ __device__ __forceinline__ unsigned long long pack(float d, uint32_t v) {
   return ((unsigned long long)__float_as_uint(d) << 32) | v;
 }
 __device__ __forceinline__ float next_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }
+// read lane `l` (wave-uniform index) of a 32-bit value: v_readlane instead of a ds_bpermute round trip
+__device__ __forceinline__ uint32_t rdlane_u32(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l));
+}
+__device__ __forceinline__ float rdlane_f32(float v, int l) { return __uint_as_float(rdlane_u32(__float_as_uint(v), l)); }
 
 struct Ctl {
   unsigned long long best_rail;
@@ -51,31 +57,50 @@ struct Ctl {
   uint32_t red_cnt[4];
   float T;
   uint32_t u0, u1, u2, u3;
+  unsigned long long cyc3[3];
 };
 
+// work lists hold voxel indices only; membership is tracked by two bits per voxel in `qstate`
+// (bit0: queued in the near list being built, bit1: queued in the far list), so a voxel is in each
+// list at most once and every list is bounded by the label size Nf.
 struct Queues {
-  uint64_t* a;
-  uint64_t* b;
-  uint64_t* c;
-  uint32_t* touched;  // capacity 2*cap
+  uint32_t* a;
+  uint32_t* b;
+  uint32_t* c;
+  uint32_t* touched;
   uint32_t cap;
 };
 
-// Returns with ctl->best_rail set (RAIL) ; distances below the final threshold are exact.
-template <bool RAIL>
+__device__ __forceinline__ uint32_t flag_or(uint8_t* base, uint32_t v, uint32_t bit) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(base + (v & ~3u));
+  const int sh = (int)(v & 3u) * 8;
+  return (atomicOr(w, bit << sh) >> sh) & 0xFFu;
+}
+__device__ __forceinline__ void flag_clear(uint8_t* base, uint32_t v, uint32_t bit) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(base + (v & ~3u));
+  const int sh = (int)(v & 3u) * 8;
+  atomicAnd(w, ~(bit << sh));
+}
+
+// MODE 0: EDF (edge length by direction).  MODE 1: railroad (cost = pdrf of the entered voxel, rails
+// absorb, stops once everything at or below the nearest rail is final).
+// On return distances below the final threshold are exact (ctl->best_rail set for MODE 1).
+template <int MODE>
 __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ wfield,
-                     float* dist, uint32_t source, Queues q, Ctl* ctl, float delta_floor) {
+                     float* dist, uint8_t* qstate, uint32_t source, Queues q, Ctl* ctl, float delta_floor) {
+  constexpr bool RAIL = MODE == 1;
   const int tid = threadIdx.x;
+  const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
-  uint64_t* cur = q.a;
-  uint64_t* next = q.b;
-  uint64_t* far = q.c;
+  uint32_t* cur = q.a;
+  uint32_t* next = q.b;
+  uint32_t* far = q.c;
   float T = RAIL ? 1e-45f : delta_floor;
   if (tid == 0) {
     ctl->n_cur = 1; ctl->n_next = 0; ctl->n_far = 0; ctl->n_far2 = 0;
     ctl->n_touched = 0;
     ctl->best_rail = NONE64;
-    cur[0] = pack(0.0f, source);
+    cur[0] = source;
     st_f32_l2(&dist[source], 0.0f);
     if (RAIL) { q.touched[0] = source; ctl->n_touched = 1; }
   }
@@ -85,35 +110,39 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
     for (;;) {
       const uint32_t n = ctl->n_cur;
       if (n == 0) break;
+      for (uint32_t i = tid; i < n; i += nthr) flag_clear(qstate, cur[i], 1u);
+      __syncthreads();
       const uint64_t items = (uint64_t)n << 5;
-      for (uint64_t w = tid; w < items; w += 256) {
+      for (uint64_t w = tid; w < items; w += nthr) {
         const int k = (int)(w & 31);
         if (k >= 26) continue;
-        const uint64_t e = cur[w >> 5];
-        const uint32_t u = (uint32_t)e;
-        const uint32_t dbits = (uint32_t)(e >> 32);
+        const uint32_t u = cur[w >> 5];
         if (!((nbrmask[u] >> k) & 1u)) continue;
-        if (__float_as_uint(ld_f32_l2(&dist[u])) != dbits) continue;  // stale entry
+        const float du = ld_f32_l2(&dist[u]);
         const uint32_t v = u + (uint32_t)g.off[k];
         const float wn = RAIL ? wfield[v] : g.w[k];
-        const float nd = __uint_as_float(dbits) + wn;
+        const float nd = du + wn;
         const uint32_t nb = __float_as_uint(nd);
         const uint32_t old = atomicMin(reinterpret_cast<uint32_t*>(&dist[v]), nb);
         if (nb < old) {
           if (RAIL && old == INF_BITS) {
             const uint32_t t = atomicAdd(&ctl->n_touched, 1u);
-            if (t < 2u * q.cap) q.touched[t] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            if (t < q.cap) q.touched[t] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
           }
           if (RAIL && wn == 0.0f) {  // a rail: absorbing
             atomicMin(&ctl->best_rail, pack(nd, v));
             continue;
           }
           if (nd < T) {
-            const uint32_t p = atomicAdd(&ctl->n_next, 1u);
-            if (p < q.cap) next[p] = pack(nd, v); else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            if (!(flag_or(qstate, v, 1u) & 1u)) {
+              const uint32_t p = atomicAdd(&ctl->n_next, 1u);
+              if (p < q.cap) next[p] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            }
           } else {
-            const uint32_t p = atomicAdd(&ctl->n_far, 1u);
-            if (p < q.cap) far[p] = pack(nd, v); else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            if (!(flag_or(qstate, v, 2u) & 2u)) {
+              const uint32_t p = atomicAdd(&ctl->n_far, 1u);
+              if (p < q.cap) far[p] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            }
           }
         }
       }
@@ -123,7 +152,7 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
         ctl->n_next = 0;
         if (ctl->n_far > q.cap) ctl->n_far = q.cap;
       }
-      uint64_t* t = cur; cur = next; next = t;
+      uint32_t* t = cur; cur = next; next = t;
       __syncthreads();
     }
     // ---- every voxel with d < T is final now
@@ -138,14 +167,11 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
     }
     const uint32_t nfar = ctl->n_far;
     if (nfar == 0) break;
-    // pass 1: min / mean of the live far entries
+    // pass 1: min / mean of the far entries (current distances)
     float mn = KH_INF, sm = 0.0f;
     uint32_t cnt = 0;
-    for (uint32_t i = tid; i < nfar; i += 256) {
-      const uint64_t e = far[i];
-      const uint32_t dbits = (uint32_t)(e >> 32);
-      if (__float_as_uint(ld_f32_l2(&dist[(uint32_t)e])) != dbits) continue;
-      const float d = __uint_as_float(dbits);
+    for (uint32_t i = tid; i < nfar; i += nthr) {
+      const float d = ld_f32_l2(&dist[far[i]]);
       mn = fminf(mn, d); sm += d; cnt++;
     }
 #pragma unroll
@@ -156,41 +182,36 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
     }
     if (lane == 0) { ctl->red_min[wave] = mn; ctl->red_sum[wave] = sm; ctl->red_cnt[wave] = cnt; }
     __syncthreads();
-    mn = fminf(fminf(ctl->red_min[0], ctl->red_min[1]), fminf(ctl->red_min[2], ctl->red_min[3]));
-    sm = ctl->red_sum[0] + ctl->red_sum[1] + ctl->red_sum[2] + ctl->red_sum[3];
-    cnt = ctl->red_cnt[0] + ctl->red_cnt[1] + ctl->red_cnt[2] + ctl->red_cnt[3];
-    if (cnt == 0) {  // only stale entries left
-      __syncthreads();
-      if (tid == 0) ctl->n_far = 0;
-      __syncthreads();
-      break;
-    }
+    mn = ctl->red_min[0]; sm = ctl->red_sum[0]; cnt = ctl->red_cnt[0];
+    for (int i = 1; i < nwav; i++) { mn = fminf(mn, ctl->red_min[i]); sm += ctl->red_sum[i]; cnt += ctl->red_cnt[i]; }
+    if (RAIL && !(mn < tcap)) break;  // nothing left at or below the nearest rail
     const float mean = sm / (float)cnt;
     float step = 0.5f * (mean - mn);
     if (!(step > delta_floor)) step = delta_floor;
     float Tn = mn + step;
     if (!(Tn > mn)) Tn = next_up(mn);
+    if (Tn < T) Tn = T;
     if (Tn > tcap) Tn = tcap;
-    if (RAIL && !(mn < tcap)) {  // nothing left at or below the best rail distance
-      break;
-    }
     T = Tn;
     // pass 2: split far -> cur (d < T) + compacted far (into the free `next` buffer)
-    for (uint32_t i = tid; i < nfar; i += 256) {
-      const uint64_t e = far[i];
-      const uint32_t dbits = (uint32_t)(e >> 32);
-      if (__float_as_uint(ld_f32_l2(&dist[(uint32_t)e])) != dbits) continue;
-      if (__uint_as_float(dbits) < T) {
-        const uint32_t p = atomicAdd(&ctl->n_cur, 1u);
-        cur[p] = e;   // p < nfar <= cap
+    for (uint32_t i = tid; i < nfar; i += nthr) {
+      const uint32_t v = far[i];
+      flag_clear(qstate, v, 2u);
+      const float d = ld_f32_l2(&dist[v]);
+      if (d < T) {
+        if (!(flag_or(qstate, v, 1u) & 1u)) {
+          const uint32_t p = atomicAdd(&ctl->n_cur, 1u);
+          cur[p] = v;  // p < nfar <= cap
+        }
       } else {
+        flag_or(qstate, v, 2u);
         const uint32_t p = atomicAdd(&ctl->n_far2, 1u);
-        next[p] = e;
+        next[p] = v;
       }
     }
     __syncthreads();
     if (tid == 0) { ctl->n_far = ctl->n_far2; ctl->n_far2 = 0; }
-    uint64_t* t = far; far = next; next = t;
+    uint32_t* t = far; far = next; next = t;
     __syncthreads();
   }
   __syncthreads();
@@ -199,7 +220,7 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int mode, const uint32_t* __restrict__ lists,
                                                         const uint32_t* __restrict__ nbrmask, Geometry g, float* field,
-                                                        uint64_t* queues, float delta_floor) {
+                                                        uint8_t* qstate, uint32_t* queues, float delta_floor) {
   __shared__ Ctl ctl;
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
@@ -216,8 +237,8 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
   q.a = queues + (uint64_t)task->q_offset * 4;
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
-  q.touched = reinterpret_cast<uint32_t*>(q.c + q.cap);
-  sssp<false>(g, nbrmask, nullptr, field, source, q, &ctl, delta_floor);
+  q.touched = q.c + q.cap;
+  sssp<0>(g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor);
   // farthest voxel: max finite distance, ties -> smallest linear index
   unsigned long long best = 0;
   for (uint32_t i = tid; i < nf; i += 256) {
@@ -245,94 +266,179 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact libstdc++ binary heap (bits/stl_heap.h __push_heap / __adjust_heap / __pop_heap) with the
-// non-strict comparator of dijkstra_invalidation.hpp:233-237; run by ONE lane.
+// The invalidation heap: an exact emulation of std::priority_queue<HeapDistanceNode, vector, Compare>
+// with Compare = `t1.dist >= t2.dist` (dijkstra_invalidation.hpp:233-237, 262-264) as libstdc++
+// implements it (bits/stl_heap.h), because the pop order among equal keys decides which source owns
+// a voxel.  The array layout after every operation is identical to libstdc++'s:
+//   push  = __push_heap: the new key climbs over every ancestor with key >= it.  The ancestors of the
+//           new leaf are known up front, so the wave loads them all at once (lane g = generation g),
+//           a ballot gives the climb length and the lanes shift the chain down in one step.
+//   pop   = __pop_heap/__adjust_heap: libstdc++ walks the hole to a leaf along the smaller child
+//           (ties: left) and then pushes the last element up again.  Because keys never decrease
+//           from parent to child this lands exactly where the text-book early-exit sift-down lands
+//           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
+//           per memory round trip: 126 speculative child keys are fetched by the 64 lanes, the path
+//           is resolved from registers, and the nodes on it are moved up in one parallel step.
+// The top `lcap` nodes live in LDS, the rest in the label's slice of HBM scratch.
 struct Heap {
-  float* key;
-  uint64_t* pay;
-  uint32_t n, cap;
+  float* lkey;     // LDS
+  uint32_t* lvox;  // LDS
+  uint32_t* lsrc;  // LDS
+  float* gkey;     // global (indexed by absolute position)
+  uint64_t* gpay;
+  uint32_t lcap, cap, n;
 };
 
-__device__ __forceinline__ bool heap_push(Heap& h, float k, uint64_t p) {
+__device__ __forceinline__ float hkey(const Heap& h, uint32_t i) { return i < h.lcap ? h.lkey[i] : h.gkey[i]; }
+__device__ __forceinline__ uint64_t hpay(const Heap& h, uint32_t i) {
+  return i < h.lcap ? (((uint64_t)h.lsrc[i] << 32) | h.lvox[i]) : h.gpay[i];
+}
+__device__ __forceinline__ void hset(const Heap& h, uint32_t i, float k, uint64_t p) {
+  if (i < h.lcap) { h.lkey[i] = k; h.lvox[i] = (uint32_t)p; h.lsrc[i] = (uint32_t)(p >> 32); }
+  else { h.gkey[i] = k; h.gpay[i] = p; }
+}
+
+struct HNode { float k; uint32_t vox, src; };
+__device__ __forceinline__ HNode hload(const Heap& h, uint32_t i) {
+  HNode n;
+  if (i < h.lcap) { n.k = h.lkey[i]; n.vox = h.lvox[i]; n.src = h.lsrc[i]; }
+  else { n.k = h.gkey[i]; const uint64_t p = h.gpay[i]; n.vox = (uint32_t)p; n.src = (uint32_t)(p >> 32); }
+  return n;
+}
+__device__ __forceinline__ void hstore(const Heap& h, uint32_t i, float k, uint32_t vox, uint32_t src) {
+  if (i < h.lcap) { h.lkey[i] = k; h.lvox[i] = vox; h.lsrc[i] = src; }
+  else { h.gkey[i] = k; h.gpay[i] = ((uint64_t)src << 32) | vox; }
+}
+
+// all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
+// the whole node of ancestor generation g+1, a ballot gives the climb length m (the ancestors with
+// key >= k form a prefix because keys never decrease from parent to child), lanes < m write their
+// ancestor one generation down and lane 0 drops the new node into generation m's slot.
+__device__ __forceinline__ bool heap_push_wave(Heap& h, float k, uint32_t vox, uint32_t src, int lane) {
   if (h.n >= h.cap) return false;
-  uint32_t hole = h.n++;
-  while (hole > 0) {
-    const uint32_t parent = (hole - 1) >> 1;
-    const float pk = h.key[parent];
-    if (!(pk >= k)) break;
-    h.key[hole] = pk;
-    h.pay[hole] = h.pay[parent];
-    hole = parent;
-  }
-  h.key[hole] = k;
-  h.pay[hole] = p;
+  const uint32_t pos = h.n++;
+  const int sh = lane + 1 < 32 ? lane + 1 : 31;
+  const uint32_t q = (pos + 1u) >> sh;
+  const bool valid = (lane < 31) && q >= 1u;
+  HNode a;
+  a.k = 0.0f; a.vox = 0; a.src = 0;
+  if (valid) a = hload(h, q - 1u);
+  const unsigned long long climb = __ballot(valid && a.k >= k);
+  const int m = __ffsll((long long)~climb) - 1;  // length of the leading run of set bits (lane 63 never set)
+  const uint32_t dest = lane < 32 ? ((pos + 1u) >> lane) - 1u : 0u;  // slot of generation `lane` (lane 0: the new leaf)
+  if (lane < m) hstore(h, dest, a.k, a.vox, a.src);
+  if (lane == 0) hstore(h, ((pos + 1u) >> m) - 1u, k, vox, src);
   return true;
 }
 
-__device__ __forceinline__ void heap_pop(Heap& h) {
-  uint32_t len = h.n;
-  if (len > 1) {
-    len--;
-    const float vk = h.key[len];
-    const uint64_t vp = h.pay[len];
-    uint32_t hole = 0, child = 0;
-    while (child < (len - 1) / 2) {
-      child = 2 * (child + 1);
-      float ck = h.key[child];
-      const float lk = h.key[child - 1];
-      if (ck >= lk) { child--; ck = lk; }
-      h.key[hole] = ck;
-      h.pay[hole] = h.pay[child];
-      hole = child;
+// removes the top; precondition h.n > 0.  libstdc++'s __adjust_heap walks the hole to a leaf along the
+// smaller child (ties: left) and then pushes the former last element up again; the result is: the path
+// nodes with key < last.key move up one level and `last` takes the slot of the deepest of them.
+// The wave fetches 6 levels (126 nodes: 2 per lane, whole nodes) per round trip, finds the path with
+// one sibling compare per lane + a ballot, keeps the chunk in registers, and issues every write at
+// the end -- so the load of `last` (usually in HBM) overlaps the whole descent.
+#define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels: heaps up to 2^30 nodes */
+__device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
+  const uint32_t len = h.n - 1u;
+  h.n = len;
+  if (len == 0) return;
+  const HNode last = hload(h, len);  // consumed only after the descent
+  // lane -> (depth, offset) of its two speculative nodes; siblings are lanes l and l^1
+  const int m0 = lane, m1 = lane + 64;
+  const int d0 = 31 - __clz(m0 + 2), d1 = 6;
+  const uint32_t j0 = (uint32_t)(m0 + 2 - (1 << d0)), j1 = (uint32_t)(m1 + 2 - 64);
+  HNode c0[KH_POP_CHUNKS], c1[KH_POP_CHUNKS];
+  uint32_t x0[KH_POP_CHUNKS], x1[KH_POP_CHUNKS];  // heap index of my node, 0xFFFFFFFF = not on the path
+  uint32_t hole = 0;
+#pragma unroll
+  for (int c = 0; c < KH_POP_CHUNKS; c++) {
+    x0[c] = 0xFFFFFFFFu; x1[c] = 0xFFFFFFFFu;
+    if (2ull * hole + 1ull >= len) continue;  // the hole is a leaf: nothing below
+    const uint64_t i0 = (((uint64_t)hole + 1u) << d0) - 1u + j0;
+    const uint64_t i1 = (((uint64_t)hole + 1u) << d1) - 1u + j1;
+    const bool e0 = i0 < len, e1 = (m1 < 126) && (i1 < len);
+    HNode n0, n1;
+    n0.k = KH_INF; n0.vox = 0; n0.src = 0; n1 = n0;
+    if (e0) n0 = hload(h, (uint32_t)i0);
+    if (e1) n1 = hload(h, (uint32_t)i1);
+    c0[c] = n0; c1[c] = n1;
+    // a node beats its sibling if it is the left one and right.key >= left.key, or the right one and
+    // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
+    const float s0 = __shfl_xor(n0.k, 1), s1 = __shfl_xor(n1.k, 1);
+    const bool left = (lane & 1) == 0;
+    const bool w0 = e0 && (left ? (s0 >= n0.k) : (n0.k < s0));
+    const bool w1 = e1 && (left ? (s1 >= n1.k) : (n1.k < s1));
+    const unsigned long long W0 = __ballot(w0), W1 = __ballot(w1);
+    // follow the winners from the hole: the children of speculative node m are 2m+2 and 2m+3; a node
+    // with no existing child has neither winner bit set below it.
+    auto wbit = [&](int q) -> bool { return ((q < 64 ? (W0 >> q) : (W1 >> (q - 64))) & 1ull) != 0; };
+    int m = wbit(0) ? 0 : 1;
+    unsigned long long P0 = 1ull << m, P1 = 0;  // path membership masks
+    bool leaf = false;
+#pragma unroll
+    for (int d = 2; d <= 6; d++) {
+      if (!leaf) {
+        const int cl = 2 * m + 2;
+        const bool wl = wbit(cl), wr = wbit(cl + 1);
+        if (!(wl || wr)) leaf = true;
+        else {
+          m = wl ? cl : cl + 1;
+          if (m < 64) P0 |= 1ull << m; else P1 |= 1ull << (m - 64);
+        }
+      }
     }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-      child = 2 * (child + 1);
-      h.key[hole] = h.key[child - 1];
-      h.pay[hole] = h.pay[child - 1];
-      hole = child - 1;
-    }
-    while (hole > 0) {
-      const uint32_t parent = (hole - 1) >> 1;
-      const float pk = h.key[parent];
-      if (!(pk >= vk)) break;
-      h.key[hole] = pk;
-      h.pay[hole] = h.pay[parent];
-      hole = parent;
-    }
-    h.key[hole] = vk;
-    h.pay[hole] = vp;
+    if ((P0 >> lane) & 1ull) x0[c] = (uint32_t)i0;
+    if ((P1 >> lane) & 1ull) x1[c] = (uint32_t)i1;
+    // next hole = heap index of the deepest path node of this chunk (a leaf ends the descent)
+    hole = leaf ? 0x7FFFFFFFu : ((m < 64) ? rdlane_u32((uint32_t)i0, m) : rdlane_u32((uint32_t)i1, m - 64));
   }
-  h.n--;
+  // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
+  // deepest such node (or the root).  Path keys are non-decreasing with depth.
+  uint32_t deepest = 0;
+  const float vk = last.k;
+#pragma unroll
+  for (int c = 0; c < KH_POP_CHUNKS; c++) {
+    const bool mv0 = x0[c] != 0xFFFFFFFFu && c0[c].k < vk;
+    const bool mv1 = x1[c] != 0xFFFFFFFFu && c1[c].k < vk;
+    if (mv0) { hstore(h, (x0[c] - 1u) >> 1, c0[c].k, c0[c].vox, c0[c].src); if (x0[c] > deepest) deepest = x0[c]; }
+    if (mv1) { hstore(h, (x1[c] - 1u) >> 1, c1[c].k, c1[c].vox, c1[c].src); if (x1[c] > deepest) deepest = x1[c]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t od = __shfl_xor(deepest, o);
+    if (od > deepest) deepest = od;
+  }
+  if (lane == 0) hstore(h, deepest, last.k, last.vox, last.src);
 }
 
 // wave 0 only.  Returns the number of voxels invalidated.
 __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
-                                    float scale, float constant, float* hkeys, uint64_t* hpay, uint32_t hcap,
-                                    uint32_t* status, uint32_t* pushes) {
+                                    float scale, float constant, Heap& h, uint32_t* status, uint32_t* pushes,
+                                    unsigned long long* cyc3) {
   const int lane = threadIdx.x & 63;
-  Heap h;
-  h.key = hkeys; h.pay = hpay; h.n = 0; h.cap = hcap;
+  unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt;
+  h.n = 0;
   uint32_t npush = 0;
   bool ovf = false;
-  if (lane == 0) {
-    for (uint32_t i = 0; i < npath; i++) {
-      if (!heap_push(h, 0.0f, ((uint64_t)i << 32) | path[i])) ovf = true;
-      npush++;
-    }
+  for (uint32_t i = 0; i < npath; i++) {
+    if (!heap_push_wave(h, 0.0f, path[i], i, lane)) ovf = true;
+    npush++;
   }
   const uint32_t sx = (uint32_t)g.sx, sxy = (uint32_t)g.sxy;
   const uint32_t xmin = task->xmin, xmax = task->xmax;
   int dx, dy, dz;
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
-  for (;;) {
-    unsigned long long top = NONE64;
-    if (lane == 0 && h.n > 0) { top = h.pay[0]; heap_pop(h); }
-    top = __shfl(top, 0);
-    if (top == NONE64) break;
-    const uint32_t vox = (uint32_t)top, si = (uint32_t)(top >> 32);
-    if (!alive[vox]) continue;
+  while (h.n > 0) {
+    const HNode top = hload(h, 0);
+    const uint32_t vox = top.vox, si = top.src;
+    const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
+    tt = clock64();
+    heap_pop_wave(h, lane);
+    c_pop += clock64() - tt;
+    if (!live) continue;
+    tt = clock64();
     if (lane == 0) alive[vox] = 0;
     count++;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -372,20 +478,22 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
       }
     }
     unsigned long long m = __ballot(want);
+    c_fire += clock64() - tt;
+    tt = clock64();
     while (m) {
       const int k = __ffsll((long long)m) - 1;
       m &= m - 1;
-      const float kd = __shfl(nd, k);
-      const uint32_t kq = __shfl(q, k);
-      if (lane == 0) {
-        if (!heap_push(h, kd, ((uint64_t)si << 32) | kq)) ovf = true;
-        npush++;
-      }
+      const float kd = rdlane_f32(nd, k);
+      const uint32_t kq = rdlane_u32(q, k);
+      if (!heap_push_wave(h, kd, kq, si, lane)) ovf = true;
+      npush++;
     }
+    c_push += clock64() - tt;
   }
   if (lane == 0) {
     if (ovf) atomicOr(status, KH_ST_HEAP_OVERFLOW);
     *pushes += npush;
+    cyc3[0] += c_pop; cyc3[1] += c_push; cyc3[2] += c_fire;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   return count;
@@ -432,18 +540,20 @@ __device__ uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nb
   return n;
 }
 
-template <typename LT>
-__global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
+__global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,
-                                                          uint8_t* alive, const uint32_t* __restrict__ manual_targets,
-                                                          float scale, float constant, uint64_t* queues, float* heap_keys,
+                                                          uint8_t* alive, uint8_t* qstate,
+                                                          const uint32_t* __restrict__ manual_targets,
+                                                          float scale, float constant, uint32_t* queues, float* heap_keys,
                                                           uint64_t* heap_payload, uint32_t* path_vertices,
-                                                          uint32_t* path_lengths) {
+                                                          uint32_t* path_lengths, uint32_t lds_nodes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Ctl ctl;
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
+  const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t* list = lists + task->list_offset;
   const float* ldaf = list_daf + task->list_offset;
@@ -453,7 +563,16 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
   q.a = queues + (uint64_t)task->q_offset * 4;
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
-  q.touched = reinterpret_cast<uint32_t*>(q.c + q.cap);
+  q.touched = q.c + q.cap;
+  Heap heap;
+  heap.lkey = reinterpret_cast<float*>(smem);
+  heap.lvox = reinterpret_cast<uint32_t*>(smem) + lds_nodes;
+  heap.lsrc = reinterpret_cast<uint32_t*>(smem) + 2 * (size_t)lds_nodes;
+  heap.gkey = heap_keys + task->heap_offset;
+  heap.gpay = heap_payload + task->heap_offset;
+  heap.lcap = lds_nodes;
+  heap.cap = task->heap_capacity;
+  heap.n = 0;
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
   const uint32_t pcap = task->path_capacity;
@@ -466,7 +585,8 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
   uint32_t valid = nf;                                  // trace.py:211
   const uint32_t max_paths = task->max_paths ? task->max_paths : nf;  // trace.py:214-215
   uint32_t npaths = 0, nverts = 0;
-  if (tid == 0) { ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; }
+  unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
+  if (tid == 0) { ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; }
   __syncthreads();
   if (nb + na >= max_paths) {                           // trace.py:217-218
     if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; }
@@ -476,13 +596,14 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
   __syncthreads();
   while ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths) {
     // ---- target selection, trace.py:225-230
+    t0 = clock64();
     uint32_t target;
     if (nb > 0) { nb--; target = implicit ? task->max_loc : before[nb]; }
     else if (valid == 0) { na--; target = after[na]; }
     else {
       // CachedTargetFinder.find_target: the valid voxel with the largest DAF (ties: largest index)
       unsigned long long best = 0;
-      for (uint32_t i = tid; i < nf; i += 256) {
+      for (uint32_t i = tid; i < nf; i += nthr) {
         const uint32_t v = list[i];
         if (!alive[v]) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(ldaf[i]) << 32) | v;
@@ -496,11 +617,12 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
       if (lane == 0) ctl.red64[wave] = best;
       __syncthreads();
       best = ctl.red64[0];
-      for (int i = 1; i < 4; i++) if (ctl.red64[i] > best) best = ctl.red64[i];
+      for (int i = 1; i < nwav; i++) if (ctl.red64[i] > best) best = ctl.red64[i];
       target = (uint32_t)best;
       __syncthreads();
     }
     // ---- railroad, trace.py:240-242
+    t_target += clock64() - t0; t0 = clock64();
     uint32_t plen = 0;
     if (nverts >= pcap || npaths >= pcap) {
       if (tid == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW);
@@ -512,7 +634,7 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
       if (tid == 0) out[0] = target;
       plen = 1;
     } else {
-      sssp<true>(g, nbrmask, pdrf, dist, target, q, &ctl, 0.0f);
+      sssp<1>(g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f);
       const unsigned long long br = ctl.best_rail;
       if (tid == 0) { ctl.u0 = 0; ctl.u2 += ctl.n_touched; }
       __syncthreads();
@@ -524,27 +646,32 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
       }
       __syncthreads();
       plen = ctl.u0;
-      // restore dist = +inf on everything the search touched
-      const uint32_t nt = ctl.n_touched < 2u * q.cap ? ctl.n_touched : 2u * q.cap;
-      for (uint32_t i = tid; i < nt; i += 256) st_f32_l2(&dist[q.touched[i]], KH_INF);
+      // restore dist = +inf and the queue flags on everything the search touched
+      const uint32_t nt = ctl.n_touched < q.cap ? ctl.n_touched : q.cap;
+      for (uint32_t i = tid; i < nt; i += nthr) {
+        const uint32_t v = q.touched[i];
+        st_f32_l2(&dist[v], KH_INF);
+        qstate[v] = 0;
+      }
       __syncthreads();
       if (plen == 0) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     // ---- invalidation, trace.py:253-259
+    t_rail += clock64() - t0; t0 = clock64();
     if (valid > 0) {
       if (wave == 0) {
-        const uint32_t c = invalidate_ball(g, task, nbrmask, dbf, alive, out, plen, scale, constant,
-                                           heap_keys + task->heap_offset, heap_payload + task->heap_offset,
-                                           task->heap_capacity, &ctl.status, &ctl.u3);
+        const uint32_t c = invalidate_ball(g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
+                                           &ctl.u3, ctl.cyc3);
         if (lane == 0) ctl.u1 = c;
       }
       __syncthreads();
       valid -= ctl.u1;
     }
     // ---- rails, trace.py:261-263
-    for (uint32_t i = tid; i < plen; i += 256) pdrf[out[i]] = 0.0f;
+    t_inval += clock64() - t0;
+    for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
     if (tid == 0) plens[npaths] = plen;
     npaths++;
     nverts += plen;
@@ -558,6 +685,12 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
     task->status |= ctl.status;
     task->stat_settled = ctl.u2;
     task->stat_heap_pushes = ctl.u3;
+    task->cyc_target = (uint32_t)(t_target >> 10);
+    task->cyc_rail = (uint32_t)(t_rail >> 10);
+    task->cyc_inval = (uint32_t)(t_inval >> 10);
+    task->cyc_pop = (uint32_t)(ctl.cyc3[0] >> 10);
+    task->cyc_push = (uint32_t)(ctl.cyc3[1] >> 10);
+    task->cyc_fire = (uint32_t)(ctl.cyc3[2] >> 10);
   }
 }
 
@@ -613,36 +746,41 @@ using namespace kh;
 
 extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint32_t* lists, const uint32_t* nbrmask,
                             int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz, float* field,
-                            uint64_t* queues, void* stream) {
+                            uint8_t* qstate, uint32_t* queues, void* stream) {
   if (int rc = require_device()) return rc;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_edf_batch: volume must have < 2^32 voxels"); return KH_EINVAL; }
+  if (((uintptr_t)qstate & 3) != 0) { set_error("kh_edf_batch: qstate must be 4-byte aligned"); return KH_EINVAL; }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
   float mn = wx < wy ? wx : wy;
   if (wz < mn) mn = wz;
   const float delta_floor = 2.0f * mn;
   hipLaunchKernelGGL(edf_batch_kernel, dim3(ntasks), dim3(256), 0, (hipStream_t)stream, tasks, mode, lists, nbrmask, g, field,
-                     queues, delta_floor);
+                     qstate, queues, delta_floor);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
 
 extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
-                              const uint32_t* nbrmask, const void* labels, int label_bytes, int64_t sx, int64_t sy,
-                              int64_t sz, float wx, float wy, float wz, const float* dbf, float* pdrf, float* dist,
-                              uint8_t* alive, const uint32_t* manual_targets, float scale, float constant, uint64_t* queues,
+                              const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                              const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
+                              const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
                               float* heap_keys, uint64_t* heap_payload, uint32_t* path_vertices, uint32_t* path_lengths,
-                              void* stream) {
+                              int lds_heap_nodes, void* stream) {
   if (int rc = require_device()) return rc;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
-  (void)labels; (void)label_bytes;
+  if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
+  if (lds_heap_nodes < 0 || lds_heap_nodes > 13000) { set_error("kh_trace_paths: lds_heap_nodes out of range"); return KH_EINVAL; }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
-  hipLaunchKernelGGL((trace_paths_kernel<uint32_t>), dim3(ntasks), dim3(256), 0, (hipStream_t)stream, tasks, lists, list_daf,
-                     nbrmask, g, dbf, pdrf, dist, alive, manual_targets, scale, constant, queues, heap_keys, heap_payload,
-                     path_vertices, path_lengths);
+  const size_t lds = (size_t)lds_heap_nodes * 12;
+  if (lds > 48 * 1024)
+    KH_HIP_CHECK(hipFuncSetAttribute((const void*)trace_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(trace_paths_kernel, dim3(ntasks), dim3(64), lds, (hipStream_t)stream, tasks, lists, list_daf, nbrmask, g,
+                     dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_keys, heap_payload,
+                     path_vertices, path_lengths, (uint32_t)lds_heap_nodes);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -1,0 +1,85 @@
+"""Multi-GPU: one process per GPU, connected components sharded round robin (kimimaro/intake.py:388-389
+does the same over its process pool), finished skeletons collected with an all-gather-v.
+
+No data-path collective: every rank holds the whole label volume (768 MiB at 512^3 -- nothing next
+to 288 GB of HBM), computes the whole-volume EDT redundantly (sub-millisecond class work) and traces
+only its own components.  The only exchange is the final gather of the skeleton arrays
+(~24 B/vertex): RCCL has no native `v` collective, so it is an all_gather of the per-rank payload
+sizes followed by an all_gather of max-padded byte buffers ("nccl" == RCCL over xGMI on ROCm; the
+same code runs over "gloo" on CPU tensors for the tests).
+"""
+from __future__ import annotations
+
+import io
+
+import numpy as np
+
+from .skeleton import Skeleton
+
+
+def pack_skeletons(skels):
+    """{label: Skeleton} -> bytes (npz container of flat arrays)."""
+    labels = np.array(sorted(skels.keys()), dtype=np.int64)
+    nv = np.array([skels[int(l)].vertices.shape[0] for l in labels], dtype=np.int64)
+    ne = np.array([skels[int(l)].edges.shape[0] for l in labels], dtype=np.int64)
+    cat = lambda parts, shape, dt: (np.concatenate(parts, axis=0) if parts else np.zeros(shape, dt))
+    buf = io.BytesIO()
+    np.savez(buf, labels=labels, nv=nv, ne=ne,
+             vertices=cat([skels[int(l)].vertices for l in labels], (0, 3), np.float32),
+             edges=cat([skels[int(l)].edges for l in labels], (0, 2), np.uint32),
+             radii=cat([skels[int(l)].radii for l in labels], (0,), np.float32),
+             vtypes=cat([skels[int(l)].vertex_types for l in labels], (0,), np.uint8),
+             transforms=cat([skels[int(l)].transform[None] for l in labels], (0, 3, 4), np.float32))
+    return buf.getvalue()
+
+
+def unpack_skeletons(blob):
+    z = np.load(io.BytesIO(blob))
+    out = {}
+    vo = np.concatenate([[0], np.cumsum(z["nv"])])
+    eo = np.concatenate([[0], np.cumsum(z["ne"])])
+    for i, l in enumerate(z["labels"].tolist()):
+        out[l] = Skeleton(z["vertices"][vo[i]:vo[i + 1]], z["edges"][eo[i]:eo[i + 1]],
+                          z["radii"][vo[i]:vo[i + 1]], z["vtypes"][vo[i]:vo[i + 1]], segid=l,
+                          transform=z["transforms"][i], space="physical")
+    return out
+
+
+def all_gather_v(blob, device=None):
+    """all-gather-v of one bytes object per rank -> list of bytes (rank order)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    payload = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if len(blob):
+        payload[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    parts = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, payload)
+    return [bytes(p[:s].cpu().numpy().tobytes()) for p, s in zip(parts, sizes)]
+
+
+def merge_rank_results(per_rank):
+    """Union of the per-rank dicts.  A label whose components landed on several ranks is merged like
+    kimimaro/intake.py:587-593 (simple_merge + consolidate)."""
+    acc = {}
+    for skels in per_rank:
+        for l, s in skels.items():
+            acc.setdefault(l, []).append(s)
+    return {l: (v[0] if len(v) == 1 else Skeleton.simple_merge(v).consolidate()) for l, v in acc.items()}
+
+
+def gather_skeletons(local, device=None):
+    """every rank contributes its {label: Skeleton}; every rank receives the merged dict."""
+    blobs = all_gather_v(pack_skeletons(local), device=device)
+    return merge_rank_results([unpack_skeletons(b) for b in blobs])
+
+
+def shard(items, rank, world):
+    """round robin, kimimaro/intake.py:388-389."""
+    return list(items)[rank::world]

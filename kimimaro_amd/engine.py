@@ -17,6 +17,7 @@ import numpy as np
 from . import _abi
 
 NONE32 = 0xFFFFFFFF
+LAST_TASKS = None  # developer probe: task records of the most recent run_labels call
 
 
 def _torch():
@@ -31,6 +32,9 @@ class Engine:
         self.lib = _abi.require_gpu()
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
+        import os
+        v = os.environ.get("KIMI_LDS_NODES")
+        self.lds_heap_nodes = int(v) if v else None  # override of the LDS share of the invalidation heaps (tuning knob)
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -115,7 +119,7 @@ class Engine:
         cnt = counts[order]
         list_off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
         total = int(cnt.sum())
-        qcap = 2 * cnt + 256
+        qcap = cnt + 64
         q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
         hcap = 4 * cnt + 1024
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
@@ -164,7 +168,8 @@ class Engine:
         d_tgt = t.from_numpy(tgt_arr.view(np.int32)).to(self.device)
         d_nbr = self.empty(nvox, t.int32)
         d_field = self.empty(nvox, t.float32)
-        d_queues = self.empty(4 * int(qcap.sum()), t.int64)
+        d_queues = self.empty(4 * int(qcap.sum()), t.int32)
+        d_qstate = self.torch.zeros(nvox + 4, dtype=t.uint8, device=self.device)
         P = self.ptr
         wx, wy, wz = (float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]))
 
@@ -179,9 +184,9 @@ class Engine:
         _abi.check(lib.kh_neighbor_mask(P(d_cc), label_bytes, sx, sy, sz, P(d_nbr), st))
         mark("lists+nbrmask")
         # find_root (trace.py:291-308) then DAF (trace.py:139-145)
-        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_queues), st))
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
         mark("edf_root")
-        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_queues), st))
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
         mark("edf_daf")
         d_ldaf = self.empty(max(total, 1), t.float32)
         _abi.check(lib.kh_gather_f32(P(d_field), P(d_lists), total, P(d_ldaf), st))
@@ -201,12 +206,18 @@ class Engine:
         d_hpay = self.empty(int(hcap.sum()), t.int64)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
-        _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), P(d_cc), label_bytes, sx, sy, sz,
-                                      wx, wy, wz, P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_tgt),
+        # LDS share of each label's invalidation heap: as much as keeps every label resident (<= 8 per CU)
+        per_cu = max(1, min(12, -(-nl // 256)))
+        lds_nodes = int(min(5300, max(256, (150 * 1024 // per_cu) // 12)))
+        lds_nodes = int(self.lds_heap_nodes) if self.lds_heap_nodes is not None else lds_nodes
+        _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz,
+                                      wx, wy, wz, P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                       np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_hkeys),
-                                      P(d_hpay), P(d_pverts), P(d_plens), st))
+                                      P(d_hpay), P(d_pverts), P(d_plens), lds_nodes, st))
         mark("paths")
         out_tasks = d_tasks.cpu().numpy().view(_abi.LABEL_T).copy()
+        global LAST_TASKS
+        LAST_TASKS = out_tasks
         bad = np.flatnonzero(out_tasks["status"])
         if bad.size:
             s = int(bad[0])

@@ -144,11 +144,12 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
 
 def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                    fix_branching, fix_borders, before, after, black_border, timings=None,
-                   rank=0, world=1):
+                   rank=0, world=1, d_cc=None):
     """Everything after the connected components (intake.py:174-221 + skeletonize_subset :434-517)."""
     shape = cc_labels.shape
     label_bytes = 4
-    d_cc = eng.to_device(cc_labels)
+    if d_cc is None:
+        d_cc = eng.to_device(cc_labels)
     d_dbf = eng.edt(d_cc, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
     counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, label_bytes, d_dbf, shape, nlabels)
 

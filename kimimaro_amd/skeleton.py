@@ -99,6 +99,25 @@ class Skeleton:
         d *= d
         return float(np.sum(np.sqrt(np.sum(d, axis=1))))
 
+    def voxel_space(self):
+        """copy with vertices divided by the (diagonal) anisotropy transform (osteoid.Skeleton.voxel_space)."""
+        if self.space == "voxel":
+            return self.clone()
+        skel = self.clone()
+        diag = np.diag(self.transform[:, :3]).astype(np.float32)
+        skel.vertices = (skel.vertices - self.transform[:, 3]) / diag
+        skel.space = "voxel"
+        return skel
+
+    def physical_space(self):
+        if self.space == "physical":
+            return self.clone()
+        skel = self.clone()
+        diag = np.diag(self.transform[:, :3]).astype(np.float32)
+        skel.vertices = skel.vertices * diag + self.transform[:, 3]
+        skel.space = "physical"
+        return skel
+
     def consolidate(self):
         if self.empty():
             return Skeleton(segid=self.id, transform=self.transform, space=self.space)

@@ -506,6 +506,10 @@ static void ko_nhood26(int64_t* nb, int64_t x, int64_t y, int64_t z, int64_t sx,
   nb[25] = (nb[1] + nb[3] + nb[5]) * (nb[3] && nb[5]);
 }
 
+/* instrumentation for DESIGN.md sizing: peak heap size of the last call */
+int64_t ko_last_heap_peak = 0;
+int64_t ko_get_last_heap_peak(void) { return ko_last_heap_peak; }
+
 int ko_invalidate_ball(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
                        float wx, float wy, float wz,
                        const uint64_t* sources, const float* max_distances, int64_t nsrc,
@@ -520,7 +524,9 @@ int ko_invalidate_ball(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
   }
   int64_t count = 0;
   int64_t nb[26];
+  size_t peak = h.n;
   while (h.n) {
+    if (h.n > peak) peak = h.n;
     const float maxd = h.a[0].maxd;
     const uint64_t src = h.a[0].src;
     const uint64_t loc = h.a[0].val;
@@ -550,6 +556,7 @@ int ko_invalidate_ball(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
     }
   }
   free(h.a);
+  ko_last_heap_peak = (int64_t)peak;
   *invalidated = count;
   if (heap_ops) *heap_ops = ops;
   return KO_OK;

@@ -1,0 +1,264 @@
+"""Generates tests/golden/*.npz.  Runs ONLY in the build container (needs /root/reference):
+
+  * compiles the reference's ext/skeletontricks where it lies (oracle/build_ref.py -> oracle/_ref)
+    and records its OUTPUTS on seeded inputs;
+  * loads the reference's kimimaro/trace.py with stub modules for its missing third-party imports
+     and records compute_pdrf / find_soma_root outputs;
+  * records scipy.ndimage.distance_transform_edt outputs for single-label volumes.
+
+Only data (inputs + expected outputs) is written; no reference source is copied.
+Usage:  python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import build_ref  # noqa: E402
+from shapes import random_walk_tube  # noqa: E402
+
+REF = "/root/reference"
+
+
+def load_reference_trace(st):
+    for name in ("dijkstra3d", "edt", "fill_voids"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    ost = types.ModuleType("osteoid")
+    ost.Skeleton = object
+    sys.modules.setdefault("osteoid", ost)
+    pkg = types.ModuleType("kimimaro")
+    pkg.__path__ = []
+    pkg.skeletontricks = st
+    sys.modules["kimimaro"] = pkg
+    sys.modules["kimimaro.skeletontricks"] = st
+    spec = importlib.util.spec_from_file_location("kimimaro.trace", os.path.join(REF, "kimimaro", "trace.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def edt_like(mask, an, rng):
+    """A plausible positive float32 field (values only matter at the path vertices)."""
+    from scipy import ndimage
+    return np.asfortranarray(ndimage.distance_transform_edt(mask, sampling=an).astype(np.float32))
+
+
+def gen_ball(st):
+    rng = np.random.default_rng(20260926)
+    cases = {}
+    n = 0
+    for t in range(60):
+        shape = (int(rng.integers(14, 30)), int(rng.integers(14, 30)), int(rng.integers(10, 26)))
+        an = [(1, 1, 1), (16, 16, 40), (4, 4, 40), (1, 2, 3), (40, 32, 20)][t % 5]
+        if t < 4:
+            # SURVEY B-8 shadow case: a 3x3 tube, a big and a small ball next to each other
+            shape, an = (40, 5, 5), (1, 1, 1)
+            m = np.zeros(shape, np.uint8, order="F")
+            m[:, 1:4, 1:4] = 1
+            path = np.array([(5, 2, 2), (8, 2, 2)] if t % 2 == 0 else [(8, 2, 2), (5, 2, 2)])
+            dbf = np.zeros(shape, np.float32, order="F")
+            dbf[5, 2, 2], dbf[8, 2, 2] = 12.0, 2.5
+            scale, const = 1.0, 0.0
+        else:
+            m = random_walk_tube(shape, 500 + t, steps=30, step=2.5, radius=(1.2, 4.0))
+            dbf = edt_like(m, an, rng)
+            idx = np.flatnonzero(m.ravel(order="F"))
+            k = int(rng.integers(1, 14))
+            if t % 2 == 0:  # a contiguous run of voxels (like a real path)
+                start = int(rng.integers(0, max(1, idx.size - k)))
+                sel = idx[start:start + k]
+            else:
+                sel = rng.choice(idx, min(k, idx.size), replace=False)
+            sx, sy = shape[0], shape[1]
+            path = np.stack([sel % sx, (sel // sx) % sy, sel // (sx * sy)], axis=1)
+            scale = [1.5, 4.0, 0.5, 2.0][t % 4]
+            const = [0.0, 3.0 * an[0], 30.0, 0.7][(t // 4) % 4]
+        before = m.copy(order="F")
+        cnt, _ = st.roll_invalidation_ball_inside_component(
+            m, dbf, scale, const, an, [tuple(int(v) for v in p) for p in path])
+        sxx, syy = shape[0], shape[1]
+        cases["shape_%d" % n] = np.array(shape)
+        cases["an_%d" % n] = np.array(an, np.float32)
+        cases["mask_%d" % n] = np.packbits(before.ravel(order="F"))
+        cases["path_%d" % n] = path.astype(np.int32)
+        cases["dbfpath_%d" % n] = dbf[path[:, 0], path[:, 1], path[:, 2]].astype(np.float32)
+        cases["sc_%d" % n] = np.array([scale, const], np.float32)
+        cases["count_%d" % n] = np.array(cnt)
+        cases["after_%d" % n] = np.packbits(m.ravel(order="F"))
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "invalidation_ball.npz"), **cases)
+    print("invalidation_ball:", n)
+
+
+def gen_cube(st):
+    # the reference's own fixture recipe (automated_test.py:710-747, seed 0xDECAFBAD) with a random DBF
+    rng = np.random.default_rng(seed=0xDECAFBAD)
+    cases = {}
+    for t in range(100):
+        shape = tuple(int(s) for s in rng.integers(8, 24, size=3))
+        labels = np.asfortranarray((rng.random(shape) < 0.8).astype(np.uint8))
+        dbf = np.asfortranarray(rng.uniform(0.0, 2.0, size=shape).astype(np.float32))
+        n_path = int(rng.integers(1, 4))
+        path = [tuple(int(rng.integers(0, s)) for s in shape) for _ in range(n_path)]
+        radius = float(rng.uniform(0.5, 3.0))
+        scale = float(rng.uniform(0.0, 1.5))
+        an = tuple(float(rng.uniform(0.5, 4.0)) for _ in range(3))
+        before = labels.copy(order="F")
+        cnt, out = st.roll_invalidation_cube(labels, dbf, path, scale, radius, anisotropy=an)
+        cases["shape_%d" % t] = np.array(shape)
+        cases["an_%d" % t] = np.array(an, np.float32)
+        cases["mask_%d" % t] = np.packbits(before.ravel(order="F"))
+        pa = np.array(path, np.int32)
+        cases["dbfpath_%d" % t] = dbf[pa[:, 0], pa[:, 1], pa[:, 2]]  # the cube only reads DBF at the path
+        cases["path_%d" % t] = pa
+        cases["sc_%d" % t] = np.array([scale, radius], np.float32)
+        cases["count_%d" % t] = np.array(cnt)
+        cases["after_%d" % t] = np.packbits(out.ravel(order="F"))
+    # the reference's exact-count cases (automated_test.py:650-708)
+    cases["n"] = np.array(100)
+    np.savez_compressed(os.path.join(HERE, "invalidation_cube.npz"), **cases)
+    print("invalidation_cube: 100")
+
+
+def gen_finder(st):
+    rng = np.random.default_rng(7)
+    cases = {}
+    for t in range(8):
+        shape = (int(rng.integers(6, 14)), int(rng.integers(6, 14)), int(rng.integers(4, 10)))
+        mask = np.asfortranarray((rng.random(shape) < 0.6).astype(np.uint8))
+        daf = np.asfortranarray(rng.permutation(mask.size).reshape(shape).astype(np.float32))  # tie free
+        finder = st.CachedTargetFinder(mask, daf)
+        seq = []
+        m = mask.copy(order="F")
+        while True:
+            tgt = finder.find_target(m)
+            if tgt is None:
+                break
+            seq.append([int(v) for v in tgt])
+            # kill a random half of the remaining voxels incl. the target
+            m[tuple(seq[-1])] = 0
+            kill = rng.random(shape) < 0.3
+            m[kill] = 0
+            cases.setdefault("kills_%d" % t, []).append(np.packbits(m.ravel(order="F")))
+        cases["kills_%d" % t] = np.stack(cases["kills_%d" % t]) if "kills_%d" % t in cases else np.zeros((0, 1), np.uint8)
+        cases["shape_%d" % t] = np.array(shape)
+        cases["mask_%d" % t] = np.packbits(mask.ravel(order="F"))
+        cases["daf_%d" % t] = daf.ravel(order="F")
+        cases["seq_%d" % t] = np.array(seq, np.int32).reshape(-1, 3)
+        # first_label / zero2inf / inf2zero
+        cases["first_%d" % t] = np.array(st.first_label(mask) or (-1, -1, -1))
+    cases["n"] = np.array(8)
+    np.savez_compressed(os.path.join(HERE, "target_finder.npz"), **cases)
+    print("target_finder: 8")
+
+
+def gen_pdrf(trace):
+    rng = np.random.default_rng(11)
+    cases = {}
+    n = 0
+    for expo in (1, 2, 4, 16):
+        for scale in (5000, 100000):
+            for zero_daf in (False, True):
+                shape = (9, 7, 5)
+                dbf = np.asfortranarray(rng.uniform(1, 400, shape).astype(np.float32))
+                bg = rng.random(shape) < 0.3
+                dbf[bg] = np.inf  # zero2inf'ed background
+                daf = np.asfortranarray(rng.uniform(0, 9000, shape).astype(np.float32))
+                daf[bg] = 0
+                dbf_max = np.max(dbf[~bg])
+                max_daf = np.float32(0) if zero_daf else np.max(daf)
+                daf_in = daf.copy(order="F")
+                out = trace.compute_pdrf(dbf_max, scale, expo, dbf, daf, max_daf)
+                cases["dbf_%d" % n] = dbf.ravel(order="F")
+                cases["daf_in_%d" % n] = daf_in.ravel(order="F")
+                cases["daf_out_%d" % n] = daf.ravel(order="F")
+                cases["par_%d" % n] = np.array([dbf_max, scale, expo, max_daf], np.float64)
+                cases["out_%d" % n] = out.ravel(order="F")
+                n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "pdrf.npz"), **cases)
+    print("pdrf:", n)
+
+
+def gen_border(st):
+    from scipy import ndimage
+    rng = np.random.default_rng(5)
+    cases = {}
+    n = 0
+    for t in range(24):
+        shape = (int(rng.integers(8, 40)), int(rng.integers(8, 40)))
+        wx, wy = [(1, 1), (16, 16), (16, 40), (40, 16), (32, 20)][t % 5]
+        k = int(rng.integers(1, 6))
+        # random blobs: rectangles / discs (lots of ties)
+        cc = np.zeros(shape, np.uint32, order="F")
+        for lab in range(1, k + 1):
+            x0, y0 = int(rng.integers(0, shape[0] - 3)), int(rng.integers(0, shape[1] - 3))
+            x1, y1 = int(rng.integers(x0 + 2, shape[0] + 1)), int(rng.integers(y0 + 2, shape[1] + 1))
+            cc[x0:x1, y0:y1] = lab
+        # make labels connected-component-like: relabel components
+        lab2, nl = ndimage.label(cc > 0, structure=np.ones((3, 3)))
+        # keep original rectangles as distinct labels (components of equal value)
+        out = np.zeros(shape, np.uint32, order="F")
+        nxt = 1
+        for v in np.unique(cc[cc > 0]):
+            comp, nc = ndimage.label(cc == v, structure=np.ones((3, 3)))
+            for c in range(1, nc + 1):
+                out[comp == c] = nxt
+                nxt += 1
+        cc = np.asfortranarray(out)
+        # black-border multi-label EDT by brute force (small planes)
+        dt = np.zeros(shape, np.float32, order="F")
+        padded = np.pad(cc, 1)
+        for v in range(1, nxt):
+            m = padded == v
+            d = ndimage.distance_transform_edt(m, sampling=(wx, wy))[1:-1, 1:-1]
+            dt[cc == v] = d[cc == v]
+        res = st.find_border_targets(dt, cc, wx, wy)
+        keys = np.array(list(res.keys()), np.int64)
+        vals = np.array([[int(res[key][0]), int(res[key][1])] for key in res.keys()], np.int64).reshape(-1, 2)
+        cases["cc_%d" % n] = cc
+        cases["dt_%d" % n] = dt
+        cases["w_%d" % n] = np.array([wx, wy], np.float32)
+        cases["keys_%d" % n] = keys
+        cases["vals_%d" % n] = vals
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "border_targets.npz"), **cases)
+    print("border_targets:", n)
+
+
+def gen_edt():
+    from scipy import ndimage
+    cases = {}
+    n = 0
+    for seed, an in [(1, (1, 1, 1)), (2, (16, 16, 40)), (3, (8, 8, 40)), (4, (40, 32, 20))]:
+        m = random_walk_tube((36, 30, 26), seed)
+        d = ndimage.distance_transform_edt(m, sampling=an).astype(np.float32)
+        cases["mask_%d" % n] = np.packbits(m.ravel(order="F"))
+        cases["shape_%d" % n] = np.array(m.shape)
+        cases["an_%d" % n] = np.array(an, np.float32)
+        cases["dt_%d" % n] = d.ravel(order="F").astype(np.float16 if False else np.float32)
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "edt_scipy.npz"), **cases)
+    print("edt_scipy:", n)
+
+
+if __name__ == "__main__":
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    trace = load_reference_trace(st)
+    gen_ball(st)
+    gen_cube(st)
+    gen_finder(st)
+    gen_pdrf(trace)
+    gen_border(st)
+    gen_edt()

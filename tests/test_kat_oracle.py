@@ -1,0 +1,96 @@
+"""The reference's own end-to-end known-answer tests (automated_test.py) run through the ORACLE
+pipeline on CPU.  They pin the parts of the oracle whose arithmetic lives in third-party packages that
+are absent from the reference tree (edt, dijkstra3d): exact vertex counts, cable lengths to 1e-3 and
+exact straight-line vertex sets."""
+import numpy as np
+import pytest
+
+from oracle import pipeline as P
+
+TP = {  # automated_test.py:54-63
+    "scale": 1.5, "const": 300, "pdrf_scale": 100000, "pdrf_exponent": 4,
+    "soma_acceptance_threshold": 3500, "soma_detection_threshold": 750,
+    "soma_invalidation_const": 300, "soma_invalidation_scale": 2,
+}
+
+
+def test_empty_image():  # automated_test.py:17-21
+    assert len(P.skeletonize(np.zeros((64, 64, 64), dtype=bool), fix_borders=True)) == 0
+
+
+def test_very_sparse_image():  # :23-31
+    labels = np.zeros((64, 64, 64), dtype=bool)
+    labels[5, 5, 5] = labels[6, 5, 5] = labels[20, 20, 20] = True
+    skels = P.skeletonize(labels, dust_threshold=0)
+    assert len(skels) == 1
+
+
+def test_binary_image():  # :39-46 (256x256x3 in the reference)
+    labels = np.ones((96, 96, 3), dtype=bool)
+    labels[-1, 0] = 0
+    labels[0, -1] = 0
+    assert len(P.skeletonize(labels, fix_borders=False)) == 1
+
+
+@pytest.mark.parametrize("corners", ["anti", "main"])
+def test_square(corners):  # :48-87, full size
+    labels = np.ones((1000, 1000), dtype=np.uint8)
+    if corners == "anti":
+        labels[-1, 0] = 0
+        labels[0, -1] = 0
+    else:
+        labels[0, 0] = 0
+        labels[-1, -1] = 0
+    skels = P.skeletonize(labels, teasar_params=TP, fix_borders=False)
+    assert len(skels) == 1
+    skel = skels[1]
+    assert skel.vertices.shape[0] == 1000
+    assert skel.edges.shape[0] == 999
+    assert abs(skel.cable_length() - 999 * np.sqrt(2)) < 0.001
+    assert skel.space == "physical"
+
+
+def test_cube():  # :89-102, full size
+    labels = np.ones((128, 128, 128), dtype=np.uint8)
+    labels[0, 0, 0] = 0
+    labels[-1, -1, -1] = 0
+    skels = P.skeletonize(labels, fix_borders=False)
+    assert len(skels) == 1
+    skel = skels[1]
+    assert skel.vertices.shape[0] == 128
+    assert skel.edges.shape[0] == 127
+    assert abs(skel.cable_length() - 127 * np.sqrt(3)) < 0.001
+    assert skel.space == "physical"
+
+
+def test_fix_borders_z():  # :116-143 at half linear size (the full size runs on the GPU tier)
+    labels = np.zeros((128, 128, 128), dtype=np.uint8)
+    labels[32:98, 32:98, :] = 128
+    skels = P.skeletonize(labels, teasar_params={"const": 250, "scale": 10, "pdrf_exponent": 4, "pdrf_scale": 100000},
+                          anisotropy=(40, 32, 20), dust_threshold=1000, fix_branching=True, fix_borders=True)
+    skel = skels[128].voxel_space()
+    assert np.all(skel.vertices[:, 0] == skel.vertices[0, 0])
+    assert np.all(skel.vertices[:, 1] == skel.vertices[0, 1])
+    assert 63 <= skel.vertices[0, 0] <= 66 and 63 <= skel.vertices[0, 1] <= 66
+    assert np.all(skel.vertices[:, 2] == np.arange(128))
+
+
+def test_dimensions():  # :261-279
+    labels = np.zeros((10,), dtype=bool)
+    P.skeletonize(labels)
+    labels = np.zeros((10, 10), dtype=bool)
+    P.skeletonize(labels)
+    labels = np.zeros((10, 10, 10, 1), dtype=bool)
+    P.skeletonize(labels)
+    with pytest.raises(P.DimensionError):
+        P.skeletonize(np.ones((10, 10, 10, 2), dtype=bool), dust_threshold=0)
+
+
+def test_extra_targets():  # :201-231 (smaller plate)
+    labels = np.zeros((100, 100, 1), dtype=np.uint8)
+    labels[10:90, 10:90, 0] = 1
+    base = P.skeletonize(labels, TP, dust_threshold=0, fix_borders=False)[1]
+    more = P.skeletonize(labels, TP, dust_threshold=0, fix_borders=False, extra_targets_after=[(10, 89, 0)])[1]
+    assert more.vertices.shape[0] >= base.vertices.shape[0]
+    pre = P.skeletonize(labels, TP, dust_threshold=0, fix_borders=False, extra_targets_before=[(10, 89, 0)])[1]
+    assert pre.vertices.shape[0] >= base.vertices.shape[0]

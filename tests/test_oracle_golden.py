@@ -1,0 +1,144 @@
+"""Pins the oracle (oracle/kimi_oracle.c) against committed golden vectors that were produced by the
+reference itself (tests/golden/make_golden.py: compiled ext/skeletontricks, the reference's
+compute_pdrf, scipy EDT).  Runs on CPU, no /root/reference needed."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as K
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.asfortranarray(np.unpackbits(bits)[:n].reshape(shape, order="F").astype(np.uint8))
+
+
+def test_invalidation_ball_golden():
+    z = np.load(os.path.join(G, "invalidation_ball.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(z["shape_%d" % i])
+        m = unpack(z["mask_%d" % i], shape)
+        path = z["path_%d" % i]
+        dbf = np.zeros(shape, np.float32, order="F")
+        dbf[path[:, 0], path[:, 1], path[:, 2]] = z["dbfpath_%d" % i]
+        scale, const = z["sc_%d" % i]
+        cnt, out = K.roll_invalidation_ball_inside_component(m, dbf, scale, const, z["an_%d" % i], path)
+        assert cnt == int(z["count_%d" % i]), i
+        np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
+
+
+def test_invalidation_ball_shadowing():
+    """SURVEY B-8: the flood is NOT the union of balls (99 voxels, not 153)."""
+    m = np.zeros((40, 5, 5), np.uint8, order="F")
+    m[:, 1:4, 1:4] = 1
+    dbf = np.zeros(m.shape, np.float32, order="F")
+    dbf[5, 2, 2], dbf[8, 2, 2] = 12.0, 2.5
+    cnt, _ = K.roll_invalidation_ball_inside_component(m, dbf, 1.0, 0.0, (1, 1, 1), [(5, 2, 2), (8, 2, 2)])
+    assert cnt == 99
+
+
+def test_invalidation_cube_golden():
+    z = np.load(os.path.join(G, "invalidation_cube.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(z["shape_%d" % i])
+        m = unpack(z["mask_%d" % i], shape)
+        path = z["path_%d" % i]
+        dbf = np.zeros(shape, np.float32, order="F")
+        dbf[path[:, 0], path[:, 1], path[:, 2]] = z["dbfpath_%d" % i]
+        scale, const = z["sc_%d" % i]
+        cnt, out = K.roll_invalidation_cube(m, dbf, path, scale, const, z["an_%d" % i])
+        assert cnt == int(z["count_%d" % i]), i
+        np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
+
+
+def test_invalidation_cube_reference_counts():
+    """the exact counts the reference asserts: automated_test.py:650-708 (125, 8, 9)."""
+    L = np.ones((10, 10, 10), np.uint8, order="F")
+    D = np.zeros((10, 10, 10), np.float32, order="F")
+    assert K.roll_invalidation_cube(L, D, [(5, 5, 5)], 0.0, 2.0)[0] == 125
+    L = np.ones((3, 4, 5), np.uint8, order="F")
+    D = np.zeros((3, 4, 5), np.float32, order="F")
+    cnt, out = K.roll_invalidation_cube(L, D, [(2, 3, 4)], 0.0, 1.0)
+    assert cnt == 8
+    assert set(map(tuple, np.argwhere(out == 0).tolist())) == {
+        (1, 2, 3), (1, 2, 4), (1, 3, 3), (1, 3, 4), (2, 2, 3), (2, 2, 4), (2, 3, 3), (2, 3, 4)}
+    L = np.ones((13, 17, 14), np.uint8, order="F")
+    D = np.zeros((13, 17, 14), np.float32, order="F")
+    assert K.roll_invalidation_cube(L, D, [(1, 16, 0)], 0.0, 0.965, (0.94, 0.93, 2.58))[0] == 9
+
+
+def test_target_finder_golden():
+    from oracle.pipeline import _TargetFinder
+    z = np.load(os.path.join(G, "target_finder.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(z["shape_%d" % i])
+        mask = unpack(z["mask_%d" % i], shape)
+        daf = np.asfortranarray(z["daf_%d" % i].reshape(shape, order="F"))
+        first = K.first_label(mask)
+        assert tuple(z["first_%d" % i]) == (first if first is not None else (-1, -1, -1))
+        finder = _TargetFinder(K.target_order(mask, daf), shape)
+        m = mask.copy(order="F")
+        seq = z["seq_%d" % i]
+        kills = z["kills_%d" % i]
+        for step in range(seq.shape[0]):
+            tgt = finder.find_target(m)
+            assert tuple(tgt) == tuple(seq[step])
+            m = unpack(kills[step], shape)
+        assert finder.find_target(m) is None
+
+
+def test_pdrf_golden():
+    z = np.load(os.path.join(G, "pdrf.npz"))
+    shape = (9, 7, 5)
+    for i in range(int(z["n"])):
+        dbf = np.asfortranarray(z["dbf_%d" % i].reshape(shape, order="F"))
+        daf = np.asfortranarray(z["daf_in_%d" % i].reshape(shape, order="F")).copy(order="F")
+        dbf_max, scale, expo, max_daf = z["par_%d" % i]
+        out = K.compute_pdrf(np.float32(dbf_max), scale, int(expo), dbf, daf, np.float32(max_daf))
+        np.testing.assert_array_equal(out.ravel(order="F"), z["out_%d" % i], err_msg="case %d" % i)
+        np.testing.assert_array_equal(daf.ravel(order="F"), z["daf_out_%d" % i])  # DAF is mutated
+
+
+def test_edt_scipy_golden():
+    z = np.load(os.path.join(G, "edt_scipy.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(z["shape_%d" % i])
+        m = unpack(z["mask_%d" % i], shape)
+        got = K.edt(m, z["an_%d" % i])
+        np.testing.assert_allclose(got.ravel(order="F"), z["dt_%d" % i], rtol=2e-7, atol=1e-4)
+
+
+def test_edt_multilabel_bruteforce():
+    """definition check on a tiny multi-label volume (both border modes)."""
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, 4, (9, 8, 7)).astype(np.uint32)
+    an = np.array((3.0, 2.0, 5.0))
+    for bb in (False, True):
+        got = K.edt(lab, an, bb)
+        pad = np.pad(lab.astype(np.int64), 1, constant_values=-1)
+        idx = np.argwhere(np.ones_like(pad, bool)) - 1
+        vals = pad.ravel()
+        for x, y, z in np.argwhere(lab > 0):
+            L = lab[x, y, z]
+            other = (vals != L) & ((vals != -1) | bb)
+            d2 = (((idx[other] - (x, y, z)) * an) ** 2).sum(1)
+            want = np.sqrt(d2.min()) if d2.size else np.inf
+            assert np.isclose(got[x, y, z], want, rtol=1e-6), (bb, x, y, z)
+        assert (got[lab == 0] == 0).all()
+
+
+def test_border_targets_golden():
+    from kimimaro_amd.border import find_border_targets
+    z = np.load(os.path.join(G, "border_targets.npz"))
+    for i in range(int(z["n"])):
+        cc, dt = np.asfortranarray(z["cc_%d" % i]), np.asfortranarray(z["dt_%d" % i])
+        wx, wy = z["w_%d" % i]
+        got = find_border_targets(dt, cc, wx, wy, int(cc.max()))
+        keys = z["keys_%d" % i]
+        vals = z["vals_%d" % i]
+        assert list(got.keys()) == keys.tolist(), i            # dict insertion order too
+        for k, v in zip(keys.tolist(), vals.tolist()):
+            assert (int(got[k][0]), int(got[k][1])) == tuple(v), (i, k)

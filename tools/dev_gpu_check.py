@@ -40,3 +40,12 @@ prev = t0
 for name, ts in timings:
     print("  %-14s %.3f s" % (name, ts - prev)); prev = ts
 print("verts", sum(s.vertices.shape[0] for s in sk.values()))
+import kimimaro_amd.engine as E
+tk = E.LAST_TASKS
+if tk is not None:
+    print("kcyc target/rail/inval sums:", tk["cyc_target"].sum(), tk["cyc_rail"].sum(), tk["cyc_inval"].sum())
+    i = np.argmax(tk["cyc_inval"].astype(np.int64) + tk["cyc_rail"])
+    print("worst label: count", tk["count"][i], "paths", tk["n_paths"][i], "kcyc", tk["cyc_target"][i], tk["cyc_rail"][i], tk["cyc_inval"][i], "pushes", tk["stat_heap_pushes"][i], "settled", tk["stat_settled"][i])
+    print("kcyc pop/push/fire sums:", tk["cyc_pop"].astype(np.int64).sum(), tk["cyc_push"].astype(np.int64).sum(), tk["cyc_fire"].astype(np.int64).sum())
+    print("kcyc pop/push/fire sums:", tk["cyc_pop"].astype(np.int64).sum(), tk["cyc_push"].astype(np.int64).sum(), tk["cyc_fire"].astype(np.int64).sum())
+    print("pushes total", tk["stat_heap_pushes"].astype(np.int64).sum(), "settled total", tk["stat_settled"].astype(np.int64).sum(), "paths", tk["n_paths"].sum())
