@@ -89,13 +89,18 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
   }
 }
 
-// y / z pass.  blockDim = (64, 4): 64 lanes along x, 4 consecutive positions along the axis.
-template <typename LT, bool LAST>
+// y / z pass.  blockDim = (64, 4): 64 lanes along x; every thread owns R consecutive positions along the
+// axis and walks outward from its group, so each row it loads (one coalesced 256-B segment per wave)
+// feeds R minima.  For output r of the group, the row at distance s to the left of the group is at
+// distance k = s + r, the one to the right at k = s + R-1-r.  A side of an output closes when its
+// same-label segment ends or when (w*k)^2 >= best (nothing farther can improve the minimum), so the
+// result is the exact minimum over the float expressions in any visiting order (== oracle ko_edt_axis).
+template <typename LT, bool LAST, int R>
 __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border) {
   // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride
-  const int xt = (sx + 63) >> 6, at = (n + 3) >> 2;
+  const int xt = (sx + 63) >> 6, at = (n + 4 * R - 1) / (4 * R);
   const int64_t ntiles = (int64_t)xt * at * m;
   const int64_t nblk = gridDim.x;
   const int64_t per_xcd = (nblk + 7) / 8;
@@ -103,49 +108,90 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
   const int64_t stride = per_xcd * 8;
   for (int64_t t = logical; t < ntiles; t += stride) {
     const int tx = (int)(t % xt);
-    const int64_t r = t / xt;
-    const int ta = (int)(r % at);
-    const int o = (int)(r / at);
+    const int64_t rr = t / xt;
+    const int ta = (int)(rr % at);
+    const int o = (int)(rr / at);
     const int x = (tx << 6) + threadIdx.x;
-    const int a = (ta << 2) + threadIdx.y;
-    if (x >= sx || a >= n) continue;
+    const int a0 = (ta * 4 + threadIdx.y) * R;
+    if (x >= sx || a0 >= n) continue;
     const int64_t base = x + (int64_t)o * ostride;
-    const int64_t i = base + (int64_t)a * astride;
-    const LT L = lab[i];
-    float best = 0.0f;
-    if (L != 0) {
-      best = fin[i];
-      bool lo = true, ro = true;
-      for (int k = 1; lo || ro; k++) {
-        const float d = w * (float)k;
-        const float tt = d * d;
-        if (tt >= best) break;
-        if (lo) {
-          const int j = a - k;
-          if (j < 0) {
-            lo = false;
-            if (black_border) best = tt;  // tt < best here
-          } else {
-            const int64_t q = base + (int64_t)j * astride;
-            if (lab[q] != L) { lo = false; best = tt; }
-            else { const float c = fin[q] + tt; if (c < best) best = c; }
-          }
+    LT L[R];
+    float f[R], best[R];
+    bool lo[R], ro[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const bool valid = a0 + r < n;
+      const int64_t i = base + (int64_t)(valid ? a0 + r : a0) * astride;
+      L[r] = valid ? lab[i] : (LT)0;
+      f[r] = valid ? fin[i] : 0.0f;
+      best[r] = (L[r] != 0) ? f[r] : 0.0f;
+      lo[r] = ro[r] = (L[r] != 0);
+    }
+    // candidates inside the group, nearest first
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+      for (int d = 1; d < R; d++) {
+        const float dd = w * (float)d;
+        const float tt = dd * dd;
+        if (r - d >= 0 && lo[r]) {
+          if (tt >= best[r]) lo[r] = false;
+          else if (L[r - d] != L[r]) { lo[r] = false; best[r] = tt; }
+          else { const float c = f[r - d] + tt; if (c < best[r]) best[r] = c; }
         }
-        if (ro) {
-          const int j = a + k;
-          if (j >= n) {
-            ro = false;
-            if (black_border && tt < best) best = tt;
-          } else {
-            const int64_t q = base + (int64_t)j * astride;
-            if (lab[q] != L) { ro = false; if (tt < best) best = tt; }
-            else { const float c = fin[q] + tt; if (c < best) best = c; }
+        if (r + d < R && ro[r]) {
+          if (tt >= best[r]) ro[r] = false;
+          else if (a0 + r + d >= n) { ro[r] = false; if (black_border) best[r] = tt; }
+          else if (L[r + d] != L[r]) { ro[r] = false; best[r] = tt; }
+          else { const float c = f[r + d] + tt; if (c < best[r]) best[r] = c; }
+        }
+      }
+    }
+    bool anyl = false, anyr = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) { anyl |= lo[r]; anyr |= ro[r]; }
+    for (int s = 1; anyl || anyr; s++) {
+      if (anyl) {
+        const int j = a0 - s;
+        LT Lj = 0;
+        float fj = 0.0f;
+        if (j >= 0) { const int64_t q = base + (int64_t)j * astride; Lj = lab[q]; fj = fin[q]; }
+        anyl = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (lo[r]) {
+            const float dd = w * (float)(s + r);
+            const float tt = dd * dd;
+            if (tt >= best[r]) lo[r] = false;
+            else if (j < 0) { lo[r] = false; if (black_border) best[r] = tt; }
+            else if (Lj != L[r]) { lo[r] = false; best[r] = tt; }
+            else { const float c = fj + tt; if (c < best[r]) best[r] = c; anyl = true; }
           }
         }
       }
-      if (LAST) best = sqrtf(best);
+      if (anyr) {
+        const int j = a0 + R - 1 + s;
+        LT Lj = 0;
+        float fj = 0.0f;
+        if (j < n) { const int64_t q = base + (int64_t)j * astride; Lj = lab[q]; fj = fin[q]; }
+        anyr = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (ro[r]) {
+            const float dd = w * (float)(s + R - 1 - r);
+            const float tt = dd * dd;
+            if (tt >= best[r]) ro[r] = false;
+            else if (j >= n) { ro[r] = false; if (black_border) best[r] = tt; }
+            else if (Lj != L[r]) { ro[r] = false; best[r] = tt; }
+            else { const float c = fj + tt; if (c < best[r]) best[r] = c; anyr = true; }
+          }
+        }
+      }
     }
-    fout[i] = best;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (a0 + r < n) fout[base + (int64_t)(a0 + r) * astride] = LAST ? sqrtf(best[r]) : best[r];
+    }
   }
 }
 
@@ -177,16 +223,17 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[1], st));
   }
   auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last) -> int {
-    const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + 3) / 4) * m;
+    constexpr int R = 4;
+    const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + 4 * R - 1) / (4 * R)) * m;
     int64_t grid = ntiles < 16384 ? ntiles : 16384;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];
     float* fout = bufs[cur ^ 1];
     if (last)
-      hipLaunchKernelGGL((edt_axis_kernel<LT, true>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
+      hipLaunchKernelGGL((edt_axis_kernel<LT, true, R>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
                          astride, m, ostride, w, black_border);
     else
-      hipLaunchKernelGGL((edt_axis_kernel<LT, false>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
+      hipLaunchKernelGGL((edt_axis_kernel<LT, false, R>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
                          astride, m, ostride, w, black_border);
     KH_LAUNCH_CHECK();
     cur ^= 1;

@@ -279,35 +279,52 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
 //           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
 //           per memory round trip: 126 speculative child keys are fetched by the 64 lanes, the path
 //           is resolved from registers, and the nodes on it are moved up in one parallel step.
-// The top `lcap` nodes live in LDS, the rest in the label's slice of HBM scratch.
+// The heap lives in the label's slice of HBM scratch; its top `lcap` nodes are mirrored write-through in
+// LDS so that the first one or two 6-level chunks of every pop are LDS reads (lcap = 127 covers levels
+// 0-6, lcap = 8191 levels 0-12).
 struct Heap {
-  float* lkey;     // LDS
-  uint32_t* lvox;  // LDS
-  uint32_t* lsrc;  // LDS
-  float* gkey;     // global (indexed by absolute position)
-  uint64_t* gpay;
-  uint32_t lcap, cap, n;
+  float* key;      // HBM scratch of this label: the authoritative copy of every node
+  uint64_t* pay;   // (source index << 32) | voxel
+  float* lkey;     // LDS write-through mirror of nodes [0, lcap): lets whole 6-level chunks be read from LDS
+  uint64_t* lpay;
+  uint32_t lcap;
+  uint32_t cap, n;
+  unsigned long long am0, am1;  // per-lane ancestor masks of the speculative sub-tree (see heap_init_lane)
 };
-
-__device__ __forceinline__ float hkey(const Heap& h, uint32_t i) { return i < h.lcap ? h.lkey[i] : h.gkey[i]; }
-__device__ __forceinline__ uint64_t hpay(const Heap& h, uint32_t i) {
-  return i < h.lcap ? (((uint64_t)h.lsrc[i] << 32) | h.lvox[i]) : h.gpay[i];
-}
-__device__ __forceinline__ void hset(const Heap& h, uint32_t i, float k, uint64_t p) {
-  if (i < h.lcap) { h.lkey[i] = k; h.lvox[i] = (uint32_t)p; h.lsrc[i] = (uint32_t)(p >> 32); }
-  else { h.gkey[i] = k; h.gpay[i] = p; }
-}
-
 struct HNode { float k; uint32_t vox, src; };
+
 __device__ __forceinline__ HNode hload(const Heap& h, uint32_t i) {
   HNode n;
-  if (i < h.lcap) { n.k = h.lkey[i]; n.vox = h.lvox[i]; n.src = h.lsrc[i]; }
-  else { n.k = h.gkey[i]; const uint64_t p = h.gpay[i]; n.vox = (uint32_t)p; n.src = (uint32_t)(p >> 32); }
+  n.k = h.key[i];
+  const uint64_t p = h.pay[i];
+  n.vox = (uint32_t)p;
+  n.src = (uint32_t)(p >> 32);
+  return n;
+}
+__device__ __forceinline__ HNode hload_lds(const Heap& h, uint32_t i) {
+  HNode n;
+  n.k = h.lkey[i];
+  const uint64_t p = h.lpay[i];
+  n.vox = (uint32_t)p;
+  n.src = (uint32_t)(p >> 32);
   return n;
 }
 __device__ __forceinline__ void hstore(const Heap& h, uint32_t i, float k, uint32_t vox, uint32_t src) {
-  if (i < h.lcap) { h.lkey[i] = k; h.lvox[i] = vox; h.lsrc[i] = src; }
-  else { h.gkey[i] = k; h.gpay[i] = ((uint64_t)src << 32) | vox; }
+  const uint64_t p = ((uint64_t)src << 32) | vox;
+  h.key[i] = k;
+  h.pay[i] = p;
+  if (i < h.lcap) { h.lkey[i] = k; h.lpay[i] = p; }
+}
+
+// The 6-level speculative sub-tree under a hole has 126 nodes m = 0..125 (children of m: 2m+2, 2m+3;
+// parent of m >= 2: (m-2)>>1).  Lane l holds nodes m = l ("slot 0") and m = l + 64 ("slot 1", depth 6
+// only).  am0 / am1 = the bits (in the slot-0 ballot) of the node's ancestors, am0 including itself.
+__device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
+  unsigned long long a0 = 0, a1 = 0;
+  for (int m = lane; ; m = (m - 2) >> 1) { a0 |= 1ull << m; if (m < 2) break; }
+  if (lane + 64 < 126) for (int m = (lane + 62) >> 1; ; m = (m - 2) >> 1) { a1 |= 1ull << m; if (m < 2) break; }
+  h.am0 = a0;
+  h.am1 = a1;
 }
 
 // all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
@@ -334,63 +351,58 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, float k, uint32_t vox, u
 // removes the top; precondition h.n > 0.  libstdc++'s __adjust_heap walks the hole to a leaf along the
 // smaller child (ties: left) and then pushes the former last element up again; the result is: the path
 // nodes with key < last.key move up one level and `last` takes the slot of the deepest of them.
-// The wave fetches 6 levels (126 nodes: 2 per lane, whole nodes) per round trip, finds the path with
-// one sibling compare per lane + a ballot, keeps the chunk in registers, and issues every write at
-// the end -- so the load of `last` (usually in HBM) overlaps the whole descent.
+// The wave fetches 6 levels (126 whole nodes, 2 per lane) per round trip.  A node is on the path iff it
+// and all its ancestors in the sub-tree beat their siblings: one sibling compare per lane, one ballot,
+// one mask test against the lane's constant ancestor mask.  The chunks stay in registers and every
+// write is issued at the end, so the load of `last` overlaps the whole descent.
 #define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels: heaps up to 2^30 nodes */
 __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
   const uint32_t len = h.n - 1u;
   h.n = len;
   if (len == 0) return;
   const HNode last = hload(h, len);  // consumed only after the descent
-  // lane -> (depth, offset) of its two speculative nodes; siblings are lanes l and l^1
-  const int m0 = lane, m1 = lane + 64;
-  const int d0 = 31 - __clz(m0 + 2), d1 = 6;
-  const uint32_t j0 = (uint32_t)(m0 + 2 - (1 << d0)), j1 = (uint32_t)(m1 + 2 - 64);
+  const int d0 = 31 - __clz(lane + 2);
+  const uint32_t j0 = (uint32_t)(lane + 2 - (1 << d0)), j1 = (uint32_t)(lane + 2);  // slot 1: depth 6, offset lane+2
+  const bool left = (lane & 1) == 0;
   HNode c0[KH_POP_CHUNKS], c1[KH_POP_CHUNKS];
-  uint32_t x0[KH_POP_CHUNKS], x1[KH_POP_CHUNKS];  // heap index of my node, 0xFFFFFFFF = not on the path
+  uint32_t x0[KH_POP_CHUNKS], x1[KH_POP_CHUNKS];  // heap index of my node if it is on the path, else ~0
   uint32_t hole = 0;
+  bool more = true;
+  int nch = 0;
 #pragma unroll
   for (int c = 0; c < KH_POP_CHUNKS; c++) {
-    x0[c] = 0xFFFFFFFFu; x1[c] = 0xFFFFFFFFu;
-    if (2ull * hole + 1ull >= len) continue;  // the hole is a leaf: nothing below
-    const uint64_t i0 = (((uint64_t)hole + 1u) << d0) - 1u + j0;
-    const uint64_t i1 = (((uint64_t)hole + 1u) << d1) - 1u + j1;
-    const bool e0 = i0 < len, e1 = (m1 < 126) && (i1 < len);
-    HNode n0, n1;
-    n0.k = KH_INF; n0.vox = 0; n0.src = 0; n1 = n0;
-    if (e0) n0 = hload(h, (uint32_t)i0);
-    if (e1) n1 = hload(h, (uint32_t)i1);
-    c0[c] = n0; c1[c] = n1;
-    // a node beats its sibling if it is the left one and right.key >= left.key, or the right one and
-    // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
-    const float s0 = __shfl_xor(n0.k, 1), s1 = __shfl_xor(n1.k, 1);
-    const bool left = (lane & 1) == 0;
-    const bool w0 = e0 && (left ? (s0 >= n0.k) : (n0.k < s0));
-    const bool w1 = e1 && (left ? (s1 >= n1.k) : (n1.k < s1));
-    const unsigned long long W0 = __ballot(w0), W1 = __ballot(w1);
-    // follow the winners from the hole: the children of speculative node m are 2m+2 and 2m+3; a node
-    // with no existing child has neither winner bit set below it.
-    auto wbit = [&](int q) -> bool { return ((q < 64 ? (W0 >> q) : (W1 >> (q - 64))) & 1ull) != 0; };
-    int m = wbit(0) ? 0 : 1;
-    unsigned long long P0 = 1ull << m, P1 = 0;  // path membership masks
-    bool leaf = false;
-#pragma unroll
-    for (int d = 2; d <= 6; d++) {
-      if (!leaf) {
-        const int cl = 2 * m + 2;
-        const bool wl = wbit(cl), wr = wbit(cl + 1);
-        if (!(wl || wr)) leaf = true;
-        else {
-          m = wl ? cl : cl + 1;
-          if (m < 64) P0 |= 1ull << m; else P1 |= 1ull << (m - 64);
-        }
+    if (more && 2ull * hole + 1ull < len) {
+      nch = c + 1;
+      x0[c] = 0xFFFFFFFFu; x1[c] = 0xFFFFFFFFu;
+      const uint64_t i0 = (((uint64_t)hole + 1u) << d0) - 1u + j0;
+      const uint64_t i1 = (((uint64_t)hole + 1u) << 6) - 1u + j1;
+      const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
+      HNode n0, n1;
+      n0.k = KH_INF; n0.vox = 0; n0.src = 0; n1 = n0;
+      if ((((uint64_t)hole + 1u) << 6) + 62u < h.lcap) {  // the whole chunk is mirrored in LDS (wave uniform)
+        if (e0) n0 = hload_lds(h, (uint32_t)i0);
+        if (e1) n1 = hload_lds(h, (uint32_t)i1);
+      } else {
+        if (e0) n0 = hload(h, (uint32_t)i0);
+        if (e1) n1 = hload(h, (uint32_t)i1);
       }
-    }
-    if ((P0 >> lane) & 1ull) x0[c] = (uint32_t)i0;
-    if ((P1 >> lane) & 1ull) x1[c] = (uint32_t)i1;
-    // next hole = heap index of the deepest path node of this chunk (a leaf ends the descent)
-    hole = leaf ? 0x7FFFFFFFu : ((m < 64) ? rdlane_u32((uint32_t)i0, m) : rdlane_u32((uint32_t)i1, m - 64));
+      // a node beats its sibling if it is the left one and right.key >= left.key, or the right one and
+      // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
+      const float s0 = __shfl_xor(n0.k, 1), s1 = __shfl_xor(n1.k, 1);
+      const bool w0 = e0 && (left ? (s0 >= n0.k) : (n0.k < s0));
+      const bool w1 = e1 && (left ? (s1 >= n1.k) : (n1.k < s1));
+      const unsigned long long W0 = __ballot(w0);
+      const bool on0 = (W0 & h.am0) == h.am0;
+      const bool on1 = w1 && ((W0 & h.am1) == h.am1);
+      const unsigned long long P0 = __ballot(on0), P1 = __ballot(on1);
+      c0[c] = n0; c1[c] = n1;
+      if (on0) x0[c] = (uint32_t)i0;
+      if (on1) x1[c] = (uint32_t)i1;
+      // next hole = the depth-6 node of the path, if the path got that deep
+      if (P1) hole = rdlane_u32((uint32_t)i1, __ffsll((long long)P1) - 1);
+      else if (P0 >> 62) hole = rdlane_u32((uint32_t)i0, (P0 >> 63) ? 63 : 62);
+      else more = false;  // the path ended at a leaf above depth 6
+    } else more = false;
   }
   // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
   // deepest such node (or the root).  Path keys are non-decreasing with depth.
@@ -398,15 +410,14 @@ __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
   const float vk = last.k;
 #pragma unroll
   for (int c = 0; c < KH_POP_CHUNKS; c++) {
+    if (c >= nch) break;
     const bool mv0 = x0[c] != 0xFFFFFFFFu && c0[c].k < vk;
     const bool mv1 = x1[c] != 0xFFFFFFFFu && c1[c].k < vk;
-    if (mv0) { hstore(h, (x0[c] - 1u) >> 1, c0[c].k, c0[c].vox, c0[c].src); if (x0[c] > deepest) deepest = x0[c]; }
-    if (mv1) { hstore(h, (x1[c] - 1u) >> 1, c1[c].k, c1[c].vox, c1[c].src); if (x1[c] > deepest) deepest = x1[c]; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t od = __shfl_xor(deepest, o);
-    if (od > deepest) deepest = od;
+    if (mv0) hstore(h, (x0[c] - 1u) >> 1, c0[c].k, c0[c].vox, c0[c].src);
+    if (mv1) hstore(h, (x1[c] - 1u) >> 1, c1[c].k, c1[c].vox, c1[c].src);
+    const unsigned long long M0 = __ballot(mv0), M1 = __ballot(mv1);
+    if (M1) deepest = rdlane_u32(x1[c], __ffsll((long long)M1) - 1);
+    else if (M0) deepest = rdlane_u32(x0[c], 63 - __clzll((long long)M0));
   }
   if (lane == 0) hstore(h, deepest, last.k, last.vox, last.src);
 }
@@ -431,7 +442,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
   while (h.n > 0) {
-    const HNode top = hload(h, 0);
+    const HNode top = h.lcap ? hload_lds(h, 0) : hload(h, 0);
     const uint32_t vox = top.vox, si = top.src;
     const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
     tt = clock64();
@@ -565,14 +576,14 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
   Heap heap;
-  heap.lkey = reinterpret_cast<float*>(smem);
-  heap.lvox = reinterpret_cast<uint32_t*>(smem) + lds_nodes;
-  heap.lsrc = reinterpret_cast<uint32_t*>(smem) + 2 * (size_t)lds_nodes;
-  heap.gkey = heap_keys + task->heap_offset;
-  heap.gpay = heap_payload + task->heap_offset;
-  heap.lcap = lds_nodes;
+  heap.key = heap_keys + task->heap_offset;
+  heap.pay = heap_payload + task->heap_offset;
   heap.cap = task->heap_capacity;
   heap.n = 0;
+  heap.lcap = lds_nodes;
+  heap.lpay = reinterpret_cast<uint64_t*>(smem);
+  heap.lkey = reinterpret_cast<float*>(smem + 8 * (size_t)lds_nodes);
+  heap_init_lane(heap, lane);
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
   const uint32_t pcap = task->path_capacity;
