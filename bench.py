@@ -195,7 +195,7 @@ def main():
     import ctypes as C
     nvox = int(np.prod(shape))
     out = eng.empty(nvox, torch.float32)
-    ws = eng.empty(nvox, torch.float32)
+    ws = eng.empty(2 * nvox, torch.float32)
     ms3 = (C.c_float * 3)()
     acc = np.zeros(3)
     reps = 10

@@ -50,7 +50,7 @@ int kh_device_count(void);
 
 /* ---- a1: edt.edt(labels, anisotropy, black_border) ---------------------------------
  * replaces: edt.edt as called at kimimaro/intake.py:178-183 and kimimaro/trace.py:112-117.
- * labels: u16/u32 [sx,sy,sz]; out: f32 same shape; workspace: f32 same shape (ping-pong).
+ * labels: u8/u16/u32 [sx,sy,sz]; out: f32 same shape; workspace: f32 same shape (ping-pong).
  * Squared distances are accumulated exactly as documented in oracle/kimi_oracle.c (ko_edt). */
 int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
            float wx, float wy, float wz, int black_border,
@@ -155,14 +155,16 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * Paths are written as linear indices, rail end first, into path_vertices with
  * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).
  * qstate as for kh_edf_batch.  lds_heap_nodes: how many top nodes of each label's invalidation heap
- * live in LDS (12 bytes each; trades occupancy against heap latency).                         */
+ * are mirrored in LDS (12 bytes each; 127 or 8191).  fix_branching = 0 selects the parental-field
+ * variant (trace.py:155,244): one weighted Dijkstra from the root, paths returned root -> target.   */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                    const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                    const uint32_t* manual_targets, float scale, float constant,
                    uint32_t* queues, float* heap_keys, uint64_t* heap_payload,
-                   uint32_t* path_vertices, uint32_t* path_lengths, int lds_heap_nodes, void* stream);
+                   uint32_t* path_vertices, uint32_t* path_lengths, int lds_heap_nodes, int fix_branching,
+                   void* stream);
 
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);

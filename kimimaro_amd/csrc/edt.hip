@@ -89,108 +89,207 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
   }
 }
 
-// y / z pass.  blockDim = (64, 4): 64 lanes along x; every thread owns R consecutive positions along the
-// axis and walks outward from its group, so each row it loads (one coalesced 256-B segment per wave)
-// feeds R minima.  For output r of the group, the row at distance s to the left of the group is at
-// distance k = s + r, the one to the right at k = s + R-1-r.  A side of an output closes when its
-// same-label segment ends or when (w*k)^2 >= best (nothing farther can improve the minimum), so the
-// result is the exact minimum over the float expressions in any visiting order (== oracle ko_edt_axis).
-template <typename LT, bool LAST, int R>
+// y / z pass: best = min over the same-label segment of f[j] + (w*(i-j))^2, clamped by the segment
+// ends (label change, or the volume border when black_border).  The search walks outward and stops as
+// soon as (w*k)^2 >= best -- nothing farther can improve the minimum -- so the result is the exact
+// minimum over the float expressions in any visiting order (== oracle ko_edt_axis).
+//
+// A workgroup (64 x 4 threads) owns 64 lanes along x times T = 64 positions along the axis.
+//  * stage: rows [A0-H, A0+T+H) of f go to LDS (H = 32, 32 KiB, bank = lane: conflict free); at the same
+//    time every column gets a 128-bit "label changes at this row" mask and a "background" mask.
+//  * limits: the number of same-label rows below / above an output is a clz / ctz on its column's mask --
+//    no label is loaded or compared inside the search loop.
+//  * search: probes read LDS only.  Runs or windows that leave the staged rows (objects wider than H
+//    voxels) continue in a slow path on global memory.
+// Every f element is fetched from L2/HBM (T+2H)/T = 2x instead of 2*window times.
+#define KH_EDT_T 64
+#define KH_EDT_H 32
+#define KH_EDT_ROWS (KH_EDT_T + 2 * KH_EDT_H)
+
+__device__ __forceinline__ int zeros_down(unsigned long long lo, unsigned long long hi, int p) {
+  // number of consecutive zero bits at p, p-1, ... ; p+1 when none is set down to bit 0
+  if (p >= 64) {
+    const unsigned long long x = hi << (127 - p);
+    if (x) return __clzll((long long)x);
+    return (p - 63) + (lo ? __clzll((long long)lo) : 64);
+  }
+  const unsigned long long x = lo << (63 - p);
+  return x ? __clzll((long long)x) : p + 1;
+}
+__device__ __forceinline__ int zeros_up(unsigned long long lo, unsigned long long hi, int p) {
+  // number of consecutive zero bits at p, p+1, ... ; 128-p when none is set up to bit 127  (0 <= p <= 128)
+  if (p >= 128) return 0;
+  if (p < 64) {
+    const unsigned long long x = lo >> p;
+    if (x) return __ffsll((long long)x) - 1;
+    return (64 - p) + (hi ? __ffsll((long long)hi) - 1 : 64);
+  }
+  const unsigned long long x = hi >> (p - 64);
+  return x ? __ffsll((long long)x) - 1 : 128 - p;
+}
+
+template <typename LT, bool LAST>
 __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border) {
-  // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride
-  const int xt = (sx + 63) >> 6, at = (n + 4 * R - 1) / (4 * R);
+  __shared__ float tile[KH_EDT_ROWS * 64];
+  __shared__ unsigned long long part[4][4][64];  // [ly][chg lo, chg hi, bg lo, bg hi][lx]
+  // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride ; blockDim = (64, 4)
+  const int xt = (sx + 63) >> 6, at = (n + KH_EDT_T - 1) / KH_EDT_T;
   const int64_t ntiles = (int64_t)xt * at * m;
   const int64_t nblk = gridDim.x;
   const int64_t per_xcd = (nblk + 7) / 8;
   const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t stride = per_xcd * 8;
+  const int lx = threadIdx.x, ly = threadIdx.y;
   for (int64_t t = logical; t < ntiles; t += stride) {
     const int tx = (int)(t % xt);
     const int64_t rr = t / xt;
     const int ta = (int)(rr % at);
     const int o = (int)(rr / at);
-    const int x = (tx << 6) + threadIdx.x;
-    const int a0 = (ta * 4 + threadIdx.y) * R;
-    if (x >= sx || a0 >= n) continue;
+    const int x = (tx << 6) + lx;
+    const int A0 = ta * KH_EDT_T;
     const int64_t base = x + (int64_t)o * ostride;
-    LT L[R];
-    float f[R], best[R];
-    bool lo[R], ro[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const bool valid = a0 + r < n;
-      const int64_t i = base + (int64_t)(valid ? a0 + r : a0) * astride;
-      L[r] = valid ? lab[i] : (LT)0;
-      f[r] = valid ? fin[i] : 0.0f;
-      best[r] = (L[r] != 0) ? f[r] : 0.0f;
-      lo[r] = ro[r] = (L[r] != 0);
-    }
-    // candidates inside the group, nearest first
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-#pragma unroll
-      for (int d = 1; d < R; d++) {
-        const float dd = w * (float)d;
-        const float tt = dd * dd;
-        if (r - d >= 0 && lo[r]) {
-          if (tt >= best[r]) lo[r] = false;
-          else if (L[r - d] != L[r]) { lo[r] = false; best[r] = tt; }
-          else { const float c = f[r - d] + tt; if (c < best[r]) best[r] = c; }
+    __syncthreads();  // previous tile fully consumed
+    unsigned long long c_lo = 0, c_hi = 0, b_lo = 0, b_hi = 0;
+    {
+      // thread (lx, ly) stages the 32 consecutive rows [32*ly, 32*ly+32): the label of the previous row
+      // is the previous iteration's register, so labels are read once (+1 row per thread).
+      const int rbeg = ly * (KH_EDT_ROWS / 4);
+      const int pbeg = A0 - KH_EDT_H + rbeg;
+      LT Lp = 0;
+      if (x < sx && pbeg - 1 >= 0 && pbeg - 1 < n) Lp = lab[base + (int64_t)(pbeg - 1) * astride];
+      unsigned int cm = 0, bm = 0;
+#pragma unroll 8
+      for (int j = 0; j < KH_EDT_ROWS / 4; j++) {
+        const int pos = pbeg + j;
+        const bool valid = x < sx && pos >= 0 && pos < n;
+        float v = 0.0f;
+        LT L = 0;
+        if (valid) {
+          const int64_t q = base + (int64_t)pos * astride;
+          v = fin[q];
+          L = lab[q];
         }
-        if (r + d < R && ro[r]) {
-          if (tt >= best[r]) ro[r] = false;
-          else if (a0 + r + d >= n) { ro[r] = false; if (black_border) best[r] = tt; }
-          else if (L[r + d] != L[r]) { ro[r] = false; best[r] = tt; }
-          else { const float c = f[r + d] + tt; if (c < best[r]) best[r] = c; }
-        }
+        tile[(rbeg + j) * 64 + lx] = v;
+        // a row outside the volume, or the first row of the volume, or a label change, ends every run
+        const bool chg = !valid || pos == 0 || L != Lp;
+        const bool bg = !valid || L == 0;
+        cm |= (chg ? 1u : 0u) << j;
+        bm |= (bg ? 1u : 0u) << j;
+        Lp = L;
       }
+      // rows of ly = 0,1 live in the low word, ly = 2,3 in the high word
+      const unsigned long long cw = (unsigned long long)cm << ((ly & 1) * 32);
+      const unsigned long long bw = (unsigned long long)bm << ((ly & 1) * 32);
+      if (ly < 2) { c_lo = cw; b_lo = bw; } else { c_hi = cw; b_hi = bw; }
     }
-    bool anyl = false, anyr = false;
-#pragma unroll
-    for (int r = 0; r < R; r++) { anyl |= lo[r]; anyr |= ro[r]; }
-    for (int s = 1; anyl || anyr; s++) {
-      if (anyl) {
-        const int j = a0 - s;
-        LT Lj = 0;
-        float fj = 0.0f;
-        if (j >= 0) { const int64_t q = base + (int64_t)j * astride; Lj = lab[q]; fj = fin[q]; }
-        anyl = false;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if (lo[r]) {
-            const float dd = w * (float)(s + r);
-            const float tt = dd * dd;
-            if (tt >= best[r]) lo[r] = false;
-            else if (j < 0) { lo[r] = false; if (black_border) best[r] = tt; }
-            else if (Lj != L[r]) { lo[r] = false; best[r] = tt; }
-            else { const float c = fj + tt; if (c < best[r]) best[r] = c; anyl = true; }
+    part[ly][0][lx] = c_lo; part[ly][1][lx] = c_hi; part[ly][2][lx] = b_lo; part[ly][3][lx] = b_hi;
+    __syncthreads();
+    if (x >= sx) continue;
+    c_lo = part[0][0][lx] | part[1][0][lx] | part[2][0][lx] | part[3][0][lx];
+    c_hi = part[0][1][lx] | part[1][1][lx] | part[2][1][lx] | part[3][1][lx];
+    b_lo = part[0][2][lx] | part[1][2][lx] | part[2][2][lx] | part[3][2][lx];
+    b_hi = part[0][3][lx] | part[1][3][lx] | part[2][3][lx] | part[3][3][lx];
+    for (int al = ly; al < KH_EDT_T; al += 4) {
+      const int a = A0 + al;
+      if (a >= n) break;
+      const int r0 = al + KH_EDT_H;  // my row in the tile
+      const int64_t i = base + (int64_t)a * astride;
+      float best = 0.0f;
+      const bool bg = ((r0 < 64 ? b_lo >> r0 : b_hi >> (r0 - 64)) & 1ull) != 0;
+      if (!bg) {
+        const int c0 = r0 * 64 + lx;
+        best = tile[c0];
+        // same-label rows below / above inside the staged rows
+        int nl = zeros_down(c_lo, c_hi, r0);
+        int nr = zeros_up(c_lo, c_hi, r0 + 1);
+        const bool lunk = nl > r0;                     // no change found down to the first staged row
+        const bool runk = r0 + 1 + nr >= KH_EDT_ROWS;  // none up to the last staged row
+        if (lunk) nl = r0;
+        if (runk) nr = KH_EDT_ROWS - 1 - r0;
+        // segment ends known here: a differing voxel (always a candidate) or the volume border
+        if (!lunk && (a - nl - 1 >= 0 || black_border)) { const float d = w * (float)(nl + 1); const float tt = d * d; if (tt < best) best = tt; }
+        if (!runk && (a + nr + 1 < n || black_border)) { const float d = w * (float)(nr + 1); const float tt = d * d; if (tt < best) best = tt; }
+        const int k1 = max(nl, nr);
+        int k = 1;
+        bool open = true;
+        // Search inside the staged rows.  Three phases: both sides valid (k <= min(nl,nr)), then only the
+        // longer side.  Groups of 4 steps: the probes are fetched with constant offsets from one base
+        // address before any is consumed, no clamps, no per-step branches; the bound (w*k)^2 >= best is
+        // tested once per group (a candidate whose (w*k)^2 exceeds `best` cannot lower it since f >= 0).
+        const float* __restrict__ pc = &tile[c0];
+        const int kb = min(min(nl, nr), k1);
+        for (; k + 3 <= kb; k += 4) {
+          const float d0 = w * (float)k;
+          if (d0 * d0 >= best) { open = false; break; }
+          const float* __restrict__ pl = pc - k * 64;
+          const float* __restrict__ pr = pc + k * 64;
+          const float l0 = pl[0], l1 = pl[-64], l2 = pl[-128], l3 = pl[-192];
+          const float r0v = pr[0], r1 = pr[64], r2 = pr[128], r3 = pr[192];
+          const float d1 = w * (float)(k + 1), d2 = w * (float)(k + 2), d3 = w * (float)(k + 3);
+          const float t0 = d0 * d0, t1 = d1 * d1, t2 = d2 * d2, t3 = d3 * d3;
+          best = fminf(best, fminf(l0 + t0, r0v + t0));
+          best = fminf(best, fminf(l1 + t1, r1 + t1));
+          best = fminf(best, fminf(l2 + t2, r2 + t2));
+          best = fminf(best, fminf(l3 + t3, r3 + t3));
+        }
+        for (; open && k <= kb; k++) {
+          const float d = w * (float)k;
+          const float tt = d * d;
+          if (tt >= best) { open = false; break; }
+          best = fminf(best, fminf(pc[-k * 64] + tt, pc[k * 64] + tt));
+        }
+        if (open && k1 > kb) {
+          // one side left; `sgn` selects it
+          const int sgn = nl > nr ? -64 : 64;
+          for (; k + 3 <= k1; k += 4) {
+            const float d0 = w * (float)k;
+            if (d0 * d0 >= best) { open = false; break; }
+            const float* __restrict__ pp = pc + k * sgn;
+            const float v0 = pp[0], v1 = pp[sgn], v2 = pp[2 * sgn], v3 = pp[3 * sgn];
+            const float d1 = w * (float)(k + 1), d2 = w * (float)(k + 2), d3 = w * (float)(k + 3);
+            best = fminf(best, fminf(v0 + d0 * d0, v1 + d1 * d1));
+            best = fminf(best, fminf(v2 + d2 * d2, v3 + d3 * d3));
+          }
+          for (; open && k <= k1; k++) {
+            const float d = w * (float)k;
+            const float tt = d * d;
+            if (tt >= best) { open = false; break; }
+            best = fminf(best, pc[k * sgn] + tt);
           }
         }
-      }
-      if (anyr) {
-        const int j = a0 + R - 1 + s;
-        LT Lj = 0;
-        float fj = 0.0f;
-        if (j < n) { const int64_t q = base + (int64_t)j * astride; Lj = lab[q]; fj = fin[q]; }
-        anyr = false;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if (ro[r]) {
-            const float dd = w * (float)(s + R - 1 - r);
-            const float tt = dd * dd;
-            if (tt >= best[r]) ro[r] = false;
-            else if (j >= n) { ro[r] = false; if (black_border) best[r] = tt; }
-            else if (Lj != L[r]) { ro[r] = false; best[r] = tt; }
-            else { const float c = fj + tt; if (c < best[r]) best[r] = c; anyr = true; }
+        if (open && (lunk || runk)) {
+          // slow path: the run leaves the staged rows; keep walking on global memory, labels checked
+          const LT L = lab[i];
+          bool lo = lunk, ro = runk;
+          for (k = min(nl, nr) + 1; lo || ro; k++) {
+            const float d = w * (float)k;
+            const float tt = d * d;
+            if (tt >= best) break;
+            if (lo && k > nl) {
+              const int j = a - k;
+              if (j < 0) { lo = false; if (black_border) best = tt; }
+              else {
+                const int64_t q = base + (int64_t)j * astride;
+                if (lab[q] != L) { lo = false; best = tt; }
+                else { const float c = fin[q] + tt; if (c < best) best = c; }
+              }
+            }
+            if (ro && k > nr) {
+              const int j = a + k;
+              if (j >= n) { ro = false; if (black_border && tt < best) best = tt; }
+              else {
+                const int64_t q = base + (int64_t)j * astride;
+                if (lab[q] != L) { ro = false; if (tt < best) best = tt; }
+                else { const float c = fin[q] + tt; if (c < best) best = c; }
+              }
+            }
           }
         }
+        if (LAST) best = sqrtf(best);
       }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (a0 + r < n) fout[base + (int64_t)(a0 + r) * astride] = LAST ? sqrtf(best[r]) : best[r];
+      fout[i] = best;
     }
   }
 }
@@ -223,17 +322,16 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[1], st));
   }
   auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last) -> int {
-    constexpr int R = 4;
-    const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + 4 * R - 1) / (4 * R)) * m;
+    const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + KH_EDT_T - 1) / KH_EDT_T) * m;
     int64_t grid = ntiles < 16384 ? ntiles : 16384;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];
     float* fout = bufs[cur ^ 1];
     if (last)
-      hipLaunchKernelGGL((edt_axis_kernel<LT, true, R>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
+      hipLaunchKernelGGL((edt_axis_kernel<LT, true>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
                          astride, m, ostride, w, black_border);
     else
-      hipLaunchKernelGGL((edt_axis_kernel<LT, false, R>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
+      hipLaunchKernelGGL((edt_axis_kernel<LT, false>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
                          astride, m, ostride, w, black_border);
     KH_LAUNCH_CHECK();
     cur ^= 1;

@@ -83,12 +83,14 @@ __device__ __forceinline__ void flag_clear(uint8_t* base, uint32_t v, uint32_t b
 }
 
 // MODE 0: EDF (edge length by direction).  MODE 1: railroad (cost = pdrf of the entered voxel, rails
-// absorb, stops once everything at or below the nearest rail is final).
+// absorb, stops once everything at or below the nearest rail is final).  MODE 2: parental field
+// (trace.py:155, fix_branching=False): field costs, no rails, runs to completion.
 // On return distances below the final threshold are exact (ctl->best_rail set for MODE 1).
 template <int MODE>
 __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ wfield,
                      float* dist, uint8_t* qstate, uint32_t source, Queues q, Ctl* ctl, float delta_floor) {
   constexpr bool RAIL = MODE == 1;
+  constexpr bool FIELD = MODE != 0;  // MODE 2: dijkstra3d.parental_field -- field weights, no rails, runs to completion
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
@@ -120,7 +122,7 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
         if (!((nbrmask[u] >> k) & 1u)) continue;
         const float du = ld_f32_l2(&dist[u]);
         const uint32_t v = u + (uint32_t)g.off[k];
-        const float wn = RAIL ? wfield[v] : g.w[k];
+        const float wn = FIELD ? wfield[v] : g.w[k];
         const float nd = du + wn;
         const uint32_t nb = __float_as_uint(nd);
         const uint32_t old = atomicMin(reinterpret_cast<uint32_t*>(&dist[v]), nb);
@@ -512,6 +514,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
 
 // wave 0 only: canonical predecessor walk (oracle ko_pred / ko_railroad).  Writes the path (rail end
 // first) to out[0..]; returns its length (0 on failure).
+template <bool RAILS>
 __device__ uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ pdrf,
                               const float* dist, uint32_t rail_end, uint32_t target, uint32_t* out, uint32_t cap,
                               uint32_t* status) {
@@ -526,7 +529,7 @@ __device__ uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nb
     if (lane < 26 && ((nbrmask[v] >> lane) & 1u)) {
       const uint32_t u = v + (uint32_t)g.off[lane];
       const float fu = pdrf[u];
-      if (fu != 0.0f) {
+      if (!RAILS || fu != 0.0f) {
         const float du = ld_f32_l2(&dist[u]);
         if (du != KH_INF) {
           const float c = du + fv;
@@ -542,7 +545,7 @@ __device__ uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nb
     if (key == NONE64) { if (lane == 0) atomicOr(status, KH_ST_NO_RAIL); return 0; }
     const uint32_t u = (uint32_t)key;
     const float du = __uint_as_float((uint32_t)(key >> 32));
-    if (du >= dv && v != rail_end) { if (lane == 0) atomicOr(status, KH_ST_PLATEAU); return 0; }
+    if (du >= dv && (!RAILS || v != rail_end)) { if (lane == 0) atomicOr(status, KH_ST_PLATEAU); return 0; }
     if (n >= cap) { if (lane == 0) atomicOr(status, KH_ST_PATH_OVERFLOW); return 0; }
     if (lane == 0) out[n] = u;
     n++;
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
                                                           const uint32_t* __restrict__ manual_targets,
                                                           float scale, float constant, uint32_t* queues, float* heap_keys,
                                                           uint64_t* heap_payload, uint32_t* path_vertices,
-                                                          uint32_t* path_lengths, uint32_t lds_nodes) {
+                                                          uint32_t* path_lengths, uint32_t lds_nodes, int fix_branching) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Ctl ctl;
   kh_label_t* task = &tasks[blockIdx.x];
@@ -603,7 +606,12 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; }
     return;
   }
-  if (tid == 0) pdrf[root] = 0.0f;                      // trace.py:220
+  if (fix_branching) {
+    if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
+  } else {
+    // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
+    sssp<2>(g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
+  }
   __syncthreads();
   while ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths) {
     // ---- target selection, trace.py:225-230
@@ -641,7 +649,19 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
       break;
     }
     uint32_t* out = pverts + nverts;
-    if (pdrf[target] == 0.0f) {
+    if (!fix_branching) {
+      // dijkstra3d.path_from_parents (trace.py:244): walk target -> root, return root -> target
+      if (tid == 0) ctl.u0 = 0;
+      __syncthreads();
+      if (wave == 0) {
+        const uint32_t n = backtrack<false>(g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, &ctl.status);
+        for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
+        if (lane == 0) ctl.u0 = n;
+      }
+      __syncthreads();
+      plen = ctl.u0;
+      if (plen == 0) break;
+    } else if (pdrf[target] == 0.0f) {
       if (tid == 0) out[0] = target;
       plen = 1;
     } else {
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
       if (br == NONE64) {
         if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
       } else if (wave == 0) {
-        const uint32_t n = backtrack(g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, &ctl.status);
+        const uint32_t n = backtrack<true>(g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, &ctl.status);
         if (lane == 0) ctl.u0 = n;
       }
       __syncthreads();
@@ -682,7 +702,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     }
     // ---- rails, trace.py:261-263
     t_inval += clock64() - t0;
-    for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
+    if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
     if (tid == 0) plens[npaths] = plen;
     npaths++;
     nverts += plen;
@@ -690,6 +710,9 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     if (ctl.status) break;
   }
   __syncthreads();
+  if (!fix_branching) {  // leave dist = +inf behind
+    for (uint32_t i = tid; i < nf; i += nthr) st_f32_l2(&dist[list[i]], KH_INF);
+  }
   if (tid == 0) {
     task->n_paths = npaths;
     task->n_vertices = nverts;
@@ -778,7 +801,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
                               float* heap_keys, uint64_t* heap_payload, uint32_t* path_vertices, uint32_t* path_lengths,
-                              int lds_heap_nodes, void* stream) {
+                              int lds_heap_nodes, int fix_branching, void* stream) {
   if (int rc = require_device()) return rc;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
@@ -791,7 +814,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
     KH_HIP_CHECK(hipFuncSetAttribute((const void*)trace_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(trace_paths_kernel, dim3(ntasks), dim3(64), lds, (hipStream_t)stream, tasks, lists, list_daf, nbrmask, g,
                      dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_keys, heap_payload,
-                     path_vertices, path_lengths, (uint32_t)lds_heap_nodes);
+                     path_vertices, path_lengths, (uint32_t)lds_heap_nodes, fix_branching);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

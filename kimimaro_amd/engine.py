@@ -69,7 +69,7 @@ class Engine:
         if out is None:
             out = self.empty(n, t.float32)
         if workspace is None:
-            workspace = self.empty(n, t.float32)
+            workspace = self.empty(2 * n, t.float32)  # f32 ping-pong volume + two u16 run-limit volumes
         _abi.check(self.lib.kh_edt(self.ptr(d_labels), label_bytes, sx, sy, sz, float(anisotropy[0]),
                                    float(anisotropy[1]), float(anisotropy[2]), int(bool(black_border)),
                                    self.ptr(workspace), self.ptr(out), self.stream()))
@@ -100,8 +100,6 @@ class Engine:
         NONE32.  targets_before/after: list (per label) of lists of linear indices (LIFO stacks as in
         kimimaro/trace.py:225-228).  Returns a dict with per-label path arrays.
         """
-        if not fix_branching:
-            raise NotImplementedError("fix_branching=False (parental_field path) is not wired into the HIP path yet")
         t = self.torch
         lib = self.lib
         st = self.stream()
@@ -223,6 +221,7 @@ class Engine:
                                           P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive),
                                           P(d_qstate), P(d_tgt), np.float32(params["scale"]), np.float32(params["const"]),
                                           P(d_queues), P(d_hkeys), P(d_hpay), P(d_pverts), P(d_plens), nodes,
+                                          int(bool(fix_branching)),
                                           C.c_void_p(stream.cuda_stream)))
 
         launch(0, nbig, 8191, cur)

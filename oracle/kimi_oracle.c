@@ -79,6 +79,11 @@ static inline uint64_t ko_lab(const void* p, int bytes, int64_t i) {
   }
 }
 
+/* instrumentation (DESIGN.md sizing): search steps taken by the last ko_edt call, per axis pass */
+int64_t ko_edt_steps[2] = {0, 0};
+static int ko_edt_axis_id = 0;
+int64_t ko_get_edt_steps(int pass) { return ko_edt_steps[pass & 1]; }
+
 static void ko_edt_axis(const void* labels, int lb, float* f, int64_t n, int64_t stride,
                         int64_t base, float w, int black_border, float* tmp) {
   /* one line: positions base + i*stride, i in [0,n) ; tmp holds the input f */
@@ -92,6 +97,7 @@ static void ko_edt_axis(const void* labels, int lb, float* f, int64_t n, int64_t
       float d = w * (float)k;
       float t = d * d;
       if (t >= best) break;
+      ko_edt_steps[ko_edt_axis_id]++;
       if (left_open) {
         int64_t j = i - k;
         if (j < 0) { left_open = 0; if (black_border && t < best) best = t; }
@@ -137,9 +143,12 @@ int ko_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t 
   int64_t m = sy > sz ? sy : sz;
   float* tmp = (float*)malloc(sizeof(float) * (size_t)(m > 0 ? m : 1));
   if (!tmp) return KO_ENOMEM;
+  ko_edt_steps[0] = ko_edt_steps[1] = 0;
+  ko_edt_axis_id = 0;
   if (sy > 1 || black_border)
     for (int64_t z = 0; z < sz; z++) for (int64_t x = 0; x < sx; x++)
       ko_edt_axis(labels, label_bytes, out, sy, sx, x + sxy * z, wy, black_border, tmp);
+  ko_edt_axis_id = 1;
   if (sz > 1 || black_border)
     for (int64_t y = 0; y < sy; y++) for (int64_t x = 0; x < sx; x++)
       ko_edt_axis(labels, label_bytes, out, sz, sxy, x + sx * y, wz, black_border, tmp);

@@ -77,3 +77,53 @@ def test_skeletonize_matches_oracle(eng, an, nlab, shape):
         np.testing.assert_array_equal(got[k].edges, want[k].edges)
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
         assert got[k].space == "physical" and got[k].id == k
+
+
+@pytest.mark.parametrize("seed,an", [(10, (1, 1, 1)), (11, (16, 16, 40))])
+def test_trace_no_fix_branching_matches_oracle(eng, seed, an):
+    """fix_branching=False: parental field + path_from_parents (trace.py:155,244)."""
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    m = biggest_component(random_walk_tube((44, 40, 36), 3000 + seed, steps=50, step=3.0, radius=(1.2, 4.5)))
+    dbf = oracle.edt(m, an)
+    params = dict(scale=1.5, const=2 * an[0], pdrf_scale=100000, pdrf_exponent=4)
+    want = P.trace(m, dbf, anisotropy=an, fix_branching=False, return_paths=True, **params)
+    got = trace(m, dbf, anisotropy=an, fix_branching=False, return_paths=True, _engine=eng, **params)
+    assert len(got) == len(want) and len(got) > 0
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
+
+
+def test_manual_targets_and_root(eng):
+    """border-style forced root + extra targets before/after (intake.py:486-492, trace.py:225-228)."""
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    an = (16, 16, 40)
+    m = biggest_component(random_walk_tube((40, 40, 32), 4242, steps=45))
+    dbf = oracle.edt(m, an)
+    idx = np.flatnonzero(m.ravel(order="F"))
+    pts = [tuple(int(v) for v in p) for p in oracle.locs_to_pts(idx[[3, idx.size // 2, idx.size - 5, idx.size // 3]], m.shape)]
+    params = dict(scale=1.5, const=40, pdrf_scale=100000, pdrf_exponent=4)
+    kw = dict(anisotropy=an, root=pts[0], manual_targets_before=[pts[1], pts[2]], manual_targets_after=[pts[3]],
+              return_paths=True)
+    want = P.trace(m, dbf, **kw, **params)
+    got = trace(m, dbf, _engine=eng, **kw, **params)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
+
+
+def test_max_paths(eng):
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    m = biggest_component(random_walk_tube((40, 40, 32), 99, steps=45))
+    dbf = oracle.edt(m, (1, 1, 1))
+    params = dict(scale=1.0, const=1.0, pdrf_scale=100000, pdrf_exponent=4)
+    want = P.trace(m, dbf, max_paths=3, return_paths=True, **params)
+    got = trace(m, dbf, max_paths=3, return_paths=True, _engine=eng, **params)
+    assert len(got) == len(want) == 3
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))

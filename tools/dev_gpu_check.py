@@ -19,7 +19,7 @@ lab = voronoi_labels(shape, nl, seed=seed, pts_per_label=pts, step=24.0, anisotr
 print("gen", time.time() - t, flush=True)
 d = eng.to_device(lab)
 n = lab.size
-out = eng.empty(n, torch.float32); ws = eng.empty(n, torch.float32)
+out = eng.empty(n, torch.float32); ws = eng.empty(2 * n, torch.float32)
 for lb, dd in ((4, d),):
     for _ in range(2):
         eng.edt(dd, lb, shape, an, False, out, ws)
