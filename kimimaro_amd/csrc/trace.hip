@@ -58,6 +58,7 @@ struct Ctl {
   float T;
   uint32_t u0, u1, u2, u3;
   unsigned long long cyc3[3];
+  Geometry g;  // the 26 offsets / edge lengths are indexed per lane: keep them in LDS, not in SGPRs
 };
 
 // work lists hold voxel indices only; membership is tracked by two bits per voxel in `qstate`
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
   const uint32_t source = (mode == 2) ? task->root : task->source;
   const uint32_t* list = lists + task->list_offset;
   const uint32_t nf = task->count;
-  if (tid == 0) ctl.status = 0;
+  if (tid == 0) { ctl.status = 0; ctl.g = g; }
   for (uint32_t i = tid; i < nf; i += 256) st_f32_l2(&field[list[i]], KH_INF);
   __syncthreads();
   Queues q;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
-  sssp<0>(g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor);
+  sssp<0>(ctl.g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor);
   // farthest voxel: max finite distance, ties -> smallest linear index
   unsigned long long best = 0;
   for (uint32_t i = tid; i < nf; i += 256) {
@@ -281,17 +282,17 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
 //           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
 //           per memory round trip: 126 speculative child keys are fetched by the 64 lanes, the path
 //           is resolved from registers, and the nodes on it are moved up in one parallel step.
-// The heap lives in the label's slice of HBM scratch; its top `lcap` nodes are mirrored write-through in
-// LDS so that the first one or two 6-level chunks of every pop are LDS reads (lcap = 127 covers levels
-// 0-6, lcap = 8191 levels 0-12).
+// The heap lives in the label's slice of HBM scratch.  A write-through LDS mirror of heap levels 0-12 was
+// tried twice and measured 10-15 % SLOWER: the pop is bound by instruction issue of its single wave, not
+// by memory latency, and the mirror adds stores and a branch.
 struct Heap {
-  float* key;      // HBM scratch of this label: the authoritative copy of every node
+  float* key;      // HBM scratch of this label (L2 resident in practice)
   uint64_t* pay;   // (source index << 32) | voxel
-  float* lkey;     // LDS write-through mirror of nodes [0, lcap): lets whole 6-level chunks be read from LDS
-  uint64_t* lpay;
-  uint32_t lcap;
   uint32_t cap, n;
-  unsigned long long am0, am1;  // per-lane ancestor masks of the speculative sub-tree (see heap_init_lane)
+  // per-lane constants of the 126-node speculative sub-tree (children of node m: 2m+2, 2m+3; parent of
+  // m >= 2: (m-2)>>1).  Lane l holds node m = l ("slot 0", depths 1..6) and m = l+64 ("slot 1", depth 6).
+  unsigned long long am0, am1;  // slot-0 ballot bits of the node's ancestors (am0 including itself)
+  uint32_t sh0, j0, j1;         // heap index of my slot-0 node = ((hole+1) << sh0) - 1 + j0, slot 1: << 6, + j1
 };
 struct HNode { float k; uint32_t vox, src; };
 
@@ -303,30 +304,21 @@ __device__ __forceinline__ HNode hload(const Heap& h, uint32_t i) {
   n.src = (uint32_t)(p >> 32);
   return n;
 }
-__device__ __forceinline__ HNode hload_lds(const Heap& h, uint32_t i) {
-  HNode n;
-  n.k = h.lkey[i];
-  const uint64_t p = h.lpay[i];
-  n.vox = (uint32_t)p;
-  n.src = (uint32_t)(p >> 32);
-  return n;
-}
 __device__ __forceinline__ void hstore(const Heap& h, uint32_t i, float k, uint32_t vox, uint32_t src) {
-  const uint64_t p = ((uint64_t)src << 32) | vox;
   h.key[i] = k;
-  h.pay[i] = p;
-  if (i < h.lcap) { h.lkey[i] = k; h.lpay[i] = p; }
+  h.pay[i] = ((uint64_t)src << 32) | vox;
 }
 
-// The 6-level speculative sub-tree under a hole has 126 nodes m = 0..125 (children of m: 2m+2, 2m+3;
-// parent of m >= 2: (m-2)>>1).  Lane l holds nodes m = l ("slot 0") and m = l + 64 ("slot 1", depth 6
-// only).  am0 / am1 = the bits (in the slot-0 ballot) of the node's ancestors, am0 including itself.
 __device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
   unsigned long long a0 = 0, a1 = 0;
   for (int m = lane; ; m = (m - 2) >> 1) { a0 |= 1ull << m; if (m < 2) break; }
   if (lane + 64 < 126) for (int m = (lane + 62) >> 1; ; m = (m - 2) >> 1) { a1 |= 1ull << m; if (m < 2) break; }
   h.am0 = a0;
   h.am1 = a1;
+  const int d0 = 31 - __clz(lane + 2);
+  h.sh0 = (uint32_t)d0;
+  h.j0 = (uint32_t)(lane + 2 - (1 << d0));
+  h.j1 = (uint32_t)(lane + 2);
 }
 
 // all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
@@ -356,38 +348,29 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, float k, uint32_t vox, u
 // The wave fetches 6 levels (126 whole nodes, 2 per lane) per round trip.  A node is on the path iff it
 // and all its ancestors in the sub-tree beat their siblings: one sibling compare per lane, one ballot,
 // one mask test against the lane's constant ancestor mask.  The chunks stay in registers and every
-// write is issued at the end, so the load of `last` overlaps the whole descent.
-#define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels: heaps up to 2^30 nodes */
+// write is issued at the end, so the load of `last` overlaps the whole descent.  Loads are
+// unconditional (index clamped to 0, key masked to +inf): no divergent branches in the descent.
+// 32-bit index math is safe: the hole of chunk c sits at level 6c <= 24, so (hole+1) << 6 < 2^31.
+#define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
 __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
   const uint32_t len = h.n - 1u;
   h.n = len;
   if (len == 0) return;
   const HNode last = hload(h, len);  // consumed only after the descent
-  const int d0 = 31 - __clz(lane + 2);
-  const uint32_t j0 = (uint32_t)(lane + 2 - (1 << d0)), j1 = (uint32_t)(lane + 2);  // slot 1: depth 6, offset lane+2
   const bool left = (lane & 1) == 0;
   HNode c0[KH_POP_CHUNKS], c1[KH_POP_CHUNKS];
-  uint32_t x0[KH_POP_CHUNKS], x1[KH_POP_CHUNKS];  // heap index of my node if it is on the path, else ~0
+  uint32_t x0[KH_POP_CHUNKS], x1[KH_POP_CHUNKS];  // heap index of my node if it is on the path, else 0
   uint32_t hole = 0;
-  bool more = true;
   int nch = 0;
 #pragma unroll
   for (int c = 0; c < KH_POP_CHUNKS; c++) {
-    if (more && 2ull * hole + 1ull < len) {
-      nch = c + 1;
-      x0[c] = 0xFFFFFFFFu; x1[c] = 0xFFFFFFFFu;
-      const uint64_t i0 = (((uint64_t)hole + 1u) << d0) - 1u + j0;
-      const uint64_t i1 = (((uint64_t)hole + 1u) << 6) - 1u + j1;
+    if (nch == c && 2u * hole + 1u < len) {  // wave uniform
+      const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
+      const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
       const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
-      HNode n0, n1;
-      n0.k = KH_INF; n0.vox = 0; n0.src = 0; n1 = n0;
-      if ((((uint64_t)hole + 1u) << 6) + 62u < h.lcap) {  // the whole chunk is mirrored in LDS (wave uniform)
-        if (e0) n0 = hload_lds(h, (uint32_t)i0);
-        if (e1) n1 = hload_lds(h, (uint32_t)i1);
-      } else {
-        if (e0) n0 = hload(h, (uint32_t)i0);
-        if (e1) n1 = hload(h, (uint32_t)i1);
-      }
+      HNode n0 = hload(h, e0 ? i0 : 0u), n1 = hload(h, e1 ? i1 : 0u);
+      n0.k = e0 ? n0.k : KH_INF;
+      n1.k = e1 ? n1.k : KH_INF;
       // a node beats its sibling if it is the left one and right.key >= left.key, or the right one and
       // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
       const float s0 = __shfl_xor(n0.k, 1), s1 = __shfl_xor(n1.k, 1);
@@ -398,28 +381,30 @@ __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
       const bool on1 = w1 && ((W0 & h.am1) == h.am1);
       const unsigned long long P0 = __ballot(on0), P1 = __ballot(on1);
       c0[c] = n0; c1[c] = n1;
-      if (on0) x0[c] = (uint32_t)i0;
-      if (on1) x1[c] = (uint32_t)i1;
+      x0[c] = on0 ? i0 : 0u;
+      x1[c] = on1 ? i1 : 0u;
       // next hole = the depth-6 node of the path, if the path got that deep
-      if (P1) hole = rdlane_u32((uint32_t)i1, __ffsll((long long)P1) - 1);
-      else if (P0 >> 62) hole = rdlane_u32((uint32_t)i0, (P0 >> 63) ? 63 : 62);
-      else more = false;  // the path ended at a leaf above depth 6
-    } else more = false;
+      if (P1) { hole = rdlane_u32(i1, __ffsll((long long)P1) - 1); nch = c + 1; }
+      else if (P0 >> 62) { hole = rdlane_u32(i0, (P0 >> 63) ? 63 : 62); nch = c + 1; }
+      else nch = -(c + 1);  // the path ended at a leaf above depth 6: stop descending
+    }
   }
+  if (nch < 0) nch = -nch;
   // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
   // deepest such node (or the root).  Path keys are non-decreasing with depth.
   uint32_t deepest = 0;
   const float vk = last.k;
 #pragma unroll
   for (int c = 0; c < KH_POP_CHUNKS; c++) {
-    if (c >= nch) break;
-    const bool mv0 = x0[c] != 0xFFFFFFFFu && c0[c].k < vk;
-    const bool mv1 = x1[c] != 0xFFFFFFFFu && c1[c].k < vk;
-    if (mv0) hstore(h, (x0[c] - 1u) >> 1, c0[c].k, c0[c].vox, c0[c].src);
-    if (mv1) hstore(h, (x1[c] - 1u) >> 1, c1[c].k, c1[c].vox, c1[c].src);
-    const unsigned long long M0 = __ballot(mv0), M1 = __ballot(mv1);
-    if (M1) deepest = rdlane_u32(x1[c], __ffsll((long long)M1) - 1);
-    else if (M0) deepest = rdlane_u32(x0[c], 63 - __clzll((long long)M0));
+    if (c < nch) {
+      const bool mv0 = x0[c] != 0u && c0[c].k < vk;
+      const bool mv1 = x1[c] != 0u && c1[c].k < vk;
+      if (mv0) hstore(h, (x0[c] - 1u) >> 1, c0[c].k, c0[c].vox, c0[c].src);
+      if (mv1) hstore(h, (x1[c] - 1u) >> 1, c1[c].k, c1[c].vox, c1[c].src);
+      const unsigned long long M0 = __ballot(mv0), M1 = __ballot(mv1);
+      if (M1) deepest = rdlane_u32(x1[c], __ffsll((long long)M1) - 1);
+      else if (M0) deepest = rdlane_u32(x0[c], 63 - __clzll((long long)M0));
+    }
   }
   if (lane == 0) hstore(h, deepest, last.k, last.vox, last.src);
 }
@@ -444,7 +429,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
   while (h.n > 0) {
-    const HNode top = h.lcap ? hload_lds(h, 0) : hload(h, 0);
+    const HNode top = hload(h, 0);
     const uint32_t vox = top.vox, si = top.src;
     const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
     tt = clock64();
@@ -562,8 +547,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
                                                           const uint32_t* __restrict__ manual_targets,
                                                           float scale, float constant, uint32_t* queues, float* heap_keys,
                                                           uint64_t* heap_payload, uint32_t* path_vertices,
-                                                          uint32_t* path_lengths, uint32_t lds_nodes, int fix_branching) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+                                                          uint32_t* path_lengths, int fix_branching) {
   __shared__ Ctl ctl;
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
@@ -583,9 +567,6 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   heap.pay = heap_payload + task->heap_offset;
   heap.cap = task->heap_capacity;
   heap.n = 0;
-  heap.lcap = lds_nodes;
-  heap.lpay = reinterpret_cast<uint64_t*>(smem);
-  heap.lkey = reinterpret_cast<float*>(smem + 8 * (size_t)lds_nodes);
   heap_init_lane(heap, lane);
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
@@ -600,7 +581,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   const uint32_t max_paths = task->max_paths ? task->max_paths : nf;  // trace.py:214-215
   uint32_t npaths = 0, nverts = 0;
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
-  if (tid == 0) { ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; }
+  if (tid == 0) { ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g; }
   __syncthreads();
   if (nb + na >= max_paths) {                           // trace.py:217-218
     if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; }
@@ -610,7 +591,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
   } else {
     // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
-    sssp<2>(g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
+    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
   }
   __syncthreads();
   while ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths) {
@@ -654,7 +635,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
       if (tid == 0) ctl.u0 = 0;
       __syncthreads();
       if (wave == 0) {
-        const uint32_t n = backtrack<false>(g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, &ctl.status);
+        const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, &ctl.status);
         for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
         if (lane == 0) ctl.u0 = n;
       }
@@ -665,14 +646,14 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
       if (tid == 0) out[0] = target;
       plen = 1;
     } else {
-      sssp<1>(g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f);
+      sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f);
       const unsigned long long br = ctl.best_rail;
       if (tid == 0) { ctl.u0 = 0; ctl.u2 += ctl.n_touched; }
       __syncthreads();
       if (br == NONE64) {
         if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
       } else if (wave == 0) {
-        const uint32_t n = backtrack<true>(g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, &ctl.status);
+        const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, &ctl.status);
         if (lane == 0) ctl.u0 = n;
       }
       __syncthreads();
@@ -693,7 +674,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     t_rail += clock64() - t0; t0 = clock64();
     if (valid > 0) {
       if (wave == 0) {
-        const uint32_t c = invalidate_ball(g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
+        const uint32_t c = invalidate_ball(ctl.g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
                                            &ctl.u3, ctl.cyc3);
         if (lane == 0) ctl.u1 = c;
       }
@@ -809,12 +790,10 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (lds_heap_nodes < 0 || lds_heap_nodes > 13000) { set_error("kh_trace_paths: lds_heap_nodes out of range"); return KH_EINVAL; }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
-  const size_t lds = (size_t)lds_heap_nodes * 12;
-  if (lds > 48 * 1024)
-    KH_HIP_CHECK(hipFuncSetAttribute((const void*)trace_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(trace_paths_kernel, dim3(ntasks), dim3(64), lds, (hipStream_t)stream, tasks, lists, list_daf, nbrmask, g,
+  (void)lds_heap_nodes;  // reserved: an LDS mirror of the heap tops was measured twice to make things slower
+  hipLaunchKernelGGL(trace_paths_kernel, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, tasks, lists, list_daf, nbrmask, g,
                      dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_keys, heap_payload,
-                     path_vertices, path_lengths, (uint32_t)lds_heap_nodes, fix_branching);
+                     path_vertices, path_lengths, fix_branching);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

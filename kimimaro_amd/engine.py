@@ -32,9 +32,6 @@ class Engine:
         self.lib = _abi.require_gpu()
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
-        import os
-        v = os.environ.get("KIMI_LDS_NODES")
-        self.lds_heap_nodes = int(v) if v else None  # override of the LDS share of the invalidation heaps (tuning knob)
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -204,29 +201,11 @@ class Engine:
         d_hpay = self.empty(int(hcap.sum()), t.int64)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
-        # The labels are sorted by size.  The biggest ones (deep heaps, they are the tail of the run) get an
-        # LDS mirror of heap levels 0-12 (8191 nodes, 96 KiB => one such workgroup per CU); the rest mirror
-        # levels 0-6 (127 nodes) and share the remaining LDS.  Two launches on two streams, same kernel.
-        nbig = min(nl, 256) if self.lds_heap_nodes is None else 0
-        small_nodes = 127 if self.lds_heap_nodes is None else int(self.lds_heap_nodes)
-        tsz = _abi.LABEL_T.itemsize
-        cur = t.cuda.current_stream(self.device)
-        side = t.cuda.Stream(self.device)
-        side.wait_stream(cur)
-
-        def launch(first, count, nodes, stream):
-            if count <= 0:
-                return
-            _abi.check(lib.kh_trace_paths(C.c_void_p(d_tasks.data_ptr() + first * tsz), count, P(d_lists), P(d_ldaf),
-                                          P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive),
-                                          P(d_qstate), P(d_tgt), np.float32(params["scale"]), np.float32(params["const"]),
-                                          P(d_queues), P(d_hkeys), P(d_hpay), P(d_pverts), P(d_plens), nodes,
-                                          int(bool(fix_branching)),
-                                          C.c_void_p(stream.cuda_stream)))
-
-        launch(0, nbig, 8191, cur)
-        launch(nbig, nl - nbig, small_nodes, side)
-        cur.wait_stream(side)
+        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first
+        _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
+                                      P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
+                                      np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_hkeys),
+                                      P(d_hpay), P(d_pverts), P(d_plens), 0, int(bool(fix_branching)), st))
         mark("paths")
         out_tasks = d_tasks.cpu().numpy().view(_abi.LABEL_T).copy()
         global LAST_TASKS
