@@ -234,7 +234,7 @@ def main():
     phases = {}
     prev = None
     for name, ts in timings:
-        if prev is not None:
+        if prev is not None and name != "setup":
             phases[name] = round(ts - prev, 4)
         prev = ts
     tk = E.LAST_TASKS

@@ -118,6 +118,12 @@ typedef struct kh_label_t {
   uint32_t cyc_pop;      /* out:   heap pops */
   uint32_t cyc_push;     /* out:   heap pushes */
   uint32_t cyc_fire;     /* out:   neighbour evaluation of live pops */
+  /* soma mode (kimimaro/trace.py:119-134,160-168,246-251); all zero for ordinary labels */
+  uint32_t soma_mode;    /* 1: root is the soma centre, one-off invalidation around it, paths are trimmed */
+  float fsr;             /* free_space_radius of the DAF search = DBF[root] (trace.py:134) */
+  float soma_radius;     /* dbf_max * soma_invalidation_scale + soma_invalidation_const (float32, trace.py:127) */
+  float soma_scale;      /* soma_invalidation_scale */
+  float soma_const;      /* soma_invalidation_const */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------

@@ -29,7 +29,7 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 31 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 36 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
@@ -39,8 +39,9 @@ LABEL_T = np.dtype([
     ("status", "<u4"), ("stat_settled", "<u4"), ("stat_heap_pushes", "<u4"),
     ("cyc_target", "<u4"), ("cyc_rail", "<u4"), ("cyc_inval", "<u4"),
     ("cyc_pop", "<u4"), ("cyc_push", "<u4"), ("cyc_fire", "<u4"),
+    ("soma_mode", "<u4"), ("fsr", "<f4"), ("soma_radius", "<f4"), ("soma_scale", "<f4"), ("soma_const", "<f4"),
 ])
-assert LABEL_T.itemsize == 124
+assert LABEL_T.itemsize == 144
 
 ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
            8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",

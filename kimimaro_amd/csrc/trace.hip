@@ -89,7 +89,8 @@ __device__ __forceinline__ void flag_clear(uint8_t* base, uint32_t v, uint32_t b
 // On return distances below the final threshold are exact (ctl->best_rail set for MODE 1).
 template <int MODE>
 __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ wfield,
-                     float* dist, uint8_t* qstate, uint32_t source, Queues q, Ctl* ctl, float delta_floor) {
+                     float* dist, uint8_t* qstate, uint32_t source, Queues q, Ctl* ctl, float delta_floor,
+                     uint32_t preseeded_far = 0) {
   constexpr bool RAIL = MODE == 1;
   constexpr bool FIELD = MODE != 0;  // MODE 2: dijkstra3d.parental_field -- field weights, no rails, runs to completion
   const int tid = threadIdx.x;
@@ -100,7 +101,7 @@ __device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, co
   uint32_t* far = q.c;
   float T = RAIL ? 1e-45f : delta_floor;
   if (tid == 0) {
-    ctl->n_cur = 1; ctl->n_next = 0; ctl->n_far = 0; ctl->n_far2 = 0;
+    ctl->n_cur = 1; ctl->n_next = 0; ctl->n_far = preseeded_far; ctl->n_far2 = 0;  // far list q.c may hold seeds
     ctl->n_touched = 0;
     ctl->best_rail = NONE64;
     cur[0] = source;
@@ -241,7 +242,36 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
-  sssp<0>(ctl.g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor);
+  uint32_t seeded = 0;
+  if (mode == 2 && task->fsr > 0.0f) {
+    // free_space_radius (trace.py:134,142; dijkstra3d source absent, restated in oracle ko_edf): label
+    // voxels closer than the radius in a straight line get that distance and seed the search (far list).
+    const float fsr = task->fsr;
+    const uint32_t sxu = (uint32_t)g.sx, sxy = (uint32_t)g.sxy;
+    const uint32_t z0 = source / sxy, r0 = source - z0 * sxy, y0 = r0 / sxu, x0 = r0 - y0 * sxu;
+    if (tid == 0) ctl.u0 = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < nf; i += 256) {
+      const uint32_t v = list[i];
+      if (v == source) continue;
+      const uint32_t z = v / sxy, r = v - z * sxy, y = r / sxu, x = r - y * sxu;
+      const float a = g.wx * (float)((int)x - (int)x0), b = g.wy * (float)((int)y - (int)y0), c = g.wz * (float)((int)z - (int)z0);
+      float s2 = a * a;
+      const float t2 = b * b, u2 = c * c;
+      s2 = s2 + t2;
+      s2 = s2 + u2;
+      const float sd = sqrtf(s2);
+      if (sd < fsr) {
+        st_f32_l2(&field[v], sd);
+        flag_or(qstate, v, 2u);
+        const uint32_t p = atomicAdd(&ctl.u0, 1u);
+        q.c[p] = v;  // p < nf <= cap
+      }
+    }
+    __syncthreads();
+    seeded = ctl.u0;
+  }
+  sssp<0>(ctl.g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor, seeded);
   // farthest voxel: max finite distance, ties -> smallest linear index
   unsigned long long best = 0;
   for (uint32_t i = tid; i < nf; i += 256) {
@@ -574,17 +604,31 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   const uint32_t root = task->root;
   const uint32_t* before = manual_targets + task->tgt_offset;
   const uint32_t* after = before + task->n_before;
-  const bool implicit = task->n_before == 0;            // trace.py:171-172
+  const bool soma = task->soma_mode != 0;
+  const bool implicit = task->n_before == 0 && !soma;   // trace.py:160-172
   uint32_t nb = implicit ? 1u : task->n_before;
   uint32_t na = task->n_after;
-  uint32_t valid = nf;                                  // trace.py:211
-  const uint32_t max_paths = task->max_paths ? task->max_paths : nf;  // trace.py:214-215
+  uint32_t valid = nf;
   uint32_t npaths = 0, nverts = 0;
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
   if (tid == 0) { ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g; }
   __syncthreads();
+  if (soma) {
+    // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
+    if (tid == 0) pverts[0] = root;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t c = invalidate_ball(ctl.g, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+                                         heap, &ctl.status, &ctl.u3, ctl.cyc3);
+      if (lane == 0) ctl.u1 = c;
+    }
+    __syncthreads();
+    valid -= ctl.u1;                                    // trace.py:211 counts what is left
+  }
+  const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
   if (nb + na >= max_paths) {                           // trace.py:217-218
-    if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; }
+    if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; task->status |= ctl.status; }
     return;
   }
   if (fix_branching) {
@@ -670,6 +714,45 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    if (soma) {
+      // trace.py:246-251: path = concat(path[:1], path[dist_to_soma_root > soma_radius]) -- path[0] is kept
+      // unconditionally AND again if it passes the test itself (the reference duplicates it then).  The
+      // distance is float64 like numpy's (float32 anisotropy * int64 offsets -> float64, norm in float64).
+      uint32_t* tmp = q.touched;  // free between searches; capacity >= Nf + 64 > plen + 1
+      if (wave == 0) {
+        const uint32_t sxu = (uint32_t)ctl.g.sx, sxy = (uint32_t)ctl.g.sxy;
+        const uint32_t rz = root / sxy, rr = root - rz * sxy, ry = rr / sxu, rx = rr - ry * sxu;
+        const double sr = (double)task->soma_radius;
+        uint32_t kept = 1;
+        if (lane == 0) tmp[0] = out[0];
+        for (uint32_t b0 = 0; b0 < plen; b0 += 64) {
+          const uint32_t i = b0 + lane;
+          bool keep = false;
+          uint32_t v = 0;
+          if (i < plen) {
+            v = out[i];
+            const uint32_t z = v / sxy, r = v - z * sxy, y = r / sxu, x = r - y * sxu;
+            const double ax = (double)ctl.g.wx * (double)((long long)x - (long long)rx);
+            const double ay = (double)ctl.g.wy * (double)((long long)y - (long long)ry);
+            const double az = (double)ctl.g.wz * (double)((long long)z - (long long)rz);
+            const double d = sqrt(ax * ax + ay * ay + az * az);
+            keep = d > sr;
+          }
+          const unsigned long long m = __ballot(keep);
+          if (keep) tmp[kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+          kept += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (kept > pcap - nverts) { if (lane == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW); kept = 0; }
+        for (uint32_t i = lane; i < kept; i += 64) out[i] = tmp[i];
+        if (lane == 0) ctl.u0 = kept;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      plen = ctl.u0;
+      __syncthreads();
+      if (plen == 0) break;
+    }
     // ---- invalidation, trace.py:253-259
     t_rail += clock64() - t0; t0 = clock64();
     if (valid > 0) {

@@ -90,7 +90,7 @@ class Engine:
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
                    xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,
-                   return_fields=False, timings=None):
+                   return_fields=False, timings=None, soma=None):
         """Run find_root -> DAF -> PDRF -> path loop for the connected components `segids`.
 
         segids/counts/...: host arrays indexed by position (same order).  roots: array of linear indices or
@@ -142,6 +142,9 @@ class Engine:
         tasks["path_offset"] = p_off
         tasks["path_capacity"] = pcap
         tasks["max_paths"] = 0 if max_paths is None else int(max_paths)
+        if soma is not None:  # per label (caller order): soma_mode, fsr, soma_radius, soma_scale, soma_const
+            for key in ("soma_mode", "fsr", "soma_radius", "soma_scale", "soma_const"):
+                tasks[key] = np.asarray(soma[key])[order]
         tgt = []
         tgt_off = np.zeros(nl, dtype=np.int64)
         for s, o in enumerate(order):

@@ -146,12 +146,21 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
                    fix_branching, fix_borders, before, after, black_border, timings=None,
                    rank=0, world=1, d_cc=None):
     """Everything after the connected components (intake.py:174-221 + skeletonize_subset :434-517)."""
+    import time as _time
+
+    def _mark(name):
+        if timings is not None:
+            eng.sync()
+            timings.append((name, _time.perf_counter()))
+
+    _mark("start")
     shape = cc_labels.shape
     label_bytes = 4
     if d_cc is None:
         d_cc = eng.to_device(cc_labels)
     d_dbf = eng.edt(d_cc, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
     counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, label_bytes, d_dbf, shape, nlabels)
+    _mark("edt+stats")
 
     # intake.py:198-201
     cc_segids = [sid for sid in range(1, nlabels + 1) if counts[sid] > dust_threshold]
@@ -160,19 +169,19 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
         from .border import compute_border_targets
         border_targets = compute_border_targets(cc_labels, anisotropy, eng=eng)  # intake.py:207
 
+    _mark("border_targets")
     params = dict(TRACE_DEFAULTS)
     params.update(teasar_params)
     if world > 1:
         cc_segids = cc_segids[rank::world]  # intake.py:388-389 round robin
 
     lazy_slices = {}
+    soma_jobs = []
     segids, roots, tb, ta = [], [], [], []
     for segid in cc_segids:
         # intake.py:454-456: bounding boxes of volume <= 1 are skipped (never true above dust_threshold >= 1)
         if counts[segid] <= 1 and dust_threshold < 1:
             continue
-        if dbf_max[segid] > params["soma_detection_threshold"]:
-            _soma_probe(cc_labels, segid, remapping, float(dbf_max[segid]), params, lazy_slices)
         mtb, mta, root = [], [], NONE32
         if len(border_targets[segid]) > 0:                      # intake.py:486-488
             mtb = [_loc(p, shape) for p in border_targets[segid]]
@@ -181,6 +190,10 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
             mtb.extend(_loc(p, shape) for p in before[segid])
         if segid in after and len(after[segid]) > 0:
             mta.extend(_loc(p, shape) for p in after[segid])
+        if dbf_max[segid] > params["soma_detection_threshold"] and _needs_soma_path(
+                cc_labels, segid, float(dbf_max[segid]), params, lazy_slices):
+            soma_jobs.append((segid, root, mtb, mta))  # traced one by one on their crop, below
+            continue
         segids.append(segid)
         roots.append(root)
         tb.append(mtb)
@@ -191,32 +204,61 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
                          dbf_max[sel] if len(sel) else [], first_index[sel] if len(sel) else [],
                          xmin[sel] if len(sel) else [], xmax[sel] if len(sel) else [], roots, tb, ta, params,
                          fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings)
-    return assemble(res, shape, anisotropy, remapping)
+    out = assemble(res, shape, anisotropy, remapping)
+    _mark("assemble")
+    if soma_jobs:
+        _trace_soma_labels(eng, soma_jobs, cc_labels, d_dbf, shape, anisotropy, remapping, params, fix_branching,
+                           lazy_slices, out)
+        _mark("soma_labels")
+    return out
 
 
-def _soma_probe(cc_labels, segid, remapping, dbf_max, params, cache):
-    """kimimaro/trace.py:108-119 for a label whose DBF max exceeds soma_detection_threshold.
+def _trace_soma_labels(eng, jobs, cc_labels, d_dbf, shape, anisotropy, remapping, params, fix_branching, cache, out):
+    """Labels that enter the soma branch of kimimaro/trace.py:108-134 (internal voids to fill, or DBF max above
+    soma_acceptance_threshold) leave the shared-volume batch -- filling voids changes which voxels belong to
+    the label -- and are traced one at a time on their bounding-box crop, exactly like intake.py:450-517."""
+    from .trace import trace as trace_one
+    all_dbf = d_dbf.cpu().numpy().reshape(shape, order="F")
+    sx, sy = shape[0], shape[1]
+    an = np.asarray(anisotropy, dtype=np.float32)
+    unloc = lambda l: (l % sx, (l // sx) % sy, l // (sx * sy))
+    for segid, root, mtb, mta in jobs:
+        slc = cache["slices"][segid - 1][::-1]
+        minpt = np.array([s.start for s in slc], dtype=np.int64)
+        labels = cc_labels[slc] == segid
+        dbf = np.where(labels, all_dbf[slc], 0.0).astype(np.float32)
+        tr = lambda ls: [tuple(int(v) for v in (np.array(unloc(l)) - minpt)) for l in ls]
+        kw = {k: params[k] for k in ("scale", "const", "pdrf_scale", "pdrf_exponent", "soma_detection_threshold",
+                                     "soma_acceptance_threshold", "soma_invalidation_scale", "soma_invalidation_const")}
+        skel = trace_one(labels, dbf, anisotropy=an, fix_branching=fix_branching, manual_targets_before=tr(mtb),
+                         manual_targets_after=tr(mta), root=(None if root == NONE32 else tr([root])[0]),
+                         max_paths=params.get("max_paths"), _engine=eng, **kw)
+        if skel.empty():
+            continue
+        skel.vertices += minpt.astype(skel.vertices.dtype)
+        orig = remapping[segid]
+        skel.id = orig
+        skel.vertices = np.multiply(skel.vertices, an, dtype=np.float32)
+        skel.space = "physical"
+        out[orig] = Skeleton.simple_merge([out[orig], skel]).consolidate() if orig in out else skel.consolidate()
 
-    Row f3 (next): the reference fills internal voids (fill_voids.fill) and, only if something was
-    filled, recomputes the DBF; soma mode proper starts above soma_acceptance_threshold.  Until the GPU
-    flood fill lands, the void test is a host stand-in (scipy.ndimage.binary_fill_holes on the crop,
-    6-connected background like fill_voids); a label without voids continues on the HIP path unchanged,
-    which is exactly what the reference does."""
+
+def _needs_soma_path(cc_labels, segid, dbf_max, params, cache):
+    """kimimaro/trace.py:108-119 for a label whose DBF max exceeds soma_detection_threshold: does it take the
+    soma branch?  True if the DBF max is already above soma_acceptance_threshold, or if the label has
+    internal voids (fill_voids.fill would change it and its DBF).  The void test is a host stand-in
+    (scipy.ndimage.binary_fill_holes on the crop, 6-connected background like fill_voids) until the GPU flood
+    fill lands (row f3).  A label without voids below the acceptance threshold continues unchanged in the
+    reference, so it stays in the shared-volume batch."""
     import scipy.ndimage
-    if dbf_max > params["soma_acceptance_threshold"]:
-        raise NotImplementedError(
-            "label %r: DBF max %.1f exceeds soma_acceptance_threshold %.1f -- soma mode "
-            "(kimimaro/trace.py:119-134,160-168,246-251; row f3) is not on the HIP path yet" % (
-                remapping[segid], dbf_max, params["soma_acceptance_threshold"]))
     if "slices" not in cache:
         cache["slices"] = scipy.ndimage.find_objects(cc_labels.T)
+    if dbf_max > params["soma_acceptance_threshold"]:
+        return True
     slc = cache["slices"][segid - 1][::-1]
     crop = cc_labels[slc] == segid
     filled = scipy.ndimage.binary_fill_holes(crop)
-    if np.count_nonzero(filled) != np.count_nonzero(crop):
-        raise NotImplementedError(
-            "label %r has internal voids and DBF max above soma_detection_threshold: the void fill + "
-            "crop re-EDT (kimimaro/trace.py:109-117; row f3) is not on the HIP path yet" % (remapping[segid],))
+    return bool(np.count_nonzero(filled) != np.count_nonzero(crop))
 
 
 def paths_of(res, slot, shape):

@@ -30,17 +30,42 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, 4, d_dbf, shape, 1)
     if counts[1] == 0:
         return [] if return_paths else Skeleton()
-    if dbf_max[1] > soma_detection_threshold:
-        raise NotImplementedError("soma mode (kimimaro/trace.py:108-134) is not on the HIP path yet")
     loc = lambda p: int(p[0]) + shape[0] * (int(p[1]) + shape[1] * int(p[2]))
-    tb = [[loc(p) for p in (manual_targets_before or [])]]
-    ta = [[loc(p) for p in (manual_targets_after or [])]]
-    r = [NONE32 if root is None else loc(root)]
+    mtb = [loc(p) for p in (manual_targets_before or [])]
+    mta = [loc(p) for p in (manual_targets_after or [])]
+    dmax = np.float32(dbf_max[1])
+    soma_mode = False
+    if dmax > soma_detection_threshold:  # kimimaro/trace.py:108-119
+        # fill_voids.fill stand-in (row f3: host scipy, 6-connected background) + crop re-EDT on the GPU
+        import scipy.ndimage
+        filled = scipy.ndimage.binary_fill_holes(cc != 0)
+        if int(np.count_nonzero(filled)) > int(counts[1]):
+            cc = np.asfortranarray(filled.astype(np.uint32))
+            d_cc = eng.to_device(cc)
+            d_dbf = eng.edt(d_cc, 4, shape, anisotropy, bool(np.all(cc)))
+            dbf = d_dbf.cpu().numpy().reshape(shape, order="F")
+            counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, 4, d_dbf, shape, 1)
+            dmax = np.float32(dbf_max[1])
+        soma_mode = bool(dmax > soma_acceptance_threshold)
+    r = NONE32 if root is None else loc(root)
+    soma = None
+    if soma_mode:  # trace.py:123-127,134
+        import scipy.ndimage
+        if root is not None:
+            mtb.insert(0, loc(root))
+        maxima = (dbf == dmax)  # find_soma_root, trace.py:269-289
+        com = np.asarray(scipy.ndimage.center_of_mass(maxima), dtype=np.float32)
+        coords = np.vstack(np.where(maxima)).T
+        sroot = coords[np.argmin(np.sum((coords - com) ** 2, axis=1))].astype(np.uint32)
+        r = loc(sroot)
+        soma_radius = dmax * soma_invalidation_scale + soma_invalidation_const
+        soma = {"soma_mode": [1], "fsr": [np.float32(dbf[tuple(sroot)])], "soma_radius": [np.float32(soma_radius)],
+                "soma_scale": [np.float32(soma_invalidation_scale)], "soma_const": [np.float32(soma_invalidation_const)]}
     params = dict(TRACE_DEFAULTS)
     params.update(scale=scale, const=const, pdrf_scale=pdrf_scale, pdrf_exponent=pdrf_exponent)
     res = eng.run_labels(d_cc, 4, d_dbf, shape, anisotropy, 1, [1], counts[1:2], dbf_max[1:2], first_index[1:2],
-                         xmin[1:2], xmax[1:2], r, tb, ta, params, fix_branching=fix_branching, max_paths=max_paths,
-                         return_fields=_return_raw)
+                         xmin[1:2], xmax[1:2], [r], [mtb], [mta], params, fix_branching=fix_branching, max_paths=max_paths,
+                         return_fields=_return_raw, soma=soma)
     if _return_raw:
         return res
     paths = paths_of(res, 0, shape)

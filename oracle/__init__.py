@@ -31,7 +31,7 @@ def lib():
         i64, f32, u64, vp = C.c_int64, C.c_float, C.c_uint64, C.c_void_p
         L.ko_weights26.argtypes = [f32, f32, f32, vp]
         L.ko_edt.argtypes = [vp, C.c_int, i64, i64, i64, f32, f32, f32, C.c_int, vp]
-        L.ko_edf.argtypes = [vp, i64, i64, i64, f32, f32, f32, u64, vp, vp, vp]
+        L.ko_edf.argtypes = [vp, i64, i64, i64, f32, f32, f32, u64, f32, vp, vp, vp]
         L.ko_pdrf.argtypes = [vp, vp, i64, f32, C.c_int, f32, f32, vp]
         L.ko_target_order.argtypes = [vp, vp, i64, vp]
         L.ko_target_order.restype = i64
@@ -116,7 +116,7 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False):
     return out.reshape(labels.shape, order="F") if nd < 3 else out
 
 
-def euclidean_distance_field(mask, source, anisotropy=(1, 1, 1)):
+def euclidean_distance_field(mask, source, anisotropy=(1, 1, 1), free_space_radius=0):
     """dijkstra3d.euclidean_distance_field(..., return_max_location=True) (trace.py:139-145)."""
     m = _f3(mask, np.uint8)
     out = np.empty(m.shape, dtype=np.float32, order="F")
@@ -124,7 +124,7 @@ def euclidean_distance_field(mask, source, anisotropy=(1, 1, 1)):
     mv = C.c_float(0)
     _check(lib().ko_edf(_p(m), m.shape[0], m.shape[1], m.shape[2],
                         float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]),
-                        loc_of(source, m.shape), _p(out), C.byref(ml), C.byref(mv)))
+                        loc_of(source, m.shape), np.float32(free_space_radius), _p(out), C.byref(ml), C.byref(mv)))
     return out, pt_of(ml.value, m.shape)
 
 

@@ -204,7 +204,7 @@ static ko_hn ko_hpop(ko_heap* h) {
  * canonical tie-break; the reference's is heap-order dependent).
  * free_space_radius (soma mode, trace.py:134) is not restated here (row f3).  */
 int ko_edf(const uint8_t* mask, int64_t sx, int64_t sy, int64_t sz,
-           float wx, float wy, float wz, uint64_t source,
+           float wx, float wy, float wz, uint64_t source, float free_space_radius,
            float* out, uint64_t* max_loc, float* max_val) {
   const int64_t sxy = sx * sy, n = sxy * sz;
   float w26[26];
@@ -214,6 +214,21 @@ int ko_edf(const uint8_t* mask, int64_t sx, int64_t sy, int64_t sz,
   ko_heap h = {0, 0, 0};
   out[source] = 0.0f;
   if (ko_hpush(&h, 0.0f, source)) return KO_ENOMEM;
+  /* free_space_radius (soma mode, trace.py:134,142): dijkstra3d source absent; restated from its
+   * documentation: foreground voxels closer than the radius (straight line, anisotropic) get the straight
+   * line distance and all of them seed the search.  PARITY UNPINNED. */
+  if (free_space_radius > 0.0f) {
+    const int64_t sz0 = (int64_t)(source / (uint64_t)sxy), sr = (int64_t)(source % (uint64_t)sxy), sy0 = sr / sx, sx0 = sr % sx;
+    for (int64_t z = 0; z < sz; z++) for (int64_t y = 0; y < sy; y++) for (int64_t x = 0; x < sx; x++) {
+      const int64_t q = x + sx * y + sxy * z;
+      if (!mask[q] || (uint64_t)q == source) continue;
+      float a = wx * (float)(x - sx0), b = wy * (float)(y - sy0), c = wz * (float)(z - sz0);
+      float s2 = a * a; float t2 = b * b; float u2 = c * c;
+      s2 = s2 + t2; s2 = s2 + u2;
+      const float sd = sqrtf(s2);
+      if (sd < free_space_radius) { out[q] = sd; if (ko_hpush(&h, sd, (uint64_t)q)) { free(h.a); return KO_ENOMEM; } }
+    }
+  }
   while (h.n) {
     ko_hn t = ko_hpop(&h);
     if (t.k > out[t.v]) continue; /* stale */

@@ -7,8 +7,9 @@ so that the HIP product path -- which works on whole-volume arrays and batches
 labels -- is checked against an independently structured implementation.
 
 Not restated (rows f2/f3 of SURVEY.md section 8 are handled where noted):
-soma mode needs fill_voids (scipy.ndimage.binary_fill_holes stand-in) and
-free_space_radius; voxel_graph, fill_holes, fix_avocados raise NotImplementedError.
+soma mode is restated with a fill_voids stand-in (scipy.ndimage.binary_fill_holes) and a documented
+guess of dijkstra3d's free_space_radius (source absent); voxel_graph, fill_holes, fix_avocados raise
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -61,17 +62,25 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
             labels = np.asfortranarray(filled.astype(np.uint8))
             DBF = K.edt(labels, anisotropy, black_border=bool(np.all(labels)))
         dbf_max = np.max(DBF)
-        if dbf_max > soma_acceptance_threshold:
-            raise NotImplementedError("soma mode (row f3) is not restated in the oracle yet")
+        soma_mode = bool(dbf_max > soma_acceptance_threshold)
+    else:
+        soma_mode = False
 
-    if root is None:
+    soma_radius = 0.0
+    if soma_mode:  # trace.py:123-127
+        if root is not None:
+            manual_targets_before.insert(0, tuple(int(v) for v in root))
+        root = find_soma_root(DBF, dbf_max)
+        soma_radius = dbf_max * soma_invalidation_scale + soma_invalidation_const
+    elif root is None:
         root = find_root(labels, anisotropy)
     if root is None:
         return Skeleton() if not return_paths else []
     root = tuple(int(v) for v in root)
 
+    free_space_radius = 0 if not soma_mode else DBF[root]  # trace.py:134
     DBF = K.zero2inf(DBF)  # trace.py:138
-    DAF, target = K.euclidean_distance_field(labels, root, anisotropy)  # :139-145
+    DAF, target = K.euclidean_distance_field(labels, root, anisotropy, free_space_radius)  # :139-145
     DAF = K.inf2zero(DAF)  # :146
     order = K.target_order(labels, DAF)  # CachedTargetFinder.__init__ :147
     finder = _TargetFinder(order, labels.shape)
@@ -82,12 +91,15 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     else:
         parents = PDRF
 
-    if len(manual_targets_before) == 0:  # :171-172
+    if soma_mode:  # trace.py:160-168
+        _, labels = K.roll_invalidation_ball_inside_component(
+            labels, DBF, soma_invalidation_scale, soma_invalidation_const, anisotropy, [root])
+    elif len(manual_targets_before) == 0:  # :171-172
         manual_targets_before.append(target)
 
     paths = compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
                           fix_branching, manual_targets_before, manual_targets_after,
-                          max_paths, stats)
+                          max_paths, stats, soma_mode=soma_mode, soma_radius=soma_radius)
     if return_paths:
         return paths
 
@@ -125,9 +137,19 @@ class _TargetFinder:
         return None
 
 
+def find_soma_root(DBF, dbf_max):
+    """kimimaro/trace.py:269-289."""
+    maxima = (DBF == dbf_max)
+    com = np.asarray(scipy.ndimage.center_of_mass(maxima), dtype=np.float32)
+    coords = np.vstack(np.where(maxima)).T
+    root = np.argmin(np.sum((coords - com) ** 2, axis=1))
+    return tuple(int(v) for v in coords[root].astype(np.uint32))
+
+
 def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
-                  fix_branching, manual_targets_before, manual_targets_after, max_paths, stats=None):
-    """kimimaro/trace.py:196-267 (non-soma branch)."""
+                  fix_branching, manual_targets_before, manual_targets_after, max_paths, stats=None,
+                  soma_mode=False, soma_radius=0.0):
+    """kimimaro/trace.py:196-267."""
     paths = []
     valid_labels = int(np.count_nonzero(labels))
     root = tuple(root)
@@ -149,6 +171,9 @@ def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
         else:
             path = K.path_from_parents(parents, target)
             settled = 0
+        if soma_mode:  # trace.py:246-251
+            dist_to_soma_root = np.linalg.norm(np.asarray(anisotropy, dtype=np.float32) * (np.asarray(path) - np.asarray(root)), axis=1)
+            path = np.concatenate((path[:1, :], path[dist_to_soma_root > soma_radius, :]))
         ops = 0
         if valid_labels > 0:
             invalidated, labels, ops = K.roll_invalidation_ball_inside_component(

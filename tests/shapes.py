@@ -43,3 +43,21 @@ def voronoi_labels(shape, nlabels, seed, pts_per_label=4, step=6.0, anisotropy=(
     ids = 1000 + rng.permutation(nlabels)
     lab = ids[np.asarray(owner)[idx]].astype(dtype)
     return lab.reshape(shape, order="F")
+
+
+def soma_shape(hole=False, shape=(64, 64, 64)):
+    """A ball with four dendrites (hub and spoke), optionally with an internal void."""
+    m = np.zeros(shape, np.uint8, order="F")
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), -1).astype(np.float64)
+    c = np.array([30, 32, 31.0])
+    m[((g - c) ** 2).sum(-1) <= 14 ** 2] = 1
+    for d in [np.array([1, 0.2, 0.1]), np.array([-0.3, 1, 0.2]), np.array([0.2, -0.4, 1]), np.array([-1, -0.6, -0.3])]:
+        d = d / np.linalg.norm(d)
+        for t in np.arange(10, 30, 0.5):
+            p = c + d * t
+            if (p < 1).any() or (p > np.array(shape) - 2).any():
+                break
+            m[((g - p) ** 2).sum(-1) <= 2.2 ** 2] = 1
+    if hole:
+        m[28:32, 30:34, 29:33] = 0
+    return m

@@ -127,3 +127,43 @@ def test_max_paths(eng):
     assert len(got) == len(want) == 3
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
+
+
+@pytest.mark.parametrize("hole", [False, True])
+@pytest.mark.parametrize("an", [(1, 1, 1), (2, 2, 3)])
+def test_soma_mode_matches_oracle(eng, hole, an):
+    """soma branch (trace.py:108-134,160-168,246-251): void fill + re-EDT, soma root, free-space DAF,
+    one-off invalidation, path trimming.  (dijkstra3d's free_space_radius is restated, parity unpinned.)"""
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    from shapes import soma_shape
+    m = soma_shape(hole=hole)
+    dbf = oracle.edt(m, an)
+    kw = dict(scale=1.5, const=2 * an[0], anisotropy=an, soma_detection_threshold=6 * an[0],
+              soma_acceptance_threshold=10 * an[0], pdrf_scale=100000, pdrf_exponent=4,
+              soma_invalidation_scale=1.0, soma_invalidation_const=1.0 * an[0], return_paths=True)
+    want = P.trace(m, dbf, **kw)
+    got = trace(m, dbf, _engine=eng, **kw)
+    assert len(got) == len(want) and len(got) >= 4
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
+
+
+def test_skeletonize_with_a_soma_label(eng):
+    """a soma label (with an internal void) next to ordinary labels: it leaves the batch and is traced on its crop."""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    from shapes import soma_shape
+    vol = np.zeros((96, 64, 64), np.uint32, order="F")
+    vol[:64][soma_shape(hole=True) > 0] = 5
+    vol[70:90, 10:50, 20:30] = 9
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params.update(const=2, soma_detection_threshold=6, soma_acceptance_threshold=10,
+                  soma_invalidation_scale=1.0, soma_invalidation_const=1.0)
+    got = kimimaro_amd.skeletonize(vol, params, dust_threshold=100, fix_borders=False, _engine=eng)
+    want = P.skeletonize(vol, params, dust_threshold=100, fix_borders=False)
+    assert sorted(got) == sorted(want) == [5, 9]
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)

@@ -36,8 +36,8 @@ sk = kimimaro_amd.skeletonize(lab, anisotropy=an, dust_threshold=1000, fix_borde
 eng.sync()
 t1 = time.perf_counter()
 print("skeletonize: %d skeletons in %.3f s -> %.1f labels/s" % (len(sk), t1 - t0, len(sk) / (t1 - t0)))
-prev = t0
-for name, ts in timings:
+prev = timings[0][1]
+for name, ts in timings[1:]:
     print("  %-14s %.3f s" % (name, ts - prev)); prev = ts
 print("verts", sum(s.vertices.shape[0] for s in sk.values()))
 import kimimaro_amd.engine as E
