@@ -3,12 +3,11 @@
 
   python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path over the synthetic volume with the connected-component labels
-ALREADY RESIDENT IN HBM: whole-volume EDT -> per-label statistics -> (border targets) -> find_root ->
-DAF -> PDRF -> TEASAR path loop for every component -> D2H of the paths -> Skeleton assembly ->
-(N > 1) all-gather-v of the skeletons.  Host-side work that precedes it in kimimaro.skeletonize
-(format_labels, connected components: SURVEY.md section 8 row f1, still host code) is outside the
-timed region and reported separately (`preamble_s`).
+One "step" = one pass of kimimaro.skeletonize's work over the synthetic label volume, which is ALREADY
+RESIDENT IN HBM: connected components (kh_ccl26) -> whole-volume EDT -> per-label statistics -> border
+targets -> find_root -> DAF -> PDRF -> TEASAR path loop for every component -> D2H of the paths ->
+Skeleton assembly -> (N > 1) all-gather-v of the skeletons.  Only format_labels and the H2D copy of the
+input are outside the timed region (`preamble_s`).
 
 Workload (config.workload): "c3" = 512x512x512, 2124 chains, anisotropy (16,16,40), default
 teasar_params, dust_threshold=1000, fix_borders=True, fix_branching=True  (BASELINE.json configs[2],
@@ -148,16 +147,24 @@ def main():
 
     t = time.perf_counter()
     lab = intake.format_labels(lab, in_place=True)
-    cc_labels, nlabels, remapping = intake.compute_cc_labels(lab)
+    d_lab = eng.to_device(lab)  # the input volume is resident in HBM before the timed region
+    eng.sync()
     preamble_s = time.perf_counter() - t
-    d_cc = eng.to_device(cc_labels)  # resident in HBM before the timed region
+    flat_lab = lab.reshape(-1, order="F")
     from collections import defaultdict
     empty = defaultdict(list)
 
     result = {}
 
+    def components():
+        d_cc, n, rep = eng.ccl_device(d_lab, lab.dtype.itemsize, shape)  # kimimaro/utility.py:58-83 on the GPU
+        orig = flat_lab[rep[1:].astype(np.int64)]
+        return d_cc, n, {i + 1: orig[i].item() for i in range(n)}
+
     def step():
-        local = intake.skeletonize_cc(eng, cc_labels, nlabels, remapping, params, an, dust, True, fix_borders,
+        d_cc, nlabels, remapping = components()
+        cc = intake.LazyVolume(eng, d_cc, shape)
+        local = intake.skeletonize_cc(eng, cc, nlabels, remapping, params, an, dust, True, fix_borders,
                                       empty, empty, black_border=False, rank=rank, world=world, d_cc=d_cc)
         if world > 1:
             local = gather_skeletons(local, device=eng.device)
@@ -181,6 +188,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     nskel = len(result["skels"])
+    d_cc, nlabels, remapping = components()
+    cc_labels = eng.to_host_volume(d_cc, shape)
     counts = np.bincount(cc_labels.ravel(order="K"))
     ncomp = int((counts[1:] > dust).sum())
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -196,6 +205,7 @@ def main():
     nvox = int(np.prod(shape))
     out = eng.empty(nvox, torch.float32)
     ws = eng.empty(2 * nvox, torch.float32)
+    d_cc, _, _ = components()
     ms3 = (C.c_float * 3)()
     acc = np.zeros(3)
     reps = 10
@@ -229,9 +239,13 @@ def main():
     import kimimaro_amd.engine as E
     tk = E.LAST_TASKS
     timings = []
-    intake.skeletonize_cc(eng, cc_labels, nlabels, remapping, params, an, dust, True, fix_borders, empty, empty,
-                          black_border=False, d_cc=d_cc, timings=timings)
-    phases = {}
+    t_ccl = time.perf_counter()
+    components()
+    eng.sync()
+    t_ccl = time.perf_counter() - t_ccl
+    intake.skeletonize_cc(eng, intake.LazyVolume(eng, d_cc, shape, host=cc_labels), nlabels, remapping, params, an, dust,
+                          True, fix_borders, empty, empty, black_border=False, d_cc=d_cc, timings=timings)
+    phases = {"ccl": round(t_ccl, 4)}
     prev = None
     for name, ts in timings:
         if prev is not None and name != "setup":

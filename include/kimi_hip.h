@@ -66,11 +66,11 @@ int kh_edt_timed(const void* labels, int label_bytes, int64_t sx, int64_t sy, in
  * np.max(DBF) trace.py:100, first_label skeletontricks.pyx:307-326, x extent of
  * scipy.ndimage.find_objects utility.py:85-102) ------------------------------------
  * For every label id in [0, nlabels]: voxel count, max DBF, smallest linear index,
- * min/max x.  All outputs are device arrays of nlabels+1 entries, zero/identity
- * initialised by the call.                                                            */
-int kh_label_stats(const void* labels, int label_bytes, const float* dbf, int64_t nvox, int64_t sx,
+ * min/max x, and (yz_extent, nullable, 4 entries per label) [ymin, ymax, zmin, zmax].  All outputs
+ * are device arrays of nlabels+1 entries, zero/identity initialised by the call.           */
+int kh_label_stats(const void* labels, int label_bytes, const float* dbf, int64_t nvox, int64_t sx, int64_t sy,
                    int64_t nlabels, uint32_t* counts, float* dbf_max, uint32_t* first_index,
-                   uint32_t* xmin, uint32_t* xmax, void* stream);
+                   uint32_t* xmin, uint32_t* xmax, uint32_t* yz_extent, void* stream);
 
 /* scatter the voxel indices of the selected labels into per-label lists.
  * slot_of_label: device int32[nlabels+1], -1 = label not selected, else its slot;
@@ -188,7 +188,18 @@ int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, int64_t sy, 
                        float wx, float wy, float wz, const uint64_t* path, int64_t npath,
                        float scale, float constant, int64_t* invalidated, void* stream);
 
-/* ---- preamble row f1 (host side for now): 26-connected multi-label CCL on HOST memory,
+/* ---- preamble row f1: 26-connected multi-label connected components on the DEVICE.
+ * replaces cc3d.connected_components + fastremap.renumber/refit as called at kimimaro/utility.py:58-83.
+ * labels: u8/u16/u32/u64 [sx,sy,sz]; out: u32 component ids 1..N by first appearance in the F-order raster
+ * (the numbering of kh_host_ccl26); parent: u32 scratch [nvox]; chunk_counts: u32 scratch [ceil(nvox/1024)];
+ * representative: u32 [nvox+1 worst case; N+1 used], representative[id] = smallest linear index of the
+ * component (skeletontricks.get_mapping, skeletontricks.pyx:490-525, reads the original label there);
+ * *ncomponents (device u32) = N.                                                                      */
+int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent,
+             uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents,
+             void* stream);
+
+/* ---- the same on HOST memory (used for the 2-D faces of fix_borders and as a cross-check),
  * restating cc3d.connected_components as called at kimimaro/utility.py:74-77.
  * Returns the number of components (ids 1..N by first appearance in F-order raster).   */
 int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,

@@ -49,17 +49,21 @@ def find_border_targets(dt, cc, wx, wy, nlab):
     return {int(l): (xy[2 * l], xy[2 * l + 1]) for l in order[:n]}
 
 
-def compute_border_targets(cc_labels, anisotropy, eng=None, edt2d=None):
+def compute_border_targets(cc_labels, anisotropy, eng=None, edt2d=None, faces=None, shape=None):
     """kimimaro/intake.py:544-585.  `eng`: Engine (2-D EDT on the GPU); `edt2d`: alternative callable
-    edt(labels2d, anisotropy, black_border) used by the oracle pipeline."""
-    sx, sy, sz = cc_labels.shape
+    edt(labels2d, anisotropy, black_border) used by the oracle pipeline.  `faces`: the six faces
+    [z=0, z=-1, y=0, y=-1, x=0, x=-1] when the component volume lives on the device (cc_labels None)."""
+    sx, sy, sz = cc_labels.shape if cc_labels is not None else shape
+    if faces is None:
+        faces = (cc_labels[:, :, 0], cc_labels[:, :, -1], cc_labels[:, 0, :], cc_labels[:, -1, :],
+                 cc_labels[0, :, :], cc_labels[-1, :, :])
     planes = (
-        (cc_labels[:, :, 0], (0, 1), lambda x, y: (x, y, 0)),
-        (cc_labels[:, :, -1], (0, 1), lambda x, y: (x, y, sz - 1)),
-        (cc_labels[:, 0, :], (0, 2), lambda x, z: (x, 0, z)),
-        (cc_labels[:, -1, :], (0, 2), lambda x, z: (x, sy - 1, z)),
-        (cc_labels[0, :, :], (1, 2), lambda y, z: (0, y, z)),
-        (cc_labels[-1, :, :], (1, 2), lambda y, z: (sx - 1, y, z)),
+        (faces[0], (0, 1), lambda x, y: (x, y, 0)),
+        (faces[1], (0, 1), lambda x, y: (x, y, sz - 1)),
+        (faces[2], (0, 2), lambda x, z: (x, 0, z)),
+        (faces[3], (0, 2), lambda x, z: (x, sy - 1, z)),
+        (faces[4], (1, 2), lambda y, z: (0, y, z)),
+        (faces[5], (1, 2), lambda y, z: (sx - 1, y, z)),
     )
     target_list = defaultdict(set)
     for plane, dims, rotatefn in planes:

@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkimi_hip.so")
-SOURCES = ["common.hip", "edt.hip", "prep.hip", "trace.hip"]
+SOURCES = ["common.hip", "edt.hip", "prep.hip", "trace.hip", "ccl.hip"]
 DEPS = SOURCES + ["common.h", os.path.join("..", "..", "include", "kimi_hip.h")]
 
 

@@ -1,0 +1,210 @@
+// ccl.hip -- row f1 of SURVEY.md section 8: 26-connected multi-label connected components on the GPU.
+//
+// Replaces cc3d.connected_components as called at kimimaro/utility.py:74-77 (third-party, source absent)
+// together with fastremap.renumber/refit (utility.py:71,79): two voxels are in the same component iff they
+// are joined by a 26-connected chain of voxels with the same non-zero label.  Components are numbered
+// 1..N in order of first appearance in the Fortran-order raster (= increasing minimum linear index), the
+// numbering the host helper kh_host_ccl26 produces.
+//
+// Lock-free union-find (every parent pointer points to a SMALLER index, so the root of a set is its
+// minimum element, stale reads are harmless and no cycle can form):
+//   init     parent[i] = i (foreground) / NONE (background)
+//   link     every voxel unions itself with its 13 already-rastered same-label neighbours (atomicCAS on roots)
+//   flatten  parent[i] = root(i)
+//   number   roots are counted per 1024-voxel chunk, the chunk counts are scanned, every root gets
+//            id = 1 + (number of roots before it), every voxel copies its root's id.
+// HBM-bound sweeps (lanes along x); the link pass is the only irregular one.
+#include "common.h"
+
+namespace kh {
+
+static constexpr uint32_t CCL_NONE = 0xFFFFFFFFu;
+
+template <typename LT>
+__global__ __launch_bounds__(256) void ccl_init_kernel(const LT* __restrict__ lab, uint32_t* __restrict__ parent, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    parent[i] = lab[i] != 0 ? (uint32_t)i : CCL_NONE;
+}
+
+__device__ __forceinline__ uint32_t ccl_ld(uint32_t* parent, uint32_t i) {
+  return __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ccl_find(uint32_t* parent, uint32_t i) {
+  uint32_t p = ccl_ld(parent, i);
+  while (p != i) {
+    const uint32_t gp = ccl_ld(parent, p);
+    if (gp != p) __hip_atomic_store(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+    i = p;
+    p = gp;
+  }
+  return i;
+}
+__device__ __forceinline__ void ccl_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = ccl_find(parent, a);
+    b = ccl_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const uint32_t t = a; a = b; b = t; }  // a > b: the larger root hangs under the smaller
+    const uint32_t old = atomicCAS(&parent[a], a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void ccl_link_kernel(const LT* __restrict__ lab, uint32_t* parent, int sx, int sy, int sz) {
+  const int xt = (sx + 255) >> 8;
+  const int64_t ntiles = (int64_t)xt * sy * sz;
+  const int64_t sxy = (int64_t)sx * sy;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int x = (int)(t % xt) * 256 + threadIdx.x;
+    const int64_t r = t / xt;
+    const int y = (int)(r % sy), z = (int)(r / sy);
+    if (x >= sx) continue;
+    const int64_t i = x + (int64_t)sx * y + sxy * z;
+    const LT L = lab[i];
+    if (L == 0) continue;
+    // the 13 neighbours that precede i in the raster: (-1,0,0), (*, -1, 0), (*, *, -1)
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+      const int dx = (k == 0) ? -1 : ((k - 1) % 3) - 1;
+      const int dy = (k == 0) ? 0 : (k < 4 ? -1 : ((k - 4) / 3) - 1);
+      const int dz = (k < 4) ? 0 : -1;
+      const int nx = x + dx, ny = y + dy, nz = z + dz;
+      if (nx < 0 || nx >= sx || ny < 0 || ny >= sy || nz < 0) continue;
+      const int64_t j = i + dx + (int64_t)sx * dy + sxy * dz;
+      if (lab[j] == L) ccl_union(parent, (uint32_t)i, (uint32_t)j);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ccl_flatten_count_kernel(uint32_t* parent, int64_t n, uint32_t* chunk_counts) {
+  // one chunk = 1024 voxels = 4 per thread; also counts the roots of the chunk
+  __shared__ uint32_t cnt;
+  const int64_t nchunks = (n + 1023) / 1024;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = c * 1024 + k * 256 + threadIdx.x;
+      if (i < n) {
+        const uint32_t p = parent[i];
+        if (p != CCL_NONE) {
+          const uint32_t r = ccl_find(parent, (uint32_t)i);
+          parent[i] = r;
+          mine += (r == (uint32_t)i);
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_counts[c] = cnt;
+    __syncthreads();
+  }
+}
+
+// exclusive scan of chunk_counts (in place) by ONE workgroup; total -> *total
+__global__ __launch_bounds__(1024) void ccl_scan_kernel(uint32_t* counts, int64_t nchunks, uint32_t* total) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t b = 0; b < nchunks; b += 1024) {
+    const int64_t i = b + threadIdx.x;
+    const uint32_t v = i < nchunks ? counts[i] : 0u;
+    uint32_t s = v;  // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o); if (lane >= o) s += t; }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    uint32_t base = carry;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (i < nchunks) counts[i] = base + s - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = base + s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void ccl_number_roots_kernel(const uint32_t* __restrict__ parent, int64_t n,
+                                                               const uint32_t* __restrict__ chunk_base,
+                                                               uint32_t* __restrict__ out, uint32_t* __restrict__ rep) {
+  // ids of the roots of a chunk, in index order: chunk_base + rank inside the chunk + 1
+  __shared__ uint32_t wbase[4];
+  const int64_t nchunks = (n + 1023) / 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    uint32_t running = chunk_base[c];
+    for (int k = 0; k < 4; k++) {  // index order: k-th quarter, then thread
+      const int64_t i = c * 1024 + k * 256 + threadIdx.x;
+      const bool root = i < n && parent[i] == (uint32_t)i;
+      const unsigned long long m = __ballot(root);
+      if (lane == 0) wbase[wave] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t before = running;
+      for (int w = 0; w < wave; w++) before += wbase[w];
+      const uint32_t tot = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+      if (root) {
+        const uint32_t id = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) + 1u;
+        out[i] = id;
+        rep[id] = (uint32_t)i;
+      }
+      running += tot;
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ccl_relabel_kernel(const uint32_t* __restrict__ parent, int64_t n, uint32_t* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t p = parent[i];
+    if (p == CCL_NONE) out[i] = 0;
+    else if (p != (uint32_t)i) out[i] = out[p];  // roots were written by ccl_number_roots_kernel
+  }
+}
+
+static inline unsigned ccl_grid(int64_t n, int per_block, int64_t cap = 16384) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <typename LT>
+static int ccl_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint32_t* chunk_counts, uint32_t* out,
+                    uint32_t* rep, uint32_t* total, hipStream_t st) {
+  const int64_t n = sx * sy * sz;
+  const int64_t nchunks = (n + 1023) / 1024;
+  hipLaunchKernelGGL((ccl_init_kernel<LT>), dim3(ccl_grid(n, 256)), dim3(256), 0, st, lab, parent, n);
+  const int64_t ntiles = ((sx + 255) / 256) * sy * sz;
+  hipLaunchKernelGGL((ccl_link_kernel<LT>), dim3(ccl_grid(ntiles, 1, 1 << 20)), dim3(256), 0, st, lab, parent, (int)sx, (int)sy, (int)sz);
+  hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(ccl_grid(nchunks, 1)), dim3(256), 0, st, parent, n, chunk_counts);
+  hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, nchunks, total);
+  hipLaunchKernelGGL(ccl_number_roots_kernel, dim3(ccl_grid(nchunks, 1)), dim3(256), 0, st, parent, n, chunk_counts, out, rep);
+  hipLaunchKernelGGL(ccl_relabel_kernel, dim3(ccl_grid(n, 256)), dim3(256), 0, st, parent, n, out);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+}  // namespace kh
+
+extern "C" int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent,
+                        uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents, void* stream) {
+  if (int rc = kh::require_device()) return rc;
+  if (!labels || !parent || !chunk_counts || !out || !representative || !ncomponents || sx <= 0 || sy <= 0 || sz <= 0 ||
+      sx * sy * sz >= (1ll << 32) - 1) {
+    kh::set_error("kh_ccl26: bad arguments (null pointer, empty volume or >= 2^32-1 voxels)");
+    return KH_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (label_bytes) {
+    case 1: return kh::ccl_impl((const uint8_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
+    case 2: return kh::ccl_impl((const uint16_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
+    case 4: return kh::ccl_impl((const uint32_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
+    case 8: return kh::ccl_impl((const uint64_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
+    default: kh::set_error("kh_ccl26: label_bytes must be 1, 2, 4 or 8"); return KH_EINVAL;
+  }
+}

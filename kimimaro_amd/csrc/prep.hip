@@ -41,8 +41,9 @@ __device__ __forceinline__ WaveRun wave_runs(uint32_t label, bool valid, bool ro
 
 template <typename LT>
 __global__ __launch_bounds__(256) void label_stats_kernel(const LT* __restrict__ lab, const float* __restrict__ dbf,
-                                                          int64_t nvox, int sx, uint32_t* counts, uint32_t* dbf_max_bits,
-                                                          uint32_t* first_index, uint32_t* xmin, uint32_t* xmax) {
+                                                          int64_t nvox, int sx, int sy, uint32_t* counts, uint32_t* dbf_max_bits,
+                                                          uint32_t* first_index, uint32_t* xmin, uint32_t* xmax,
+                                                          uint32_t* yzext) {
   const int lane = threadIdx.x & 63;
   const int64_t nchunks = (nvox + 255) / 256;
   for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -65,6 +66,14 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const LT* __restrict__
       atomicMin(&first_index[L], (uint32_t)(i - (len - 1)));
       atomicMin(&xmin[L], (uint32_t)(x - (len - 1)));
       atomicMax(&xmax[L], (uint32_t)x);
+      if (yzext) {  // bounding box in y and z: [ymin, ymax, zmin, zmax] per label
+        const int64_t row = i / sx;
+        const uint32_t y = (uint32_t)(row % sy), z = (uint32_t)(row / sy);
+        atomicMin(&yzext[4 * (size_t)L + 0], y);
+        atomicMax(&yzext[4 * (size_t)L + 1], y);
+        atomicMin(&yzext[4 * (size_t)L + 2], z);
+        atomicMax(&yzext[4 * (size_t)L + 3], z);
+      }
     }
   }
 }
@@ -188,9 +197,15 @@ using namespace kh;
     default: set_error("label_bytes must be 1, 2 or 4"); return KH_EINVAL; \
   }
 
-extern "C" int kh_label_stats(const void* labels, int label_bytes, const float* dbf, int64_t nvox, int64_t sx,
+__global__ void init_yzext_kernel(uint32_t* p, int64_t n1) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (int64_t)gridDim.x * blockDim.x) {
+    p[4 * i + 0] = 0xFFFFFFFFu; p[4 * i + 1] = 0u; p[4 * i + 2] = 0xFFFFFFFFu; p[4 * i + 3] = 0u;
+  }
+}
+
+extern "C" int kh_label_stats(const void* labels, int label_bytes, const float* dbf, int64_t nvox, int64_t sx, int64_t sy,
                               int64_t nlabels, uint32_t* counts, float* dbf_max, uint32_t* first_index, uint32_t* xmin,
-                              uint32_t* xmax, void* stream) {
+                              uint32_t* xmax, uint32_t* yz_extent, void* stream) {
   if (int rc = require_device()) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int64_t n1 = nlabels + 1;
@@ -199,9 +214,10 @@ extern "C" int kh_label_stats(const void* labels, int label_bytes, const float* 
   hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, first_index, n1, 0xFFFFFFFFu);
   hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, xmin, n1, 0xFFFFFFFFu);
   hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, xmax, n1, 0u);
+  if (yz_extent) hipLaunchKernelGGL(init_yzext_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, st, yz_extent, n1);
   KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((label_stats_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
-                                                 (const LT*)labels, dbf, nvox, (int)sx, counts, (uint32_t*)dbf_max,
-                                                 first_index, xmin, xmax));
+                                                 (const LT*)labels, dbf, nvox, (int)sx, (int)sy, counts, (uint32_t*)dbf_max,
+                                                 first_index, xmin, xmax, yz_extent));
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -58,6 +58,48 @@ class Engine:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
+    # -- f1: connected components on the device ---------------------------------
+    def ccl(self, labels):
+        """26-connected multi-label CCL (kimimaro/utility.py:58-83).  labels: host ndarray (F order, integer).
+        Returns (d_cc u32 device tensor, N, representative[N+1] host array of smallest linear indices)."""
+        t = self.torch
+        lab = labels
+        if lab.dtype == bool:
+            lab = lab.view(np.uint8)
+        if lab.dtype.kind not in "ui":
+            lab = lab.astype(np.uint64)
+        lab = np.asfortranarray(lab)
+        return self.ccl_device(self.to_device(lab), lab.dtype.itemsize, lab.shape)
+
+    def ccl_device(self, d_lab, itemsize, shape):
+        """kh_ccl26 on a label volume that is already resident in HBM."""
+        t = self.torch
+        n = int(shape[0]) * int(shape[1]) * int(shape[2])
+        d_parent = self.empty(n, t.int32)
+        d_counts = self.empty((n + 1023) // 1024, t.int32)
+        d_cc = self.empty(n, t.int32)
+        d_rep = self.empty(n + 1, t.int32)
+        d_total = self.empty(1, t.int32)
+        _abi.check(self.lib.kh_ccl26(self.ptr(d_lab), itemsize, shape[0], shape[1], shape[2], self.ptr(d_parent),
+                                     self.ptr(d_counts), self.ptr(d_cc), self.ptr(d_rep), self.ptr(d_total), self.stream()))
+        ncomp = int(d_total.cpu().numpy().view(np.uint32)[0])
+        rep = d_rep[: ncomp + 1].cpu().numpy().view(np.uint32)
+        return d_cc, ncomp, rep
+
+    def to_host_volume(self, d, shape, dtype=np.uint32):
+        return d.cpu().numpy().view(dtype).reshape(shape, order="F")
+
+    def face(self, d, shape, axis, index):
+        """one face of a device volume as a host array (Fortran order semantics: d is [sx, sy, sz], x fastest)."""
+        v = d.view(shape[2], shape[1], shape[0])  # torch C order (z, y, x) == F order (x, y, z)
+        if axis == 2:
+            f = v[index, :, :]      # (y, x)
+        elif axis == 1:
+            f = v[:, index, :]      # (z, x)
+        else:
+            f = v[:, :, index]      # (z, y)
+        return np.asfortranarray(f.contiguous().cpu().numpy().view(np.uint32).T)  # -> (x,y) / (x,z) / (y,z)
+
     # -- a1 -------------------------------------------------------------------
     def edt(self, d_labels, label_bytes, shape, anisotropy, black_border, out=None, workspace=None):
         sx, sy, sz = shape
@@ -80,12 +122,19 @@ class Engine:
         first = self.empty(n1, t.int32)
         xmin = self.empty(n1, t.int32)
         xmax = self.empty(n1, t.int32)
+        yz = self.empty(4 * n1, t.int32)
         nvox = shape[0] * shape[1] * shape[2]
-        _abi.check(self.lib.kh_label_stats(self.ptr(d_labels), label_bytes, self.ptr(d_dbf), nvox, shape[0], nlabels,
-                                           self.ptr(counts), self.ptr(dmax), self.ptr(first), self.ptr(xmin),
-                                           self.ptr(xmax), self.stream()))
+        _abi.check(self.lib.kh_label_stats(self.ptr(d_labels), label_bytes, self.ptr(d_dbf), nvox, shape[0], shape[1],
+                                           nlabels, self.ptr(counts), self.ptr(dmax), self.ptr(first), self.ptr(xmin),
+                                           self.ptr(xmax), self.ptr(yz), self.stream()))
         u32 = lambda x: x.cpu().numpy().view(np.uint32)
+        self.last_yz_extent = u32(yz).reshape(n1, 4)  # [ymin, ymax, zmin, zmax] per label (bounding boxes)
         return u32(counts), dmax.cpu().numpy(), u32(first), u32(xmin), u32(xmax)
+
+    def crop(self, d, shape, lo, hi, dtype=np.uint32):
+        """host copy of the box [lo, hi) of a device volume, as an (x, y, z) Fortran-ordered array."""
+        v = d.view(shape[2], shape[1], shape[0])[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+        return np.asfortranarray(v.contiguous().cpu().numpy().view(dtype).transpose(2, 1, 0))
 
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,

@@ -94,6 +94,41 @@ def compute_cc_labels(all_labels):
     return cc, int(n), remap
 
 
+def compute_cc_labels_device(eng, all_labels):
+    """kimimaro/utility.py:58-83 on the MI355X (kh_ccl26): (device cc volume, N, {cc id: original id})."""
+    d_cc, n, rep = eng.ccl(all_labels)
+    orig = all_labels.reshape(-1, order="F")[rep[1:].astype(np.int64)] if n else []
+    remap = {i + 1: orig[i].item() for i in range(n)}  # skeletontricks.get_mapping :490-525
+    return d_cc, n, remap
+
+
+class LazyVolume:
+    """The component volume lives in HBM; the few host-side consumers (border faces, extra-target lookups,
+    soma crops) pull what they need, the whole array only if a soma label asks for its crop."""
+
+    def __init__(self, eng, d_cc, shape, host=None):
+        self.eng, self.d, self.shape, self._host = eng, d_cc, tuple(shape), host
+
+    def host(self):
+        if self._host is None:
+            self._host = self.eng.to_host_volume(self.d, self.shape)
+        return self._host
+
+    def faces(self):
+        if self._host is not None:
+            c = self._host
+            return (c[:, :, 0], c[:, :, -1], c[:, 0, :], c[:, -1, :], c[0, :, :], c[-1, :, :])
+        e, d, s = self.eng, self.d, self.shape
+        return (e.face(d, s, 2, 0), e.face(d, s, 2, s[2] - 1), e.face(d, s, 1, 0), e.face(d, s, 1, s[1] - 1),
+                e.face(d, s, 0, 0), e.face(d, s, 0, s[0] - 1))
+
+    def __getitem__(self, pt):
+        if self._host is not None:
+            return self._host[pt]
+        x, y, z = (int(v) for v in pt)
+        return int(self.d[x + self.shape[0] * (y + self.shape[1] * z)].item()) & 0xFFFFFFFF
+
+
 def _points_to_labels(pts, cc_labels):
     mapping = defaultdict(list)
     for pt in pts:
@@ -132,14 +167,14 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     if minlabel == 0 and maxlabel == 0:
         return {}
 
-    cc_labels, nlabels, remapping = compute_cc_labels(all_labels)
-    shape = cc_labels.shape
-    before = _points_to_labels(extra_targets_before, cc_labels)
-    after = _points_to_labels(extra_targets_after, cc_labels)
+    d_cc, nlabels, remapping = compute_cc_labels_device(eng, all_labels)  # row f1 on the GPU
+    cc = LazyVolume(eng, d_cc, all_labels.shape)
+    before = _points_to_labels(extra_targets_before, cc)
+    after = _points_to_labels(extra_targets_after, cc)
 
-    return skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
+    return skeletonize_cc(eng, cc, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                           fix_branching, fix_borders, before, after, black_border=(minlabel == maxlabel),
-                          timings=_timings)
+                          timings=_timings, d_cc=d_cc)
 
 
 def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
@@ -154,12 +189,18 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
             timings.append((name, _time.perf_counter()))
 
     _mark("start")
+    if not isinstance(cc_labels, LazyVolume):
+        cc_labels = LazyVolume(eng, d_cc, cc_labels.shape, host=cc_labels)
     shape = cc_labels.shape
     label_bytes = 4
     if d_cc is None:
-        d_cc = eng.to_device(cc_labels)
+        d_cc = eng.to_device(cc_labels.host())
+        cc_labels.d = d_cc
     d_dbf = eng.edt(d_cc, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
     counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, label_bytes, d_dbf, shape, nlabels)
+    yz = eng.last_yz_extent
+    bbox = lambda sid: ((int(xmin[sid]), int(yz[sid, 0]), int(yz[sid, 2])),
+                        (int(xmax[sid]) + 1, int(yz[sid, 1]) + 1, int(yz[sid, 3]) + 1))  # find_objects, utility.py:85-102
     _mark("edt+stats")
 
     # intake.py:198-201
@@ -167,7 +208,7 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     border_targets = defaultdict(list)
     if fix_borders:
         from .border import compute_border_targets
-        border_targets = compute_border_targets(cc_labels, anisotropy, eng=eng)  # intake.py:207
+        border_targets = compute_border_targets(None, anisotropy, eng=eng, faces=cc_labels.faces(), shape=shape)  # intake.py:207
 
     _mark("border_targets")
     params = dict(TRACE_DEFAULTS)
@@ -175,7 +216,6 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     if world > 1:
         cc_segids = cc_segids[rank::world]  # intake.py:388-389 round robin
 
-    lazy_slices = {}
     soma_jobs = []
     segids, roots, tb, ta = [], [], [], []
     for segid in cc_segids:
@@ -191,7 +231,7 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
         if segid in after and len(after[segid]) > 0:
             mta.extend(_loc(p, shape) for p in after[segid])
         if dbf_max[segid] > params["soma_detection_threshold"] and _needs_soma_path(
-                cc_labels, segid, float(dbf_max[segid]), params, lazy_slices):
+                eng, d_cc, shape, bbox(segid), segid, float(dbf_max[segid]), params):
             soma_jobs.append((segid, root, mtb, mta))  # traced one by one on their crop, below
             continue
         segids.append(segid)
@@ -207,26 +247,24 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     out = assemble(res, shape, anisotropy, remapping)
     _mark("assemble")
     if soma_jobs:
-        _trace_soma_labels(eng, soma_jobs, cc_labels, d_dbf, shape, anisotropy, remapping, params, fix_branching,
-                           lazy_slices, out)
+        _trace_soma_labels(eng, soma_jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out)
         _mark("soma_labels")
     return out
 
 
-def _trace_soma_labels(eng, jobs, cc_labels, d_dbf, shape, anisotropy, remapping, params, fix_branching, cache, out):
+def _trace_soma_labels(eng, jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out):
     """Labels that enter the soma branch of kimimaro/trace.py:108-134 (internal voids to fill, or DBF max above
     soma_acceptance_threshold) leave the shared-volume batch -- filling voids changes which voxels belong to
     the label -- and are traced one at a time on their bounding-box crop, exactly like intake.py:450-517."""
     from .trace import trace as trace_one
-    all_dbf = d_dbf.cpu().numpy().reshape(shape, order="F")
     sx, sy = shape[0], shape[1]
     an = np.asarray(anisotropy, dtype=np.float32)
     unloc = lambda l: (l % sx, (l // sx) % sy, l // (sx * sy))
     for segid, root, mtb, mta in jobs:
-        slc = cache["slices"][segid - 1][::-1]
-        minpt = np.array([s.start for s in slc], dtype=np.int64)
-        labels = cc_labels[slc] == segid
-        dbf = np.where(labels, all_dbf[slc], 0.0).astype(np.float32)
+        lo, hi = bbox(segid)
+        minpt = np.array(lo, dtype=np.int64)
+        labels = eng.crop(d_cc, shape, lo, hi) == segid
+        dbf = np.where(labels, eng.crop(d_dbf, shape, lo, hi, np.float32), 0.0).astype(np.float32)
         tr = lambda ls: [tuple(int(v) for v in (np.array(unloc(l)) - minpt)) for l in ls]
         kw = {k: params[k] for k in ("scale", "const", "pdrf_scale", "pdrf_exponent", "soma_detection_threshold",
                                      "soma_acceptance_threshold", "soma_invalidation_scale", "soma_invalidation_const")}
@@ -243,20 +281,17 @@ def _trace_soma_labels(eng, jobs, cc_labels, d_dbf, shape, anisotropy, remapping
         out[orig] = Skeleton.simple_merge([out[orig], skel]).consolidate() if orig in out else skel.consolidate()
 
 
-def _needs_soma_path(cc_labels, segid, dbf_max, params, cache):
+def _needs_soma_path(eng, d_cc, shape, box, segid, dbf_max, params):
     """kimimaro/trace.py:108-119 for a label whose DBF max exceeds soma_detection_threshold: does it take the
     soma branch?  True if the DBF max is already above soma_acceptance_threshold, or if the label has
     internal voids (fill_voids.fill would change it and its DBF).  The void test is a host stand-in
-    (scipy.ndimage.binary_fill_holes on the crop, 6-connected background like fill_voids) until the GPU flood
-    fill lands (row f3).  A label without voids below the acceptance threshold continues unchanged in the
-    reference, so it stays in the shared-volume batch."""
+    (scipy.ndimage.binary_fill_holes on the label's crop, 6-connected background like fill_voids) until the GPU
+    flood fill lands (row f3).  A label without voids below the acceptance threshold continues unchanged in
+    the reference, so it stays in the shared-volume batch."""
     import scipy.ndimage
-    if "slices" not in cache:
-        cache["slices"] = scipy.ndimage.find_objects(cc_labels.T)
     if dbf_max > params["soma_acceptance_threshold"]:
         return True
-    slc = cache["slices"][segid - 1][::-1]
-    crop = cc_labels[slc] == segid
+    crop = eng.crop(d_cc, shape, box[0], box[1]) == segid
     filled = scipy.ndimage.binary_fill_holes(crop)
     return bool(np.count_nonzero(filled) != np.count_nonzero(crop))
 
@@ -274,9 +309,33 @@ def paths_of(res, slot, shape):
     return out
 
 
+def consolidate_paths(locs, lens, radii, shape):
+    """Skeleton.from_path per path + simple_merge + consolidate (kimimaro/trace.py:182-184) for one label, on
+    linear voxel indices: returns (vertices (n,3) f32 sorted lexicographically by (x,y,z) like
+    np.unique(axis=0), edges (m,2) u32 sorted/unique without self loops, radii of the first occurrences).
+    Same result as kimimaro_amd.skeleton.Skeleton.consolidate, ~10x cheaper (1-D unique on a key)."""
+    sx, sy, sz = shape
+    x, y, z = locs % sx, (locs // sx) % sy, locs // (sx * sy)
+    key = (x * sy + y) * sz + z                      # row-lexicographic order of (x, y, z)
+    ukey, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    n = locs.size
+    starts = np.cumsum(lens)[:-1]
+    eidx = np.arange(n - 1)
+    if starts.size:
+        keep = np.ones(n - 1, dtype=bool)
+        keep[starts - 1] = False                     # no edge across two paths
+        eidx = eidx[keep]
+    a, b = inv[eidx], inv[eidx + 1]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    ok = lo != hi
+    ekey = np.unique(lo[ok] * np.int64(ukey.size) + hi[ok])
+    edges = np.stack([ekey // ukey.size, ekey % ukey.size], axis=1).astype(np.uint32)
+    verts = np.stack([x[first], y[first], z[first]], axis=1).astype(np.float32)
+    return verts, edges, radii[first]
+
+
 def assemble(res, shape, anisotropy, remapping):
     """Skeleton assembly: kimimaro/trace.py:182-192 + intake.py:506-517, 587-593."""
-    sx, sy = shape[0], shape[1]
     tasks = res["tasks"]
     skeletons = defaultdict(list)
     an = np.asarray(anisotropy, dtype=np.float32)
@@ -287,24 +346,14 @@ def assemble(res, shape, anisotropy, remapping):
             continue
         locs = res["verts"][v0:v1].astype(np.int64)
         lens = res["lens"][res["loff"][slot]:res["loff"][slot + 1]].astype(np.int64)
-        verts = np.stack([locs % sx, (locs // sx) % sy, locs // (sx * sy)], axis=1).astype(np.float32)
-        # Skeleton.from_path per path + simple_merge: consecutive edges inside each path
-        starts = np.concatenate([[0], np.cumsum(lens)])
-        eidx = np.arange(verts.shape[0] - 1)
-        is_break = np.zeros(verts.shape[0] - 1, dtype=bool)
-        is_break[starts[1:-1] - 1] = True
-        eidx = eidx[~is_break]
-        edges = np.stack([eidx, eidx + 1], axis=1).astype(np.uint32)
-        skel = Skeleton(verts, edges, radii=res["radii"][v0:v1]).consolidate()
-        if skel.empty():
+        verts, edges, radii = consolidate_paths(locs, lens, res["radii"][v0:v1], shape)
+        if edges.shape[0] == 0:                      # Skeleton.empty(), intake.py:506
             continue
-        skel.transform = transform
         orig = remapping[int(tasks["segid"][slot])]
-        skel.id = orig
-        skel.vertices = np.multiply(skel.vertices, an, dtype=np.float32)  # intake.py:513
-        skel.space = "physical"
+        skel = Skeleton(np.multiply(verts, an, dtype=np.float32), edges, radii=radii, segid=orig,  # intake.py:513
+                        transform=transform, space="physical")
         skeletons[orig].append(skel)
     merged = {}
     for segid, skels in skeletons.items():
-        merged[segid] = Skeleton.simple_merge(skels).consolidate()
+        merged[segid] = skels[0] if len(skels) == 1 else Skeleton.simple_merge(skels).consolidate()
     return merged

@@ -1,0 +1,72 @@
+"""Host-side logic of the product (no GPU): Skeleton semantics, fast consolidation, format_labels."""
+import numpy as np
+import pytest
+
+
+def test_consolidate_paths_equals_generic_consolidate():
+    from kimimaro_amd.intake import consolidate_paths
+    from kimimaro_amd.skeleton import Skeleton
+    rng = np.random.default_rng(0)
+    shape = (23, 17, 11)
+    for trial in range(30):
+        npaths = int(rng.integers(1, 6))
+        lens = rng.integers(1, 12, npaths)
+        locs = rng.integers(0, np.prod(shape), int(lens.sum())).astype(np.int64)
+        if trial % 3 == 0 and locs.size > 3:
+            locs[2] = locs[0]          # repeated vertices, self loops
+            locs[1] = locs[0]
+        radii = rng.random(locs.size).astype(np.float32)
+        radii = radii[np.unique(locs, return_inverse=True)[1]]  # a vertex always has the same radius
+        sx, sy = shape[0], shape[1]
+        pts = np.stack([locs % sx, (locs // sx) % sy, locs // (sx * sy)], axis=1)
+        parts, pos = [], 0
+        for n in lens:
+            sk = Skeleton.from_path(pts[pos:pos + n])
+            sk.radii = radii[pos:pos + n]
+            parts.append(sk)
+            pos += n
+        want = Skeleton.simple_merge(parts).consolidate()
+        v, e, r = consolidate_paths(locs, lens.astype(np.int64), radii, shape)
+        if want.empty():
+            assert e.shape[0] == 0
+            continue
+        np.testing.assert_array_equal(v, want.vertices)
+        np.testing.assert_array_equal(e, want.edges)
+        np.testing.assert_array_equal(r, want.radii)
+
+
+def test_skeleton_semantics():
+    from kimimaro_amd.skeleton import Skeleton
+    s = Skeleton.from_path([[0, 0, 0], [1, 1, 1], [2, 2, 2]])
+    assert s.edges.tolist() == [[0, 1], [1, 2]] and not s.empty()
+    assert Skeleton.from_path(np.zeros((0, 3))).empty()
+    assert Skeleton.from_path([[3, 3, 3]]).empty()          # one vertex, no edge
+    m = Skeleton.simple_merge([s, Skeleton.from_path([[2, 2, 2], [3, 2, 2]])]).consolidate()
+    assert m.vertices.shape[0] == 4 and m.edges.shape[0] == 3
+    assert abs(m.cable_length() - (2 * np.sqrt(3) + 1)) < 1e-5
+    p = Skeleton(m.vertices * np.float32(2), m.edges, transform=[[2, 0, 0, 0], [0, 2, 0, 0], [0, 0, 2, 0]], space="physical")
+    np.testing.assert_array_equal(p.voxel_space().vertices, m.vertices)
+    assert "1 0" in m.to_swc().splitlines()[2]
+    assert len(m.components()) == 1
+
+
+def test_format_labels_and_dimension_error():
+    from kimimaro_amd import intake
+    assert intake.format_labels(np.zeros((5,), bool)).shape == (5, 1, 1)
+    assert intake.format_labels(np.zeros((5, 4), np.uint8)).flags.f_contiguous
+    assert intake.format_labels(np.zeros((5, 4, 3, 1), np.uint8)).shape == (5, 4, 3)
+    with pytest.raises(intake.DimensionError):
+        intake.format_labels(np.zeros((5, 4, 3, 2), np.uint8))
+    lab = np.arange(24, dtype=np.uint32).reshape(2, 3, 4)
+    out = intake.apply_object_mask(lab.copy(), [3, 5])
+    assert sorted(np.unique(out).tolist()) == [0, 3, 5]
+
+
+def test_defaults_match_reference():
+    """kimimaro/intake.py:47-56 and kimimaro/trace.py:38-43."""
+    import kimimaro_amd
+    from kimimaro_amd.intake import TRACE_DEFAULTS
+    assert kimimaro_amd.DEFAULT_TEASAR_PARAMS == {
+        "scale": 1.5, "const": 300, "pdrf_scale": 100000, "pdrf_exponent": 4, "soma_acceptance_threshold": 3500,
+        "soma_detection_threshold": 750, "soma_invalidation_const": 300, "soma_invalidation_scale": 2}
+    assert TRACE_DEFAULTS["scale"] == 10 and TRACE_DEFAULTS["pdrf_exponent"] == 16 and TRACE_DEFAULTS["max_paths"] is None
