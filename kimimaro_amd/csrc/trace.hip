@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t rdlane_u32(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l));
 }
 __device__ __forceinline__ float rdlane_f32(float v, int l) { return __uint_as_float(rdlane_u32(__float_as_uint(v), l)); }
+// value of lane l^1 (the sibling node): DPP quad_perm [1,0,3,2], no LDS crossbar round trip
+__device__ __forceinline__ float sibling_f32(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+}
 
 struct Ctl {
   unsigned long long best_rail;
@@ -88,7 +92,7 @@ __device__ __forceinline__ void flag_clear(uint8_t* base, uint32_t v, uint32_t b
 // (trace.py:155, fix_branching=False): field costs, no rails, runs to completion.
 // On return distances below the final threshold are exact (ctl->best_rail set for MODE 1).
 template <int MODE>
-__device__ void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ wfield,
+__device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ wfield,
                      float* dist, uint8_t* qstate, uint32_t source, Queues q, Ctl* ctl, float delta_floor,
                      uint32_t preseeded_far = 0) {
   constexpr bool RAIL = MODE == 1;
@@ -403,9 +407,9 @@ __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
       n1.k = e1 ? n1.k : KH_INF;
       // a node beats its sibling if it is the left one and right.key >= left.key, or the right one and
       // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
-      const float s0 = __shfl_xor(n0.k, 1), s1 = __shfl_xor(n1.k, 1);
-      const bool w0 = e0 && (left ? (s0 >= n0.k) : (n0.k < s0));
-      const bool w1 = e1 && (left ? (s1 >= n1.k) : (n1.k < s1));
+      const float s0 = sibling_f32(n0.k), s1 = sibling_f32(n1.k);
+      const bool w0 = e0 & ((left & (s0 >= n0.k)) | (!left & (n0.k < s0)));
+      const bool w1 = e1 & ((left & (s1 >= n1.k)) | (!left & (n1.k < s1)));
       const unsigned long long W0 = __ballot(w0);
       const bool on0 = (W0 & h.am0) == h.am0;
       const bool on1 = w1 && ((W0 & h.am1) == h.am1);
@@ -530,7 +534,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
 // wave 0 only: canonical predecessor walk (oracle ko_pred / ko_railroad).  Writes the path (rail end
 // first) to out[0..]; returns its length (0 on failure).
 template <bool RAILS>
-__device__ uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ pdrf,
+__device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ pdrf,
                               const float* dist, uint32_t rail_end, uint32_t target, uint32_t* out, uint32_t cap,
                               uint32_t* status) {
   const int lane = threadIdx.x & 63;
