@@ -1,14 +1,14 @@
 """Developer experiment: does the tie order of the invalidation heap matter?
 Replays every roll_invalidation_ball_inside_component call of the oracle pipeline with three canonical total
-orders (tools/canon_heap.c) and counts the calls whose final mask differs from the libstdc++ order.
-Build first: gcc -O2 -ffp-contract=off -shared -fPIC tools/canon_heap.c -o tools/canon_heap.so -lm"""
+orders (tests/experiments/canon_heap.c) and counts the calls whose final mask differs from the libstdc++ order.
+Build first: gcc -O2 -ffp-contract=off -shared -fPIC tests/experiments/canon_heap.c -o tests/experiments/canon_heap.so -lm"""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, oracle as K
 from oracle import pipeline as P
 from shapes import random_walk_tube, voronoi_labels
-canon = C.CDLL(os.path.join(ROOT, 'tools', 'canon_heap.so'))
+canon = C.CDLL(os.path.join(ROOT, "tests", "experiments", "canon_heap.so"))
 canon.canon_ball.restype = C.c_int64
 canon.canon_ball.argtypes=[C.c_void_p]+[C.c_int64]*3+[C.c_float]*3+[C.c_void_p,C.c_void_p,C.c_int64,C.c_int]
 orig = K.roll_invalidation_ball_inside_component
