@@ -39,7 +39,7 @@ extern "C" {
 #define KH_ST_HEAP_OVERFLOW 2u    /* invalidation heap overflow */
 #define KH_ST_PATH_OVERFLOW 4u    /* path output buffer overflow */
 #define KH_ST_NO_RAIL 8u          /* railroad: no rail reachable from a target */
-#define KH_ST_PLATEAU 16u         /* float-absorption plateau met while back-tracking */
+#define KH_ST_PLATEAU 16u         /* a float-absorption plateau search found no exit (scratch exhausted) */
 #define KH_ST_BAD_TARGET 32u      /* a target / root outside the label */
 
 int kh_version(void);

@@ -531,29 +531,36 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   return count;
 }
 
-// wave 0 only: canonical predecessor walk (oracle ko_pred / ko_railroad).  Writes the path (rail end
-// first) to out[0..]; returns its length (0 on failure).
+// wave 0 only: canonical predecessor walk (oracle ko_walk).  Writes the path (start first) to out[0..];
+// returns its length (0 on failure).
+//   - normally pred(v) = the achieving neighbour (fl(d[u] + f[v]) == d[v]) with d[u] < d[v] minimising (d[u], index);
+//   - at the rail end of a railroad (f == 0) every achieving neighbour has d[u] == d[v]: smallest index;
+//   - float-absorption plateau (all achieving neighbours have d[u] == d[v]): breadth-first search over the
+//     equal-distance achieving neighbours (FIFO, neighbours in direction order) to the first voxel with a
+//     strictly smaller achieving predecessor; the BFS route is followed.  bq / bpar: scratch lists (>= Nf
+//     entries), visited marks live in bit 4 of the label's own qstate bytes.
 template <bool RAILS>
-__device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ pdrf,
-                              const float* dist, uint32_t rail_end, uint32_t target, uint32_t* out, uint32_t cap,
-                              uint32_t* status) {
+__device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nbrmask,
+                                                        const float* __restrict__ pdrf, const float* dist,
+                                                        uint32_t rail_end, uint32_t target, uint32_t* out, uint32_t cap,
+                                                        uint32_t* bq, uint32_t* bpar, uint32_t bcap, uint8_t* qstate,
+                                                        uint32_t* status) {
   const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t v = rail_end, n = 0;
   if (lane == 0) out[0] = v;
   n = 1;
   while (v != target) {
     const float dv = ld_f32_l2(&dist[v]);
     const float fv = pdrf[v];
+    const bool at_rail_end = RAILS && v == rail_end;
     unsigned long long key = NONE64;
     if (lane < 26 && ((nbrmask[v] >> lane) & 1u)) {
       const uint32_t u = v + (uint32_t)g.off[lane];
       const float fu = pdrf[u];
       if (!RAILS || fu != 0.0f) {
         const float du = ld_f32_l2(&dist[u]);
-        if (du != KH_INF) {
-          const float c = du + fv;
-          if (c == dv) key = pack(du, u);
-        }
+        if (du != KH_INF && du + fv == dv && (at_rail_end || du < dv)) key = pack(du, u);
       }
     }
 #pragma unroll
@@ -561,14 +568,63 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
       const unsigned long long ok = __shfl_xor(key, o);
       if (ok < key) key = ok;
     }
-    if (key == NONE64) { if (lane == 0) atomicOr(status, KH_ST_NO_RAIL); return 0; }
-    const uint32_t u = (uint32_t)key;
-    const float du = __uint_as_float((uint32_t)(key >> 32));
-    if (du >= dv && (!RAILS || v != rail_end)) { if (lane == 0) atomicOr(status, KH_ST_PLATEAU); return 0; }
-    if (n >= cap) { if (lane == 0) atomicOr(status, KH_ST_PATH_OVERFLOW); return 0; }
-    if (lane == 0) out[n] = u;
-    n++;
-    v = u;
+    if (key != NONE64) {
+      if (n >= cap) { if (lane == 0) atomicOr(status, KH_ST_PATH_OVERFLOW); return 0; }
+      v = (uint32_t)key;
+      if (lane == 0) out[n] = v;
+      n++;
+      continue;
+    }
+    if (at_rail_end) { if (lane == 0) atomicOr(status, KH_ST_NO_RAIL); return 0; }
+    // ---- plateau search
+    uint32_t head = 0, tail = 1, found = 0xFFFFFFFFu;
+    if (lane == 0) { bq[0] = v; bpar[0] = 0xFFFFFFFFu; qstate[v] |= 0x10; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    while (head < tail) {
+      const uint32_t x = bq[head];
+      const float dx = ld_f32_l2(&dist[x]);
+      const float fx = pdrf[x];
+      bool strict = false, equal = false;
+      uint32_t u = 0;
+      if (lane < 26 && ((nbrmask[x] >> lane) & 1u)) {
+        u = x + (uint32_t)g.off[lane];
+        const float fu = pdrf[u];
+        if (!RAILS || fu != 0.0f) {
+          const float du = ld_f32_l2(&dist[u]);
+          if (du != KH_INF && du + fx == dx) {
+            strict = du < dx;
+            equal = (du == dx) && !(qstate[u] & 0x10);
+          }
+        }
+      }
+      if (head > 0 && __ballot(strict)) { found = head; break; }
+      const unsigned long long em = __ballot(equal);
+      const uint32_t cnt = (uint32_t)__popcll(em);
+      if (tail + cnt > bcap) { found = 0xFFFFFFFFu; head = tail; break; }
+      if (equal) {
+        const uint32_t p = tail + (uint32_t)__popcll(em & below);
+        bq[p] = u;
+        bpar[p] = head;
+        qstate[u] |= 0x10;
+      }
+      tail += cnt;
+      head++;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    for (uint32_t i = lane; i < tail; i += 64) qstate[bq[i]] &= (uint8_t)~0x10;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (found == 0xFFFFFFFFu) { if (lane == 0) atomicOr(status, KH_ST_PLATEAU); return 0; }
+    // route v -> ... -> bq[found] (the BFS tree, backwards), appended forwards
+    uint32_t len = 0;
+    for (uint32_t i = found; i != 0; i = bpar[i]) len++;
+    if (n + len > cap) { if (lane == 0) atomicOr(status, KH_ST_PATH_OVERFLOW); return 0; }
+    if (lane == 0) {
+      uint32_t pos = n + len - 1;
+      for (uint32_t i = found; i != 0; i = bpar[i]) out[pos--] = bq[i];
+    }
+    n += len;
+    v = bq[found];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   }
   return n;
 }
@@ -683,7 +739,8 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
       if (tid == 0) ctl.u0 = 0;
       __syncthreads();
       if (wave == 0) {
-        const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, &ctl.status);
+        const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, q.a, q.b, q.cap,
+                                            qstate, &ctl.status);
         for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
         if (lane == 0) ctl.u0 = n;
       }
@@ -701,7 +758,8 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
       if (br == NONE64) {
         if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
       } else if (wave == 0) {
-        const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, &ctl.status);
+        const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, q.a, q.b,
+                                           q.cap, qstate, &ctl.status);
         if (lane == 0) ctl.u0 = n;
       }
       __syncthreads();

@@ -38,6 +38,8 @@ def lib():
         L.ko_railroad.argtypes = [vp, i64, i64, i64, u64, vp, vp, vp, vp]
         L.ko_parental_field.argtypes = [vp, i64, i64, i64, u64, vp, vp]
         L.ko_path_from_parents.argtypes = [vp, i64, u64, vp, vp]
+        L.ko_field_distances.argtypes = [vp, i64, i64, i64, u64, vp]
+        L.ko_path_to_source.argtypes = [vp, vp, i64, i64, i64, u64, u64, vp, vp]
         L.ko_invalidate_ball.argtypes = [vp, i64, i64, i64, f32, f32, f32, vp, vp, i64, vp, vp]
         L.ko_ball_radii.argtypes = [vp, vp, i64, f32, f32, vp]
         L.ko_invalidate_cube.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, vp, i64, f32, f32, vp]
@@ -170,6 +172,25 @@ def parental_field(field, source):
     _check(lib().ko_parental_field(_p(f), f.shape[0], f.shape[1], f.shape[2],
                                    loc_of(source, f.shape), _p(d), _p(parents)))
     return parents
+
+
+def field_distances(field, source):
+    """distances of dijkstra3d.parental_field's search (trace.py:155)."""
+    f = _f3(field, np.float32)
+    d = np.empty(f.shape, dtype=np.float32, order="F")
+    _check(lib().ko_field_distances(_p(f), f.shape[0], f.shape[1], f.shape[2], loc_of(source, f.shape), _p(d)))
+    return d
+
+
+def path_to_source(field, dist, source, target):
+    """dijkstra3d.path_from_parents (trace.py:244) as a predecessor walk on `dist`: source -> ... -> target."""
+    f = _f3(field, np.float32)
+    d = _f3(dist, np.float32)
+    path = np.empty(f.size, dtype=np.uint64)
+    n = C.c_int64(0)
+    _check(lib().ko_path_to_source(_p(f), _p(d), f.shape[0], f.shape[1], f.shape[2], loc_of(source, f.shape),
+                                   loc_of(target, f.shape), _p(path), C.byref(n)))
+    return locs_to_pts(path[: n.value], f.shape)
 
 
 def path_from_parents(parents, target):

@@ -375,6 +375,93 @@ static int ko_field_sssp(const float* f, int64_t sx, int64_t sy, int64_t sz, uin
   return KO_OK;
 }
 
+/* Predecessor walk from `start` back to the search source `stop` (canonical, identical in the HIP kernel):
+ *   - normally: pred(v) = achieving neighbour (fl(d[u]+f[v]) == d[v]) with d[u] < d[v], minimising (d[u], index);
+ *   - at the rail end of a railroad (f == 0): every achieving neighbour has d[u] == d[v]; take the smallest index;
+ *   - float-absorption plateau (a step cost below half an ulp of the accumulated distance: every achieving
+ *     neighbour has d[u] == d[v]): breadth-first search over the equal-distance achieving neighbours
+ *     (FIFO, neighbours in direction order 0..25) to the first voxel that has a strictly smaller achieving
+ *     predecessor; the BFS route is followed.  A real Dijkstra resolves such plateaus by its heap order. */
+static int ko_pred_strict(const float* f, const float* d, int64_t sx, int64_t sy, int64_t sz,
+                          uint64_t v, int rails_absorb, int allow_equal, uint64_t* pred) {
+  const int64_t sxy = sx * sy;
+  int64_t z = (int64_t)(v / (uint64_t)sxy), r = (int64_t)(v % (uint64_t)sxy), y = r / sx, x = r % sx;
+  const float dv = d[v], fv = f[v];
+  int found = 0; float bd = 0; uint64_t bu = 0;
+  for (int i = 0; i < 26; i++) {
+    int64_t nx = x + KO_DIR[i][0], ny = y + KO_DIR[i][1], nz = z + KO_DIR[i][2];
+    if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
+    uint64_t u = (uint64_t)(nx + sx * ny + sxy * nz);
+    float du = d[u];
+    if (du == INFINITY) continue;
+    if (rails_absorb && f[u] == 0.0f) continue;
+    if (du + fv != dv) continue;
+    if (!allow_equal && !(du < dv)) continue;
+    if (!found || du < bd || (du == bd && u < bu)) { found = 1; bd = du; bu = u; }
+  }
+  if (found) *pred = bu;
+  return found;
+}
+
+int64_t ko_plateau_count = 0;  /* instrumentation: plateau searches since the last reset */
+int64_t ko_get_plateau_count(int reset) { int64_t v = ko_plateau_count; if (reset) ko_plateau_count = 0; return v; }
+
+static int ko_walk(const float* f, const float* d, int64_t sx, int64_t sy, int64_t sz, uint64_t start, uint64_t stop,
+                   int rails_absorb, uint64_t* path, int64_t* npath) {
+  const int64_t sxy = sx * sy, n = sxy * sz;
+  int64_t k = 0; uint64_t v = start;
+  path[k++] = v;
+  uint8_t* seen = 0; uint64_t* q = 0; int64_t* par = 0;
+  int rc = KO_OK;
+  while (v != stop) {
+    uint64_t u;
+    if (k >= n) { rc = KO_ENOPATH; break; }
+    if (rails_absorb && v == start) {  /* the rail end: equal distances are the rule */
+      if (!ko_pred_strict(f, d, sx, sy, sz, v, 1, 1, &u)) { rc = KO_ENOPATH; break; }
+      path[k++] = u; v = u; continue;
+    }
+    if (ko_pred_strict(f, d, sx, sy, sz, v, rails_absorb, 0, &u)) { path[k++] = u; v = u; continue; }
+    /* plateau */
+    ko_plateau_count++;
+    if (!seen) {
+      seen = (uint8_t*)calloc((size_t)n, 1); q = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+      par = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+      if (!seen || !q || !par) { rc = KO_ENOMEM; break; }
+    }
+    int64_t head = 0, tail = 0, found = -1;
+    q[tail] = v; par[tail] = -1; tail++; seen[v] = 1;
+    while (head < tail) {
+      const uint64_t x = q[head];
+      uint64_t tmp;
+      if (head > 0 && ko_pred_strict(f, d, sx, sy, sz, x, rails_absorb, 0, &tmp)) { found = head; break; }
+      int64_t xz = (int64_t)(x / (uint64_t)sxy), xr = (int64_t)(x % (uint64_t)sxy), xy = xr / sx, xx = xr % sx;
+      for (int i = 0; i < 26; i++) {
+        int64_t nx = xx + KO_DIR[i][0], ny = xy + KO_DIR[i][1], nz = xz + KO_DIR[i][2];
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
+        uint64_t w = (uint64_t)(nx + sx * ny + sxy * nz);
+        if (seen[w] || d[w] != d[x]) continue;
+        if (rails_absorb && f[w] == 0.0f) continue;
+        if (d[w] + f[x] != d[x]) continue;
+        seen[w] = 1; q[tail] = w; par[tail] = head; tail++;
+      }
+      head++;
+    }
+    for (int64_t i = 0; i < tail; i++) seen[q[i]] = 0;
+    if (found < 0) { rc = KO_ENOPATH; break; }
+    /* route v -> ... -> q[found]: collect backwards, append forwards */
+    int64_t len = 0;
+    for (int64_t i = found; i > 0; i = par[i]) len++;
+    if (k + len > n) { rc = KO_ENOPATH; break; }
+    int64_t pos = k + len - 1;
+    for (int64_t i = found; i > 0; i = par[i]) path[pos--] = q[i];
+    k += len;
+    v = q[found];
+  }
+  free(seen); free(q); free(par);
+  *npath = k;
+  return rc;
+}
+
 /* a8: dijkstra3d.railroad(field, source=target) (trace.py:240-242).
  * Returns the path ordered rail end -> ... -> target (trace.py:249-250 keeps
  * path[:1] as the junction).  If the target itself is a rail the path is the
@@ -387,17 +474,24 @@ int ko_railroad(const float* f, int64_t sx, int64_t sy, int64_t sz, uint64_t tar
   uint64_t e = 0;
   int rc = ko_field_sssp(f, sx, sy, sz, target, 1, d, &e, settled);
   if (rc) return rc;
-  int64_t k = 0; uint64_t v = e;
-  path[k++] = v;
-  while (v != target) {
-    uint64_t u;
-    rc = ko_pred(f, d, sx, sy, sz, v, 1, &u);
-    if (rc) return rc;
-    if (d[u] >= d[v] && !(v == e)) return KO_EPLATEAU; /* float absorption plateau: not restated */
-    if (k >= n) return KO_EPLATEAU;
-    path[k++] = u; v = u;
-  }
-  *npath = k;
+  return ko_walk(f, d, sx, sy, sz, e, target, 1, path, npath);
+}
+
+/* fix_branching=False (trace.py:155,244): distances of the one Dijkstra from the root ... */
+int ko_field_distances(const float* f, int64_t sx, int64_t sy, int64_t sz, uint64_t source, float* d) {
+  const int64_t n = sx * sy * sz;
+  if ((int64_t)source >= n || f[source] == INFINITY) return KO_EINVAL;
+  return ko_field_sssp(f, sx, sy, sz, source, 0, d, 0, 0);
+}
+/* ... and dijkstra3d.path_from_parents(parents, target) as a predecessor walk target -> source on those
+ * distances, returned source -> ... -> target (handles absorption plateaus, see ko_walk).      */
+int ko_path_to_source(const float* f, const float* d, int64_t sx, int64_t sy, int64_t sz, uint64_t source,
+                      uint64_t target, uint64_t* path, int64_t* npath) {
+  if (d[target] == INFINITY) return KO_ENOPATH;
+  int rc = ko_walk(f, d, sx, sy, sz, target, source, 0, path, npath);
+  if (rc) return rc;
+  const int64_t k = *npath;
+  for (int64_t i = 0; i < k / 2; i++) { uint64_t t = path[i]; path[i] = path[k - 1 - i]; path[k - 1 - i] = t; }
   return KO_OK;
 }
 

@@ -87,7 +87,7 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     PDRF = K.compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, DAF[target])  # :148
 
     if not fix_branching:
-        parents = K.parental_field(PDRF, root)  # :155
+        parents = (PDRF, K.field_distances(PDRF, root))  # :155 (the parental field is its distance field here)
     else:
         parents = PDRF
 
@@ -157,7 +157,8 @@ def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
         max_paths = valid_labels
     if len(manual_targets_before) + len(manual_targets_after) >= max_paths:
         return []
-    parents[root] = 0  # initial rail, :220
+    if fix_branching:
+        parents[root] = 0  # initial rail, :220
     while (valid_labels > 0 or manual_targets_before or manual_targets_after) and len(paths) < max_paths:
         if manual_targets_before:
             target = manual_targets_before.pop()
@@ -169,7 +170,7 @@ def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
         if fix_branching:
             path, settled = K.railroad(parents, target, return_stats=True)
         else:
-            path = K.path_from_parents(parents, target)
+            path = K.path_to_source(parents[0], parents[1], root, target)  # :244
             settled = 0
         if soma_mode:  # trace.py:246-251
             dist_to_soma_root = np.linalg.norm(np.asarray(anisotropy, dtype=np.float32) * (np.asarray(path) - np.asarray(root)), axis=1)

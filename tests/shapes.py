@@ -61,3 +61,17 @@ def soma_shape(hole=False, shape=(64, 64, 64)):
     if hole:
         m[28:32, 30:34, 29:33] = 0
     return m
+
+
+def lollipop(length=1500, radius=14):
+    """A 1-voxel-thick stick ending in a ball: with pdrf_scale 1e5 the accumulated PDRF along the stick
+    exceeds 2^24 times the tiny PDRF near the ball centre -> float-absorption plateau in the railroad."""
+    n = 2 * radius + 5
+    shape = (length + n, n, n)
+    m = np.zeros(shape, np.uint8, order="F")
+    c = np.array([length + radius + 2, n // 2, n // 2])
+    g = np.stack(np.meshgrid(np.arange(length, shape[0]), np.arange(n), np.arange(n), indexing="ij"), -1)
+    ball = ((g - c) ** 2).sum(-1) <= radius ** 2
+    m[length:][ball] = 1
+    m[1:length + 3, n // 2, n // 2] = 1
+    return m, tuple(int(v) for v in c)

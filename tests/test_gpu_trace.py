@@ -167,3 +167,29 @@ def test_skeletonize_with_a_soma_label(eng):
     for k in got:
         np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
         np.testing.assert_array_equal(got[k].edges, want[k].edges)
+
+
+@pytest.mark.parametrize("fix_branching", [True, False])
+def test_float_absorption_plateau(eng, fix_branching):
+    """A 6000-voxel stick accumulates ~4.5e8 of PDRF (ulp 32) before it reaches the ball, whose centre has
+    PDRF < 16: fl(d + w) == d there.  The predecessor walk must cross the plateau the same way in the
+    oracle and on the GPU (BFS over equal-distance achieving neighbours)."""
+    import ctypes as C
+    import oracle
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    from shapes import lollipop
+    m, centre = lollipop(length=6000)
+    dbf = oracle.edt(m, (1, 1, 1))
+    root = centre if fix_branching else (1, m.shape[1] // 2, m.shape[2] // 2)  # big costs first, tiny ones last
+    kw = dict(scale=1.5, const=2, anisotropy=(1, 1, 1), pdrf_scale=100000, pdrf_exponent=4, root=root,
+              fix_branching=fix_branching, soma_detection_threshold=1e9, return_paths=True)
+    L = oracle.lib()
+    L.ko_get_plateau_count.restype = C.c_int64
+    L.ko_get_plateau_count(1)
+    want = P.trace(m, dbf, **kw)
+    assert L.ko_get_plateau_count(1) >= 1, "the fixture no longer produces a plateau"
+    got = trace(m, dbf, _engine=eng, **kw)
+    assert len(got) == len(want) >= 1
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
