@@ -138,7 +138,25 @@ def main():
     from kimimaro_amd.distributed import gather_skeletons
 
     eng = Engine()
-    lab, an = make_volume(args.workload)
+    if world > 1:
+        # rank 0 builds the volume once and broadcasts it over RCCL (8 ranks running the KD-tree recipe at the
+        # same time on one host would take minutes); any failure falls back to local generation (deterministic).
+        shape0, _, _, _, an = WORKLOADS[args.workload]
+        try:
+            if rank == 0:
+                lab, an = make_volume(args.workload)
+                d_vol = eng.to_device(lab)
+            else:
+                d_vol = torch.empty(int(np.prod(shape0)), dtype=torch.int32, device=eng.device)
+            dist.broadcast(d_vol, src=0)
+            if rank != 0:
+                lab = d_vol.cpu().numpy().view(np.uint32).reshape(shape0, order="F")
+            del d_vol
+        except Exception as e:  # pragma: no cover
+            print("bench: broadcast of the volume failed (%r); generating locally" % (e,), file=sys.stderr)
+            lab, an = make_volume(args.workload)
+    else:
+        lab, an = make_volume(args.workload)
     shape = lab.shape
     an = np.asarray(an, dtype=np.float32)
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)

@@ -193,3 +193,28 @@ def test_float_absorption_plateau(eng, fix_branching):
     assert len(got) == len(want) >= 1
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_skeletonize_fuzz_small_volumes(eng, seed):
+    """random small multi-label volumes, dust_threshold 0 (single voxels, 2-voxel labels, flat volumes,
+    labels touching every face) with fix_borders on and off: the whole product path vs the oracle pipeline."""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    rng = np.random.default_rng(1000 + seed)
+    shape = [(24, 20, 16), (40, 9, 7), (31, 31, 1), (12, 12, 12), (50, 3, 3), (17, 23, 5)][seed % 6]
+    an = [(1, 1, 1), (16, 16, 40), (4, 3, 2)][seed % 3]
+    nlab = int(rng.integers(2, 9))
+    lab = voronoi_labels(shape, nlab, seed=seed, pts_per_label=2, step=4.0, anisotropy=an)
+    lab[rng.random(shape) < 0.25] = 0          # holes and isolated voxels
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = float(rng.choice([0.5, 2.0, 6.0])) * an[0]
+    params["scale"] = float(rng.choice([0.5, 1.5, 4.0]))
+    fb = bool(seed % 2)
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=0, fix_borders=fb, progress=False, _engine=eng)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=0, fix_borders=fb)
+    assert sorted(got.keys()) == sorted(want.keys())
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
