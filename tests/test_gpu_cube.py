@@ -66,3 +66,38 @@ def test_cube_rejects_non_contiguous():
     L = np.ones((8, 8, 8), np.uint8)[::2]
     with pytest.raises(ValueError):
         roll_invalidation_cube(L, np.zeros(L.shape, np.float32), [(1, 1, 1)], 1.0, 1.0)
+
+
+def test_cube_reference_random_recipe_on_gpu():
+    """automated_test.py:710-747 verbatim recipe against the geometric reference, through kh_invalidate_cube."""
+    from kimimaro_amd.ops import roll_invalidation_cube
+    from test_oracle_golden import _expected_corner_cube
+    rng = np.random.default_rng(seed=0xDECAFBAD)
+    for trial in range(100):
+        shape = tuple(int(s) for s in rng.integers(8, 24, size=3))
+        labels = np.ones(shape, dtype=np.uint8)
+        dbf = np.zeros(shape, dtype=np.float32)
+        n_path = int(rng.integers(1, 4))
+        path = [tuple(int(rng.integers(0, s)) for s in shape) for _ in range(n_path)]
+        radius = float(rng.uniform(0.5, 3.0))
+        anisotropy = tuple(float(rng.uniform(0.5, 4.0)) for _ in range(3))
+        count, out = roll_invalidation_cube(labels.copy(), dbf, path, 0.0, radius, anisotropy=anisotropy)
+        expected = set()
+        for coord in path:
+            expected |= _expected_corner_cube(coord, radius, shape, anisotropy)
+        assert set(map(tuple, np.argwhere(out == 0).tolist())) == expected and count == len(expected), trial
+
+
+def test_cube_singleton_and_dbf_layout_untouched():
+    """automated_test.py:797-825: singleton volume; a C-ordered DBF with F-ordered labels is normalised
+    without mutating the caller's array."""
+    from kimimaro_amd.ops import roll_invalidation_cube
+    L = np.ones((1, 1, 1), np.uint8)
+    assert roll_invalidation_cube(L, np.zeros((1, 1, 1), np.float32), [(0, 0, 0)], 1.0, 1.0)[0] == 1
+    rng = np.random.default_rng(2)
+    Lf = np.asfortranarray(np.ones((9, 8, 7), np.uint8))
+    Dc = np.ascontiguousarray(rng.uniform(0.8, 2.5, (9, 8, 7)).astype(np.float32))
+    keep = Dc.copy()
+    c, out = roll_invalidation_cube(Lf, Dc, [(4, 4, 3)], 1.0, 0.5)
+    assert out is Lf and c > 0 and Dc.flags.c_contiguous
+    np.testing.assert_array_equal(Dc, keep)

@@ -94,3 +94,46 @@ def test_extra_targets():  # :201-231 (smaller plate)
     assert more.vertices.shape[0] >= base.vertices.shape[0]
     pre = P.skeletonize(labels, TP, dust_threshold=0, fix_borders=False, extra_targets_before=[(10, 89, 0)])[1]
     assert pre.vertices.shape[0] >= base.vertices.shape[0]
+
+
+def test_solid_image():  # automated_test.py:33-37 at 48^3 (single label: black_border EDT, targets on all six faces)
+    labels = np.ones((48, 48, 48), dtype=bool)
+    assert len(P.skeletonize(labels, fix_borders=True)) == 1
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_fix_borders_x_y(axis):  # :145-199 at 96^3: a bar through the volume along x / y
+    labels = np.zeros((96, 96, 96), dtype=np.uint8)
+    sl = [slice(24, 74)] * 3
+    sl[axis] = slice(None)
+    labels[tuple(sl)] = 128
+    skels = P.skeletonize(labels, teasar_params={"const": 250, "scale": 10, "pdrf_exponent": 4, "pdrf_scale": 100000},
+                          anisotropy=(1, 1, 1), dust_threshold=1000, fix_branching=True, fix_borders=True)
+    v = skels[128].voxel_space().vertices
+    others = [i for i in range(3) if i != axis]
+    assert np.all(v[:, axis] == np.arange(96))
+    for o in others:
+        assert np.all(v[:, o] == v[0, o]) and 47 <= v[0, o] <= 50
+
+
+def test_parallel_quadrants():  # :234-259 (four labels; the reference runs them in two processes)
+    labels = np.zeros((64, 64, 32), dtype=np.uint8)
+    labels[0:32, 0:32, :] = 1
+    labels[32:64, 0:32, :] = 2
+    labels[0:32, 32:64, :] = 3
+    labels[32:64, 32:64, :] = 4
+    assert len(P.skeletonize(labels, TP, dust_threshold=100, parallel=2)) == 4
+
+
+def test_joinability():  # :281-333: with fix_borders two overlapping chunks share a face vertex
+    from shapes import random_walk_tube
+    vol = random_walk_tube((64, 48, 48), 314, steps=80, step=3.0, radius=(2.5, 5.0)).astype(np.uint32)
+    params = dict(TP)
+    params["const"] = 4
+    sa = P.skeletonize(vol[:33], params, dust_threshold=50, fix_borders=True)
+    sb = P.skeletonize(vol[32:], params, dust_threshold=50, fix_borders=True)
+    if 1 in sa and 1 in sb:
+        va = {tuple(v[1:]) for v in sa[1].vertices[sa[1].vertices[:, 0] == 32].tolist()}
+        vb = {tuple(v[1:]) for v in sb[1].vertices[sb[1].vertices[:, 0] == 0].tolist()}
+        if va and vb:
+            assert va & vb

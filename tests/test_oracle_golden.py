@@ -142,3 +142,44 @@ def test_border_targets_golden():
         assert list(got.keys()) == keys.tolist(), i            # dict insertion order too
         for k, v in zip(keys.tolist(), vals.tolist()):
             assert (int(got[k][0]), int(got[k][1])) == tuple(v), (i, k)
+
+
+def _expected_corner_cube(coord, radius, shape, anisotropy=(1.0, 1.0, 1.0)):
+    """the geometric reference of the reference's own test (automated_test.py:635-648), restated."""
+    bbox = []
+    for i in range(3):
+        lo = max(0, int(coord[i] - radius / anisotropy[i]))
+        hi = min(shape[i] - 1, int(0.5 + coord[i] + radius / anisotropy[i]))
+        bbox.append((lo, hi))
+    return {(a, b, c) for a in range(bbox[0][0], bbox[0][1] + 1) for b in range(bbox[1][0], bbox[1][1] + 1)
+            for c in range(bbox[2][0], bbox[2][1] + 1)}
+
+
+def test_invalidation_cube_reference_random_recipe():
+    """automated_test.py:710-747 verbatim recipe (seed 0xDECAFBAD, 100 trials) against the geometric reference."""
+    rng = np.random.default_rng(seed=0xDECAFBAD)
+    for trial in range(100):
+        shape = tuple(int(s) for s in rng.integers(8, 24, size=3))
+        labels = np.ones(shape, dtype=np.uint8, order="F")
+        dbf = np.zeros(shape, dtype=np.float32, order="F")
+        n_path = int(rng.integers(1, 4))
+        path = [tuple(int(rng.integers(0, s)) for s in shape) for _ in range(n_path)]
+        radius = float(rng.uniform(0.5, 3.0))
+        anisotropy = tuple(float(rng.uniform(0.5, 4.0)) for _ in range(3))
+        count, out = K.roll_invalidation_cube(labels, dbf, path, 0.0, radius, anisotropy)
+        expected = set()
+        for coord in path:
+            expected |= _expected_corner_cube(coord, radius, shape, anisotropy)
+        assert set(map(tuple, np.argwhere(out == 0).tolist())) == expected and count == len(expected), trial
+
+
+def test_invalidation_cube_singleton_and_anisotropic_ordering():
+    """automated_test.py:680-695 (axis ordering) and the singleton volume."""
+    L = np.ones((10, 10, 10), np.uint8, order="F")
+    D = np.zeros((10, 10, 10), np.float32, order="F")
+    _, out = K.roll_invalidation_cube(L, D, [(5, 5, 5)], 0.0, 3.0, (1.0, 2.0, 4.0))
+    z = np.argwhere(out == 0)
+    widths = [z[:, i].max() - z[:, i].min() + 1 for i in range(3)]
+    assert widths[0] >= widths[1] >= widths[2]
+    L = np.ones((1, 1, 1), np.uint8, order="F")
+    assert K.roll_invalidation_cube(L, np.zeros((1, 1, 1), np.float32, order="F"), [(0, 0, 0)], 1.0, 1.0)[0] == 1
