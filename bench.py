@@ -266,8 +266,8 @@ def main():
     phases = {"ccl": round(t_ccl, 4)}
     prev = None
     for name, ts in timings:
-        if prev is not None and name != "setup":
-            phases[name] = round(ts - prev, 4)
+        if prev is not None:
+            phases["host_setup" if name == "setup" else name] = round(ts - prev, 4)
         prev = ts
     tk = E.LAST_TASKS
     nf = tk["count"].astype(np.float64).sum()
