@@ -160,16 +160,19 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * is +inf again on exit; list_daf: DAF gathered in list order (target finder keys).
  * Paths are written as linear indices, rail end first, into path_vertices with
  * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).
- * qstate as for kh_edf_batch.  lds_heap_nodes: how many top nodes of each label's invalidation heap
- * are mirrored in LDS (12 bytes each; 127 or 8191).  fix_branching = 0 selects the parental-field
- * variant (trace.py:155,244): one weighted Dijkstra from the root, paths returned root -> target.   */
+ * qstate as for kh_edf_batch.  heap_nodes: scratch for the invalidation heaps, 16 bytes per node
+ * (16-byte aligned), each label owning nodes [heap_offset, heap_offset + heap_capacity).
+ * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
+ * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
+ * from the root, paths returned root -> target.                                                  */
+#define KH_TRACE_PROFILE 1
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                    const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                    const uint32_t* manual_targets, float scale, float constant,
-                   uint32_t* queues, float* heap_keys, uint64_t* heap_payload,
-                   uint32_t* path_vertices, uint32_t* path_lengths, int lds_heap_nodes, int fix_branching,
+                   uint32_t* queues, void* heap_nodes,
+                   uint32_t* path_vertices, uint32_t* path_lengths, int flags, int fix_branching,
                    void* stream);
 
 /* small helpers used by the host mirror */

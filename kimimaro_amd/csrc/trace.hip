@@ -45,12 +45,6 @@ __device__ __forceinline__ float next_up(float x) { return __uint_as_float(__flo
 __device__ __forceinline__ uint32_t rdlane_u32(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l));
 }
-__device__ __forceinline__ float rdlane_f32(float v, int l) { return __uint_as_float(rdlane_u32(__float_as_uint(v), l)); }
-// value of lane l^1 (the sibling node): DPP quad_perm [1,0,3,2], no LDS crossbar round trip
-__device__ __forceinline__ float sibling_f32(float v) {
-  return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
-}
-
 struct Ctl {
   unsigned long long best_rail;
   unsigned long long red64[4];
@@ -314,33 +308,30 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
 //           (ties: left) and then pushes the last element up again.  Because keys never decrease
 //           from parent to child this lands exactly where the text-book early-exit sift-down lands
 //           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
-//           per memory round trip: 126 speculative child keys are fetched by the 64 lanes, the path
+//           per memory round trip: 126 speculative child nodes are fetched by the 64 lanes, the path
 //           is resolved from registers, and the nodes on it are moved up in one parallel step.
-// The heap lives in the label's slice of HBM scratch.  A write-through LDS mirror of heap levels 0-12 was
-// tried twice and measured 10-15 % SLOWER: the pop is bound by instruction issue of its single wave, not
-// by memory latency, and the mirror adds stores and a branch.
+// Nodes are 16-byte records {key bits, voxel, source index, -} in the label's slice of HBM scratch, so
+// a node is one dwordx4 load or store.  Keys are non-negative floats: they are compared as their bit
+// patterns (unsigned), which lets "ties go left" be written as k < sibling + (1 on left lanes).
+// A write-through LDS mirror of heap levels 0-12 was tried twice and measured 10-15 % SLOWER: the pop is
+// bound by instruction issue of its single wave more than by memory latency.
+// a native LLVM vector (HIP's uint4 is a struct around a union, which ends up in scratch memory here)
+typedef uint32_t hnode_t __attribute__((ext_vector_type(4)));
+
 struct Heap {
-  float* key;      // HBM scratch of this label (L2 resident in practice)
-  uint64_t* pay;   // (source index << 32) | voxel
+  hnode_t* node;     // HBM scratch of this label (L2 resident in practice)
   uint32_t cap, n;
   // per-lane constants of the 126-node speculative sub-tree (children of node m: 2m+2, 2m+3; parent of
   // m >= 2: (m-2)>>1).  Lane l holds node m = l ("slot 0", depths 1..6) and m = l+64 ("slot 1", depth 6).
   unsigned long long am0, am1;  // slot-0 ballot bits of the node's ancestors (am0 including itself)
   uint32_t sh0, j0, j1;         // heap index of my slot-0 node = ((hole+1) << sh0) - 1 + j0, slot 1: << 6, + j1
+  uint32_t lf;                  // 1 on even lanes (left children), 0 on odd lanes
 };
-struct HNode { float k; uint32_t vox, src; };
 
-__device__ __forceinline__ HNode hload(const Heap& h, uint32_t i) {
-  HNode n;
-  n.k = h.key[i];
-  const uint64_t p = h.pay[i];
-  n.vox = (uint32_t)p;
-  n.src = (uint32_t)(p >> 32);
-  return n;
-}
-__device__ __forceinline__ void hstore(const Heap& h, uint32_t i, float k, uint32_t vox, uint32_t src) {
-  h.key[i] = k;
-  h.pay[i] = ((uint64_t)src << 32) | vox;
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// value of lane l^1 (the sibling node): DPP quad_perm [1,0,3,2], no LDS crossbar round trip
+__device__ __forceinline__ uint32_t sibling_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
 __device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
@@ -353,26 +344,25 @@ __device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
   h.sh0 = (uint32_t)d0;
   h.j0 = (uint32_t)(lane + 2 - (1 << d0));
   h.j1 = (uint32_t)(lane + 2);
+  h.lf = (lane & 1) ? 0u : 1u;
 }
 
 // all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
 // the whole node of ancestor generation g+1, a ballot gives the climb length m (the ancestors with
 // key >= k form a prefix because keys never decrease from parent to child), lanes < m write their
-// ancestor one generation down and lane 0 drops the new node into generation m's slot.
-__device__ __forceinline__ bool heap_push_wave(Heap& h, float k, uint32_t vox, uint32_t src, int lane) {
+// ancestor one generation down and lane m drops the new node into generation m's slot.
+__device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
   if (h.n >= h.cap) return false;
   const uint32_t pos = h.n++;
   const int sh = lane + 1 < 32 ? lane + 1 : 31;
   const uint32_t q = (pos + 1u) >> sh;
   const bool valid = (lane < 31) && q >= 1u;
-  HNode a;
-  a.k = 0.0f; a.vox = 0; a.src = 0;
-  if (valid) a = hload(h, q - 1u);
-  const unsigned long long climb = __ballot(valid && a.k >= k);
+  const hnode_t a = h.node[valid ? q - 1u : 0u];
+  const unsigned long long climb = ballot64(valid && a.x >= kbits);
   const int m = __ffsll((long long)~climb) - 1;  // length of the leading run of set bits (lane 63 never set)
-  const uint32_t dest = lane < 32 ? ((pos + 1u) >> lane) - 1u : 0u;  // slot of generation `lane` (lane 0: the new leaf)
-  if (lane < m) hstore(h, dest, a.k, a.vox, a.src);
-  if (lane == 0) hstore(h, ((pos + 1u) >> m) - 1u, k, vox, src);
+  const uint32_t dest = ((pos + 1u) >> (lane < 31 ? lane : 31)) - 1u;  // slot of generation `lane` (lane 0: the new leaf)
+  const hnode_t fresh = {kbits, vox, src, 0u};
+  if (lane <= m) h.node[dest] = lane < m ? a : fresh;
   return true;
 }
 
@@ -381,80 +371,73 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, float k, uint32_t vox, u
 // nodes with key < last.key move up one level and `last` takes the slot of the deepest of them.
 // The wave fetches 6 levels (126 whole nodes, 2 per lane) per round trip.  A node is on the path iff it
 // and all its ancestors in the sub-tree beat their siblings: one sibling compare per lane, one ballot,
-// one mask test against the lane's constant ancestor mask.  The chunks stay in registers and every
-// write is issued at the end, so the load of `last` overlaps the whole descent.  Loads are
-// unconditional (index clamped to 0, key masked to +inf): no divergent branches in the descent.
+// one mask test against the lane's constant ancestor mask.  The chunks nest (chunk c+1 runs inside
+// chunk c, which keeps its two nodes in registers) and every write is issued on the way back up, so the
+// load of `last` overlaps the whole descent.  Loads are unconditional (index clamped to 0, key masked
+// to +inf): no divergent branches in the descent.
 // 32-bit index math is safe: the hole of chunk c sits at level 6c <= 24, so (hole+1) << 6 < 2^31.
 #define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
+template <int C>
+__device__ __forceinline__ void heap_pop_chunk(const Heap& h, uint32_t hole, uint32_t len, uint32_t vk, int lane,
+                                               uint32_t& deepest, bool& found) {
+  const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
+  const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
+  const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
+  const hnode_t n0 = h.node[e0 ? i0 : 0u], n1 = h.node[e1 ? i1 : 0u];
+  const uint32_t k0 = e0 ? n0.x : INF_BITS, k1 = e1 ? n1.x : INF_BITS;
+  // a node beats its sibling if it is the left one and left.key <= right.key, or the right one and
+  // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
+  const bool w0 = e0 & (k0 < sibling_u32(k0) + h.lf);
+  const bool w1 = e1 & (k1 < sibling_u32(k1) + h.lf);
+  const unsigned long long W0 = ballot64(w0);
+  const bool on0 = (W0 & h.am0) == h.am0;
+  const bool on1 = w1 && ((W0 & h.am1) == h.am1);
+  if constexpr (C + 1 < KH_POP_CHUNKS) {
+    // next hole = the depth-6 node of the path, if the path got that deep and that node has children
+    const unsigned long long P0 = ballot64(on0), P1 = ballot64(on1);
+    uint32_t nh = 0;
+    if (P1) nh = rdlane_u32(i1, __ffsll((long long)P1) - 1);
+    else if (P0 >> 62) nh = rdlane_u32(i0, (P0 >> 63) ? 63 : 62);
+    if (nh != 0u && 2u * nh + 1u < len) heap_pop_chunk<C + 1>(h, nh, len, vk, lane, deepest, found);
+  }
+  // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
+  // deepest such node (or the root).  Path keys are non-decreasing with depth.
+  const bool mv0 = on0 && k0 < vk;
+  const bool mv1 = on1 && k1 < vk;
+  if (mv0) h.node[(i0 - 1u) >> 1] = n0;
+  if (mv1) h.node[(i1 - 1u) >> 1] = n1;
+  if (!found) {
+    const unsigned long long M0 = ballot64(mv0), M1 = ballot64(mv1);
+    if (M1) { deepest = rdlane_u32(i1, __ffsll((long long)M1) - 1); found = true; }
+    else if (M0) { deepest = rdlane_u32(i0, 63 - __clzll((long long)M0)); found = true; }
+  }
+}
+
 __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
   const uint32_t len = h.n - 1u;
   h.n = len;
   if (len == 0) return;
-  const HNode last = hload(h, len);  // consumed only after the descent
-  const bool left = (lane & 1) == 0;
-  HNode c0[KH_POP_CHUNKS], c1[KH_POP_CHUNKS];
-  uint32_t x0[KH_POP_CHUNKS], x1[KH_POP_CHUNKS];  // heap index of my node if it is on the path, else 0
-  uint32_t hole = 0;
-  int nch = 0;
-#pragma unroll
-  for (int c = 0; c < KH_POP_CHUNKS; c++) {
-    if (nch == c && 2u * hole + 1u < len) {  // wave uniform
-      const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
-      const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
-      const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
-      HNode n0 = hload(h, e0 ? i0 : 0u), n1 = hload(h, e1 ? i1 : 0u);
-      n0.k = e0 ? n0.k : KH_INF;
-      n1.k = e1 ? n1.k : KH_INF;
-      // a node beats its sibling if it is the left one and right.key >= left.key, or the right one and
-      // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
-      const float s0 = sibling_f32(n0.k), s1 = sibling_f32(n1.k);
-      const bool w0 = e0 & ((left & (s0 >= n0.k)) | (!left & (n0.k < s0)));
-      const bool w1 = e1 & ((left & (s1 >= n1.k)) | (!left & (n1.k < s1)));
-      const unsigned long long W0 = __ballot(w0);
-      const bool on0 = (W0 & h.am0) == h.am0;
-      const bool on1 = w1 && ((W0 & h.am1) == h.am1);
-      const unsigned long long P0 = __ballot(on0), P1 = __ballot(on1);
-      c0[c] = n0; c1[c] = n1;
-      x0[c] = on0 ? i0 : 0u;
-      x1[c] = on1 ? i1 : 0u;
-      // next hole = the depth-6 node of the path, if the path got that deep
-      if (P1) { hole = rdlane_u32(i1, __ffsll((long long)P1) - 1); nch = c + 1; }
-      else if (P0 >> 62) { hole = rdlane_u32(i0, (P0 >> 63) ? 63 : 62); nch = c + 1; }
-      else nch = -(c + 1);  // the path ended at a leaf above depth 6: stop descending
-    }
-  }
-  if (nch < 0) nch = -nch;
-  // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
-  // deepest such node (or the root).  Path keys are non-decreasing with depth.
+  const hnode_t last = h.node[len];  // consumed only after the descent
   uint32_t deepest = 0;
-  const float vk = last.k;
-#pragma unroll
-  for (int c = 0; c < KH_POP_CHUNKS; c++) {
-    if (c < nch) {
-      const bool mv0 = x0[c] != 0u && c0[c].k < vk;
-      const bool mv1 = x1[c] != 0u && c1[c].k < vk;
-      if (mv0) hstore(h, (x0[c] - 1u) >> 1, c0[c].k, c0[c].vox, c0[c].src);
-      if (mv1) hstore(h, (x1[c] - 1u) >> 1, c1[c].k, c1[c].vox, c1[c].src);
-      const unsigned long long M0 = __ballot(mv0), M1 = __ballot(mv1);
-      if (M1) deepest = rdlane_u32(x1[c], __ffsll((long long)M1) - 1);
-      else if (M0) deepest = rdlane_u32(x0[c], 63 - __clzll((long long)M0));
-    }
-  }
-  if (lane == 0) hstore(h, deepest, last.k, last.vox, last.src);
+  bool found = false;
+  if (len > 1u) heap_pop_chunk<0>(h, 0u, len, last.x, lane, deepest, found);
+  if (lane == 0) h.node[deepest] = last;
 }
 
-// wave 0 only.  Returns the number of voxels invalidated.
+// wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
+// cycle split (s_memtime waits on the scalar memory counter, so the production kernel leaves it out).
+template <bool PROF>
 __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                     float scale, float constant, Heap& h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3) {
   const int lane = threadIdx.x & 63;
-  unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt;
+  unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt = 0;
   h.n = 0;
   uint32_t npush = 0;
   bool ovf = false;
   for (uint32_t i = 0; i < npath; i++) {
-    if (!heap_push_wave(h, 0.0f, path[i], i, lane)) ovf = true;
+    if (!heap_push_wave(h, 0u, path[i], i, lane)) ovf = true;
     npush++;
   }
   const uint32_t sx = (uint32_t)g.sx, sxy = (uint32_t)g.sxy;
@@ -463,14 +446,14 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
   while (h.n > 0) {
-    const HNode top = hload(h, 0);
-    const uint32_t vox = top.vox, si = top.src;
+    const hnode_t top = h.node[0];
+    const uint32_t vox = top.y, si = top.z;
     const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
-    tt = clock64();
+    if (PROF) tt = clock64();
     heap_pop_wave(h, lane);
-    c_pop += clock64() - tt;
+    if (PROF) c_pop += clock64() - tt;
     if (!live) continue;
-    tt = clock64();
+    if (PROF) tt = clock64();
     if (lane == 0) alive[vox] = 0;
     count++;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -509,23 +492,21 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
         }
       }
     }
-    unsigned long long m = __ballot(want);
-    c_fire += clock64() - tt;
-    tt = clock64();
+    unsigned long long m = ballot64(want);
+    if (PROF) { c_fire += clock64() - tt; tt = clock64(); }
+    const uint32_t ndb = __float_as_uint(nd);
     while (m) {
       const int k = __ffsll((long long)m) - 1;
       m &= m - 1;
-      const float kd = rdlane_f32(nd, k);
-      const uint32_t kq = rdlane_u32(q, k);
-      if (!heap_push_wave(h, kd, kq, si, lane)) ovf = true;
+      if (!heap_push_wave(h, rdlane_u32(ndb, k), rdlane_u32(q, k), si, lane)) ovf = true;
       npush++;
     }
-    c_push += clock64() - tt;
+    if (PROF) c_push += clock64() - tt;
   }
   if (lane == 0) {
     if (ovf) atomicOr(status, KH_ST_HEAP_OVERFLOW);
     *pushes += npush;
-    cyc3[0] += c_pop; cyc3[1] += c_push; cyc3[2] += c_fire;
+    if (PROF) { cyc3[0] += c_pop; cyc3[1] += c_push; cyc3[2] += c_fire; }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   return count;
@@ -629,14 +610,15 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
   return n;
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,
                                                           uint8_t* alive, uint8_t* qstate,
                                                           const uint32_t* __restrict__ manual_targets,
-                                                          float scale, float constant, uint32_t* queues, float* heap_keys,
-                                                          uint64_t* heap_payload, uint32_t* path_vertices,
+                                                          float scale, float constant, uint32_t* queues, hnode_t* heap_nodes,
+                                                          uint32_t* path_vertices,
                                                           uint32_t* path_lengths, int fix_branching) {
   __shared__ Ctl ctl;
   kh_label_t* task = &tasks[blockIdx.x];
@@ -653,8 +635,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
   Heap heap;
-  heap.key = heap_keys + task->heap_offset;
-  heap.pay = heap_payload + task->heap_offset;
+  heap.node = heap_nodes + task->heap_offset;
   heap.cap = task->heap_capacity;
   heap.n = 0;
   heap_init_lane(heap, lane);
@@ -679,7 +660,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 0) {
-      const uint32_t c = invalidate_ball(ctl.g, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+      const uint32_t c = invalidate_ball<PROF>(ctl.g, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
                                          heap, &ctl.status, &ctl.u3, ctl.cyc3);
       if (lane == 0) ctl.u1 = c;
     }
@@ -819,7 +800,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     t_rail += clock64() - t0; t0 = clock64();
     if (valid > 0) {
       if (wave == 0) {
-        const uint32_t c = invalidate_ball(ctl.g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
+        const uint32_t c = invalidate_ball<PROF>(ctl.g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
                                            &ctl.u3, ctl.cyc3);
         if (lane == 0) ctl.u1 = c;
       }
@@ -926,19 +907,24 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                               const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
-                              float* heap_keys, uint64_t* heap_payload, uint32_t* path_vertices, uint32_t* path_lengths,
-                              int lds_heap_nodes, int fix_branching, void* stream) {
+                              void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths, int flags,
+                              int fix_branching, void* stream) {
   if (int rc = require_device()) return rc;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
-  if (lds_heap_nodes < 0 || lds_heap_nodes > 13000) { set_error("kh_trace_paths: lds_heap_nodes out of range"); return KH_EINVAL; }
+  if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
+  if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
-  (void)lds_heap_nodes;  // reserved: an LDS mirror of the heap tops was measured twice to make things slower
-  hipLaunchKernelGGL(trace_paths_kernel, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, tasks, lists, list_daf, nbrmask, g,
-                     dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_keys, heap_payload,
-                     path_vertices, path_lengths, fix_branching);
+  if (flags & KH_TRACE_PROFILE)
+    hipLaunchKernelGGL(trace_paths_kernel<true>, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, tasks, lists, list_daf,
+                       nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues,
+                       (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching);
+  else
+    hipLaunchKernelGGL(trace_paths_kernel<false>, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, tasks, lists, list_daf,
+                       nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues,
+                       (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -32,6 +32,7 @@ class Engine:
         self.lib = _abi.require_gpu()
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
+        self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -249,15 +250,15 @@ class Engine:
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
-        d_hkeys = self.empty(int(hcap.sum()), t.float32)
-        d_hpay = self.empty(int(hcap.sum()), t.int64)
+        d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first
         _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
                                       P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
-                                      np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_hkeys),
-                                      P(d_hpay), P(d_pverts), P(d_plens), 0, int(bool(fix_branching)), st))
+                                      np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
+                                      P(d_pverts), P(d_plens), 1 if self.profile else 0,
+                                      int(bool(fix_branching)), st))
         mark("paths")
         out_tasks = d_tasks.cpu().numpy().view(_abi.LABEL_T).copy()
         global LAST_TASKS

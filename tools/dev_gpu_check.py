@@ -9,6 +9,8 @@ import kimimaro_amd
 from shapes import voronoi_labels
 
 eng = Engine()
+import os
+eng.profile = bool(int(os.environ.get("KH_PROFILE", "0")))
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 if which == "c2":
     shape, nl, pts, seed, an = (512, 512, 100), 333, 12, 2, (16, 16, 40)
@@ -46,6 +48,5 @@ if tk is not None:
     print("kcyc target/rail/inval sums:", tk["cyc_target"].sum(), tk["cyc_rail"].sum(), tk["cyc_inval"].sum())
     i = np.argmax(tk["cyc_inval"].astype(np.int64) + tk["cyc_rail"])
     print("worst label: count", tk["count"][i], "paths", tk["n_paths"][i], "kcyc", tk["cyc_target"][i], tk["cyc_rail"][i], tk["cyc_inval"][i], "pushes", tk["stat_heap_pushes"][i], "settled", tk["stat_settled"][i])
-    print("kcyc pop/push/fire sums:", tk["cyc_pop"].astype(np.int64).sum(), tk["cyc_push"].astype(np.int64).sum(), tk["cyc_fire"].astype(np.int64).sum())
     print("kcyc pop/push/fire sums:", tk["cyc_pop"].astype(np.int64).sum(), tk["cyc_push"].astype(np.int64).sum(), tk["cyc_fire"].astype(np.int64).sum())
     print("pushes total", tk["stat_heap_pushes"].astype(np.int64).sum(), "settled total", tk["stat_settled"].astype(np.int64).sum(), "paths", tk["n_paths"].sum())
