@@ -317,9 +317,16 @@ __global__ __launch_bounds__(256) void edf_batch_kernel(kh_label_t* tasks, int m
 // bound by instruction issue of its single wave more than by memory latency.
 // a native LLVM vector (HIP's uint4 is a struct around a union, which ends up in scratch memory here)
 typedef uint32_t hnode_t __attribute__((ext_vector_type(4)));
+// LDS pointers keep their address space in the type, so LDS and HBM accesses can never be merged into flat_* ones
+typedef __attribute__((address_space(3))) hnode_t lds_hnode_t;
 
+// Heap slots 0..KH_TOP-1 (the root and the first 6-level chunk under it) live in LDS and nowhere else; slots
+// >= KH_TOP live in the label's slice of HBM scratch.  Every pop starts in the LDS part, so the top read and
+// the first chunk cost an LDS round trip instead of an L2 one.
+#define KH_TOP 127
 struct Heap {
-  hnode_t* node;     // HBM scratch of this label (L2 resident in practice)
+  hnode_t* node;   // HBM scratch of this label (L2 resident in practice); slots < KH_TOP unused
+  lds_hnode_t* top;  // LDS, KH_TOP + 3 entries (the first chunk's lanes 62/63 read two slots past the end)
   uint32_t cap, n;
   // per-lane constants of the 126-node speculative sub-tree (children of node m: 2m+2, 2m+3; parent of
   // m >= 2: (m-2)>>1).  Lane l holds node m = l ("slot 0", depths 1..6) and m = l+64 ("slot 1", depth 6).
@@ -348,21 +355,35 @@ __device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
 }
 
 // all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
-// the whole node of ancestor generation g+1, a ballot gives the climb length m (the ancestors with
-// key >= k form a prefix because keys never decrease from parent to child), lanes < m write their
-// ancestor one generation down and lane m drops the new node into generation m's slot.
+// the whole node of ancestor generation g+1 (from LDS or HBM, whichever holds that slot), a ballot gives
+// the climb length m (the ancestors with key >= k form a prefix because keys never decrease from parent
+// to child), lanes < m write their ancestor one generation down and lane m drops the new node into
+// generation m's slot.
 __device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
   if (h.n >= h.cap) return false;
   const uint32_t pos = h.n++;
   const int sh = lane + 1 < 32 ? lane + 1 : 31;
   const uint32_t q = (pos + 1u) >> sh;
   const bool valid = (lane < 31) && q >= 1u;
-  const hnode_t a = h.node[valid ? q - 1u : 0u];
+  const uint32_t ai = q - 1u;
+  hnode_t a;
+  if (pos < KH_TOP) {                     // wave uniform: the whole chain is in LDS
+    a = h.top[valid ? ai : 0u];
+  } else {
+    const bool lo = !valid || ai < KH_TOP;
+    const hnode_t ag = h.node[lo ? KH_TOP : ai];
+    const hnode_t al = h.top[lo && valid ? ai : 0u];
+    a = lo ? al : ag;
+  }
   const unsigned long long climb = ballot64(valid && a.x >= kbits);
   const int m = __ffsll((long long)~climb) - 1;  // length of the leading run of set bits (lane 63 never set)
   const uint32_t dest = ((pos + 1u) >> (lane < 31 ? lane : 31)) - 1u;  // slot of generation `lane` (lane 0: the new leaf)
   const hnode_t fresh = {kbits, vox, src, 0u};
-  if (lane <= m) h.node[dest] = lane < m ? a : fresh;
+  const hnode_t val = lane < m ? a : fresh;
+  if (lane <= m) {
+    if (dest < KH_TOP) h.top[dest] = val;
+    else h.node[dest] = val;
+  }
   return true;
 }
 
@@ -373,8 +394,8 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t
 // and all its ancestors in the sub-tree beat their siblings: one sibling compare per lane, one ballot,
 // one mask test against the lane's constant ancestor mask.  The chunks nest (chunk c+1 runs inside
 // chunk c, which keeps its two nodes in registers) and every write is issued on the way back up, so the
-// load of `last` overlaps the whole descent.  Loads are unconditional (index clamped to 0, key masked
-// to +inf): no divergent branches in the descent.
+// load of `last` overlaps the whole descent.  Loads are unconditional (index clamped, key masked
+// to +inf): no divergent branches in the descent.  Chunk 0 is exactly the LDS part of the heap.
 // 32-bit index math is safe: the hole of chunk c sits at level 6c <= 24, so (hole+1) << 6 < 2^31.
 #define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
 template <int C>
@@ -383,7 +404,9 @@ __device__ __forceinline__ void heap_pop_chunk(const Heap& h, uint32_t hole, uin
   const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
   const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
   const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
-  const hnode_t n0 = h.node[e0 ? i0 : 0u], n1 = h.node[e1 ? i1 : 0u];
+  hnode_t n0, n1;
+  if constexpr (C == 0) { n0 = h.top[i0]; n1 = h.top[i1]; }   // i0 = lane + 1, i1 = lane + 65
+  else { n0 = h.node[e0 ? i0 : KH_TOP]; n1 = h.node[e1 ? i1 : KH_TOP]; }
   const uint32_t k0 = e0 ? n0.x : INF_BITS, k1 = e1 ? n1.x : INF_BITS;
   // a node beats its sibling if it is the left one and left.key <= right.key, or the right one and
   // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
@@ -404,8 +427,18 @@ __device__ __forceinline__ void heap_pop_chunk(const Heap& h, uint32_t hole, uin
   // deepest such node (or the root).  Path keys are non-decreasing with depth.
   const bool mv0 = on0 && k0 < vk;
   const bool mv1 = on1 && k1 < vk;
-  if (mv0) h.node[(i0 - 1u) >> 1] = n0;
-  if (mv1) h.node[(i1 - 1u) >> 1] = n1;
+  const uint32_t q0 = (i0 - 1u) >> 1, q1 = (i1 - 1u) >> 1;
+  if constexpr (C == 0) {
+    if (mv0) h.top[q0] = n0;
+    if (mv1) h.top[q1] = n1;
+  } else if constexpr (C == 1) {
+    // the parent of this chunk's two depth-1 nodes (lanes 0, 1) is the hole: a depth-6 node of the LDS part
+    if (mv0) { if (lane < 2) h.top[hole] = n0; else h.node[q0] = n0; }
+    if (mv1) h.node[q1] = n1;
+  } else {
+    if (mv0) h.node[q0] = n0;
+    if (mv1) h.node[q1] = n1;
+  }
   if (!found) {
     const unsigned long long M0 = ballot64(mv0), M1 = ballot64(mv1);
     if (M1) { deepest = rdlane_u32(i1, __ffsll((long long)M1) - 1); found = true; }
@@ -417,11 +450,14 @@ __device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
   const uint32_t len = h.n - 1u;
   h.n = len;
   if (len == 0) return;
-  const hnode_t last = h.node[len];  // consumed only after the descent
+  const hnode_t last = len < KH_TOP ? h.top[len] : h.node[len];  // consumed only after the descent
   uint32_t deepest = 0;
   bool found = false;
   if (len > 1u) heap_pop_chunk<0>(h, 0u, len, last.x, lane, deepest, found);
-  if (lane == 0) h.node[deepest] = last;
+  if (lane == 0) {
+    if (deepest < KH_TOP) h.top[deepest] = last;
+    else h.node[deepest] = last;
+  }
 }
 
 // wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
@@ -446,7 +482,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
   while (h.n > 0) {
-    const hnode_t top = h.node[0];
+    const hnode_t top = h.top[0];
     const uint32_t vox = top.y, si = top.z;
     const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
     if (PROF) tt = clock64();
@@ -621,6 +657,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
                                                           uint32_t* path_vertices,
                                                           uint32_t* path_lengths, int fix_branching) {
   __shared__ Ctl ctl;
+  __shared__ hnode_t heap_top[KH_TOP + 3];
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
@@ -636,6 +673,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   q.touched = q.c + q.cap;
   Heap heap;
   heap.node = heap_nodes + task->heap_offset;
+  heap.top = (lds_hnode_t*)heap_top;
   heap.cap = task->heap_capacity;
   heap.n = 0;
   heap_init_lane(heap, lane);
