@@ -106,26 +106,30 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
 #define KH_EDT_H 32
 #define KH_EDT_ROWS (KH_EDT_T + 2 * KH_EDT_H)
 
+// 128-bit mask helpers; the bit position p is wave uniform (a row index), so the shifts are by scalars and
+// the two cases of each shift are scalar branches; the data dependent part is select-only.
 __device__ __forceinline__ int zeros_down(unsigned long long lo, unsigned long long hi, int p) {
-  // number of consecutive zero bits at p, p-1, ... ; p+1 when none is set down to bit 0
-  if (p >= 64) {
-    const unsigned long long x = hi << (127 - p);
-    if (x) return __clzll((long long)x);
-    return (p - 63) + (lo ? __clzll((long long)lo) : 64);
-  }
-  const unsigned long long x = lo << (63 - p);
-  return x ? __clzll((long long)x) : p + 1;
+  // number of consecutive zero bits at p, p-1, ... ; p+1 when none is set down to bit 0  (0 <= p <= 127)
+  const int s = 127 - p;  // bits p..0 moved to the top of a 128-bit word
+  unsigned long long xh, xl;
+  if (s >= 64) { xh = lo << (s - 64); xl = 0; }
+  else if (s == 0) { xh = hi; xl = lo; }
+  else { xh = (hi << s) | (lo >> (64 - s)); xl = lo << s; }
+  const int nz = xh ? __clzll((long long)xh) : 64 + (xl ? __clzll((long long)xl) : 64);
+  return min(nz, p + 1);
 }
 __device__ __forceinline__ int zeros_up(unsigned long long lo, unsigned long long hi, int p) {
   // number of consecutive zero bits at p, p+1, ... ; 128-p when none is set up to bit 127  (0 <= p <= 128)
   if (p >= 128) return 0;
-  if (p < 64) {
-    const unsigned long long x = lo >> p;
-    if (x) return __ffsll((long long)x) - 1;
-    return (64 - p) + (hi ? __ffsll((long long)hi) - 1 : 64);
-  }
-  const unsigned long long x = hi >> (p - 64);
-  return x ? __ffsll((long long)x) - 1 : 128 - p;
+  unsigned long long xh, xl;
+  if (p >= 64) { xl = hi >> (p - 64); xh = 0; }
+  else if (p == 0) { xl = lo; xh = hi; }
+  else { xl = (lo >> p) | (hi << (64 - p)); xh = hi >> p; }
+  const int nz = xl ? __ffsll((long long)xl) - 1 : 64 + (xh ? __ffsll((long long)xh) - 1 : 64);
+  return min(nz, 128 - p);
+}
+__device__ __forceinline__ bool bit128(unsigned long long lo, unsigned long long hi, int p) {
+  return (((p < 64) ? (lo >> p) : (hi >> (p - 64))) & 1ull) != 0;
 }
 
 template <typename LT, bool LAST>
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border) {
   __shared__ float tile[KH_EDT_ROWS * 64];
-  __shared__ unsigned long long part[4][4][64];  // [ly][chg lo, chg hi, bg lo, bg hi][lx]
+  __shared__ unsigned int part[2][4][64];  // [label change | background][ly][lx]: 32 rows of a column mask each
+  __shared__ __attribute__((aligned(16))) float tsq[KH_EDT_ROWS + 8];  // [0] = +inf, [k+3] = (w*k)^2 for k >= 1
   // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride ; blockDim = (64, 4)
   const int xt = (sx + 63) >> 6, at = (n + KH_EDT_T - 1) / KH_EDT_T;
   const int64_t ntiles = (int64_t)xt * at * m;
@@ -141,7 +146,13 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
   const int64_t per_xcd = (nblk + 7) / 8;
   const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t stride = per_xcd * 8;
-  const int lx = threadIdx.x, ly = threadIdx.y;
+  // blockDim = (64, 4): a wave is one row of the block, so ly is wave uniform -- say so (SGPR), which turns
+  // every row-index test and shift below into scalar code
+  const int lx = threadIdx.x, ly = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  for (int k = threadIdx.y * 64 + threadIdx.x; k < KH_EDT_ROWS + 8; k += 256) {
+    const float d = w * (float)(k - 3);
+    tsq[k] = k == 0 ? KH_INF : d * d;
+  }
   for (int64_t t = logical; t < ntiles; t += stride) {
     const int tx = (int)(t % xt);
     const int64_t rr = t / xt;
@@ -151,7 +162,6 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
     const int A0 = ta * KH_EDT_T;
     const int64_t base = x + (int64_t)o * ostride;
     __syncthreads();  // previous tile fully consumed
-    unsigned long long c_lo = 0, c_hi = 0, b_lo = 0, b_hi = 0;
     {
       // thread (lx, ly) stages the 32 consecutive rows [32*ly, 32*ly+32): the label of the previous row
       // is the previous iteration's register, so labels are read once (+1 row per thread).
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
       for (int j = 0; j < KH_EDT_ROWS / 4; j++) {
         const int pos = pbeg + j;
         const bool valid = x < sx && pos >= 0 && pos < n;
-        float v = 0.0f;
+        float v = KH_INF;
         LT L = 0;
         if (valid) {
           const int64_t q = base + (int64_t)pos * astride;
@@ -179,110 +189,93 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
         bm |= (bg ? 1u : 0u) << j;
         Lp = L;
       }
-      // rows of ly = 0,1 live in the low word, ly = 2,3 in the high word
-      const unsigned long long cw = (unsigned long long)cm << ((ly & 1) * 32);
-      const unsigned long long bw = (unsigned long long)bm << ((ly & 1) * 32);
-      if (ly < 2) { c_lo = cw; b_lo = bw; } else { c_hi = cw; b_hi = bw; }
+      part[0][ly][lx] = cm;  // rows [32*ly, 32*ly+32) of the column masks
+      part[1][ly][lx] = bm;
     }
-    part[ly][0][lx] = c_lo; part[ly][1][lx] = c_hi; part[ly][2][lx] = b_lo; part[ly][3][lx] = b_hi;
     __syncthreads();
     if (x >= sx) continue;
-    c_lo = part[0][0][lx] | part[1][0][lx] | part[2][0][lx] | part[3][0][lx];
-    c_hi = part[0][1][lx] | part[1][1][lx] | part[2][1][lx] | part[3][1][lx];
-    b_lo = part[0][2][lx] | part[1][2][lx] | part[2][2][lx] | part[3][2][lx];
-    b_hi = part[0][3][lx] | part[1][3][lx] | part[2][3][lx] | part[3][3][lx];
+    const unsigned long long c_lo = part[0][0][lx] | ((unsigned long long)part[0][1][lx] << 32);
+    const unsigned long long c_hi = part[0][2][lx] | ((unsigned long long)part[0][3][lx] << 32);
+    const unsigned long long b_lo = part[1][0][lx] | ((unsigned long long)part[1][1][lx] << 32);
+    const unsigned long long b_hi = part[1][2][lx] | ((unsigned long long)part[1][3][lx] << 32);
     for (int al = ly; al < KH_EDT_T; al += 4) {
       const int a = A0 + al;
       if (a >= n) break;
-      const int r0 = al + KH_EDT_H;  // my row in the tile
+      const int r0 = al + KH_EDT_H;  // my row in the tile (wave uniform)
       const int64_t i = base + (int64_t)a * astride;
       float best = 0.0f;
-      const bool bg = ((r0 < 64 ? b_lo >> r0 : b_hi >> (r0 - 64)) & 1ull) != 0;
-      if (!bg) {
-        const int c0 = r0 * 64 + lx;
-        best = tile[c0];
+      if (!bit128(b_lo, b_hi, r0)) {
+        const float* __restrict__ pc = &tile[r0 * 64 + lx];
+        best = pc[0];
         // same-label rows below / above inside the staged rows
         int nl = zeros_down(c_lo, c_hi, r0);
         int nr = zeros_up(c_lo, c_hi, r0 + 1);
         const bool lunk = nl > r0;                     // no change found down to the first staged row
         const bool runk = r0 + 1 + nr >= KH_EDT_ROWS;  // none up to the last staged row
-        if (lunk) nl = r0;
-        if (runk) nr = KH_EDT_ROWS - 1 - r0;
-        // segment ends known here: a differing voxel (always a candidate) or the volume border
-        if (!lunk && (a - nl - 1 >= 0 || black_border)) { const float d = w * (float)(nl + 1); const float tt = d * d; if (tt < best) best = tt; }
-        if (!runk && (a + nr + 1 < n || black_border)) { const float d = w * (float)(nr + 1); const float tt = d * d; if (tt < best) best = tt; }
-        const int k1 = max(nl, nr);
+        nl = min(nl, r0);
+        nr = min(nr, KH_EDT_ROWS - 1 - r0);
+        // a segment end that is known here is a candidate: a differing voxel, or the volume border when
+        // black_border.  (Rows outside the volume are staged as +inf, so probing them is harmless.)
+        const bool lc = !lunk && (a - nl - 1 >= 0 || black_border);
+        const bool rc = !runk && (a + nr + 1 < n || black_border);
+        const float tl = tsq[lc ? nl + 4 : 0], tr = tsq[rc ? nr + 4 : 0];   // tsq[0] = +inf, tsq[k+3] = (w*k)^2
+        best = fminf(best, fminf(tl, tr));
+        // Both sides are probed together for k <= kb.  A side that ended in a candidate needs nothing beyond
+        // its end: the candidate (w*(end+1))^2 already bounds everything farther away.  A side without one
+        // (volume border, or a run leaving the staged rows) is probed up to the edge of the staged rows.
+        const int kb = min(lc ? nl : r0, rc ? nr : KH_EDT_ROWS - 1 - r0);
         int k = 1;
         bool open = true;
-        // Search inside the staged rows.  Three phases: both sides valid (k <= min(nl,nr)), then only the
-        // longer side.  Groups of 4 steps: the probes are fetched with constant offsets from one base
-        // address before any is consumed, no clamps, no per-step branches; the bound (w*k)^2 >= best is
-        // tested once per group (a candidate whose (w*k)^2 exceeds `best` cannot lower it since f >= 0).
-        const float* __restrict__ pc = &tile[c0];
-        const int kb = min(min(nl, nr), k1);
+        // Groups of 4 steps: (w*k)^2 comes from the LDS table (one broadcast read per group), the 8 probes
+        // are fetched with constant offsets from one base address before any is consumed, no clamps, no
+        // per-step branches; the bound (w*k)^2 >= best is tested once per group (a candidate whose (w*k)^2
+        // exceeds `best` cannot lower it since f >= 0).
         for (; k + 3 <= kb; k += 4) {
-          const float d0 = w * (float)k;
-          if (d0 * d0 >= best) { open = false; break; }
+          const float4 t = *reinterpret_cast<const float4*>(&tsq[k + 3]);
+          if (t.x >= best) { open = false; break; }
           const float* __restrict__ pl = pc - k * 64;
           const float* __restrict__ pr = pc + k * 64;
           const float l0 = pl[0], l1 = pl[-64], l2 = pl[-128], l3 = pl[-192];
           const float r0v = pr[0], r1 = pr[64], r2 = pr[128], r3 = pr[192];
-          const float d1 = w * (float)(k + 1), d2 = w * (float)(k + 2), d3 = w * (float)(k + 3);
-          const float t0 = d0 * d0, t1 = d1 * d1, t2 = d2 * d2, t3 = d3 * d3;
-          best = fminf(best, fminf(l0 + t0, r0v + t0));
-          best = fminf(best, fminf(l1 + t1, r1 + t1));
-          best = fminf(best, fminf(l2 + t2, r2 + t2));
-          best = fminf(best, fminf(l3 + t3, r3 + t3));
+          best = fminf(best, fminf(l0 + t.x, r0v + t.x));
+          best = fminf(best, fminf(l1 + t.y, r1 + t.y));
+          best = fminf(best, fminf(l2 + t.z, r2 + t.z));
+          best = fminf(best, fminf(l3 + t.w, r3 + t.w));
         }
         for (; open && k <= kb; k++) {
-          const float d = w * (float)k;
-          const float tt = d * d;
+          const float tt = tsq[k + 3];
           if (tt >= best) { open = false; break; }
           best = fminf(best, fminf(pc[-k * 64] + tt, pc[k * 64] + tt));
         }
-        if (open && k1 > kb) {
-          // one side left; `sgn` selects it
-          const int sgn = nl > nr ? -64 : 64;
-          for (; k + 3 <= k1; k += 4) {
-            const float d0 = w * (float)k;
-            if (d0 * d0 >= best) { open = false; break; }
-            const float* __restrict__ pp = pc + k * sgn;
-            const float v0 = pp[0], v1 = pp[sgn], v2 = pp[2 * sgn], v3 = pp[3 * sgn];
-            const float d1 = w * (float)(k + 1), d2 = w * (float)(k + 2), d3 = w * (float)(k + 3);
-            best = fminf(best, fminf(v0 + d0 * d0, v1 + d1 * d1));
-            best = fminf(best, fminf(v2 + d2 * d2, v3 + d3 * d3));
-          }
-          for (; open && k <= k1; k++) {
-            const float d = w * (float)k;
-            const float tt = d * d;
-            if (tt >= best) { open = false; break; }
-            best = fminf(best, pc[k * sgn] + tt);
-          }
-        }
-        if (open && (lunk || runk)) {
-          // slow path: the run leaves the staged rows; keep walking on global memory, labels checked
+        if (open && !(lc && rc)) {
+          // rare: one side has no end inside the staged rows (objects wider than H voxels) or ends at the volume
+          // border.  Keep walking: staged rows first, then global memory with the labels checked.
           const LT L = lab[i];
           bool lo = lunk, ro = runk;
-          for (k = min(nl, nr) + 1; lo || ro; k++) {
+          for (;; k++) {
+            const bool lin = k <= nl, rin = k <= nr;
+            if (!(lin || rin || lo || ro)) break;
             const float d = w * (float)k;
             const float tt = d * d;
             if (tt >= best) break;
-            if (lo && k > nl) {
+            if (lin) best = fminf(best, pc[-k * 64] + tt);
+            else if (lo) {
               const int j = a - k;
               if (j < 0) { lo = false; if (black_border) best = tt; }
               else {
                 const int64_t q = base + (int64_t)j * astride;
                 if (lab[q] != L) { lo = false; best = tt; }
-                else { const float c = fin[q] + tt; if (c < best) best = c; }
+                else best = fminf(best, fin[q] + tt);
               }
             }
-            if (ro && k > nr) {
+            if (rin) best = fminf(best, pc[k * 64] + tt);
+            else if (ro) {
               const int j = a + k;
-              if (j >= n) { ro = false; if (black_border && tt < best) best = tt; }
+              if (j >= n) { ro = false; if (black_border) best = fminf(best, tt); }
               else {
                 const int64_t q = base + (int64_t)j * astride;
-                if (lab[q] != L) { ro = false; if (tt < best) best = tt; }
-                else { const float c = fin[q] + tt; if (c < best) best = c; }
+                if (lab[q] != L) { ro = false; best = fminf(best, tt); }
+                else best = fminf(best, fin[q] + tt);
               }
             }
           }
