@@ -103,8 +103,6 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
 //    voxels) continue in a slow path on global memory.
 // Every f element is fetched from L2/HBM (T+2H)/T = 2x instead of 2*window times.
 #define KH_EDT_T 64
-#define KH_EDT_H 32
-#define KH_EDT_ROWS (KH_EDT_T + 2 * KH_EDT_H)
 
 // 128-bit mask helpers; the bit position p is wave uniform (a row index), so the shifts are by scalars and
 // the two cases of each shift are scalar branches; the data dependent part is select-only.
@@ -128,17 +126,23 @@ __device__ __forceinline__ int zeros_up(unsigned long long lo, unsigned long lon
   const int nz = xl ? __ffsll((long long)xl) - 1 : 64 + (xh ? __ffsll((long long)xh) - 1 : 64);
   return min(nz, 128 - p);
 }
+// min of two floats that are known to be >= +0 (or +inf): the order of the bit patterns is the order of the values
+__device__ __forceinline__ float minpos(float a, float b) {
+  return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b)));
+}
 __device__ __forceinline__ bool bit128(unsigned long long lo, unsigned long long hi, int p) {
   return (((p < 64) ? (lo >> p) : (hi >> (p - 64))) & 1ull) != 0;
 }
 
-template <typename LT, bool LAST>
+template <typename LT, bool LAST, int KH_EDT_H>
 __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border) {
+  constexpr int KH_EDT_ROWS = KH_EDT_T + 2 * KH_EDT_H;  // staged rows: <= 128 (column masks), multiple of 4
+  static_assert(KH_EDT_ROWS <= 128 && KH_EDT_ROWS % 4 == 0 && KH_EDT_ROWS / 4 <= 32, "tile shape");
   __shared__ float tile[KH_EDT_ROWS * 64];
-  __shared__ unsigned int part[2][4][64];  // [label change | background][ly][lx]: 32 rows of a column mask each
-  __shared__ __attribute__((aligned(16))) float tsq[KH_EDT_ROWS + 8];  // [0] = +inf, [k+3] = (w*k)^2 for k >= 1
+  __shared__ unsigned int part[2][4][64];  // [label change | background][ly][lx]: ROWS/4 rows of a column mask each
+  __shared__ __attribute__((aligned(16))) float tsq[KH_EDT_ROWS + 8];  // [0] = +inf, [k+2] = (w*k)^2 for k >= 0
   // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride ; blockDim = (64, 4)
   const int xt = (sx + 63) >> 6, at = (n + KH_EDT_T - 1) / KH_EDT_T;
   const int64_t ntiles = (int64_t)xt * at * m;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
   // every row-index test and shift below into scalar code
   const int lx = threadIdx.x, ly = __builtin_amdgcn_readfirstlane(threadIdx.y);
   for (int k = threadIdx.y * 64 + threadIdx.x; k < KH_EDT_ROWS + 8; k += 256) {
-    const float d = w * (float)(k - 3);
+    const float d = w * (float)(k - 2);
     tsq[k] = k == 0 ? KH_INF : d * d;
   }
   for (int64_t t = logical; t < ntiles; t += stride) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
     const int64_t base = x + (int64_t)o * ostride;
     __syncthreads();  // previous tile fully consumed
     {
-      // thread (lx, ly) stages the 32 consecutive rows [32*ly, 32*ly+32): the label of the previous row
+      // thread (lx, ly) stages KH_EDT_ROWS / 4 consecutive rows: the label of the previous row
       // is the previous iteration's register, so labels are read once (+1 row per thread).
       const int rbeg = ly * (KH_EDT_ROWS / 4);
       const int pbeg = A0 - KH_EDT_H + rbeg;
@@ -189,15 +193,21 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
         bm |= (bg ? 1u : 0u) << j;
         Lp = L;
       }
-      part[0][ly][lx] = cm;  // rows [32*ly, 32*ly+32) of the column masks
+      part[0][ly][lx] = cm;
       part[1][ly][lx] = bm;
     }
     __syncthreads();
     if (x >= sx) continue;
-    const unsigned long long c_lo = part[0][0][lx] | ((unsigned long long)part[0][1][lx] << 32);
-    const unsigned long long c_hi = part[0][2][lx] | ((unsigned long long)part[0][3][lx] << 32);
-    const unsigned long long b_lo = part[1][0][lx] | ((unsigned long long)part[1][1][lx] << 32);
-    const unsigned long long b_hi = part[1][2][lx] | ((unsigned long long)part[1][3][lx] << 32);
+    // thread ly contributed rows [RPT*ly, RPT*ly + RPT) of the column masks
+    constexpr int RPT = KH_EDT_ROWS / 4;
+    unsigned __int128 cmask = 0, bmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      cmask |= (unsigned __int128)part[0][j][lx] << (j * RPT);
+      bmask |= (unsigned __int128)part[1][j][lx] << (j * RPT);
+    }
+    const unsigned long long c_lo = (unsigned long long)cmask, c_hi = (unsigned long long)(cmask >> 64);
+    const unsigned long long b_lo = (unsigned long long)bmask, b_hi = (unsigned long long)(bmask >> 64);
     for (int al = ly; al < KH_EDT_T; al += 4) {
       const int a = A0 + al;
       if (a >= n) break;
@@ -218,35 +228,44 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
         // black_border.  (Rows outside the volume are staged as +inf, so probing them is harmless.)
         const bool lc = !lunk && (a - nl - 1 >= 0 || black_border);
         const bool rc = !runk && (a + nr + 1 < n || black_border);
-        const float tl = tsq[lc ? nl + 4 : 0], tr = tsq[rc ? nr + 4 : 0];   // tsq[0] = +inf, tsq[k+3] = (w*k)^2
-        best = fminf(best, fminf(tl, tr));
+        const float tl = tsq[lc ? nl + 3 : 0], tr = tsq[rc ? nr + 3 : 0];   // tsq[0] = +inf, tsq[k+2] = (w*k)^2
+        best = minpos(best, minpos(tl, tr));
         // Both sides are probed together for k <= kb.  A side that ended in a candidate needs nothing beyond
         // its end: the candidate (w*(end+1))^2 already bounds everything farther away.  A side without one
         // (volume border, or a run leaving the staged rows) is probed up to the edge of the staged rows.
         const int kb = min(lc ? nl : r0, rc ? nr : KH_EDT_ROWS - 1 - r0);
-        int k = 1;
-        bool open = true;
-        // Groups of 4 steps: (w*k)^2 comes from the LDS table (one broadcast read per group), the 8 probes
-        // are fetched with constant offsets from one base address before any is consumed, no clamps, no
-        // per-step branches; the bound (w*k)^2 >= best is tested once per group (a candidate whose (w*k)^2
-        // exceeds `best` cannot lower it since f >= 0).
-        for (; k + 3 <= kb; k += 4) {
-          const float4 t = *reinterpret_cast<const float4*>(&tsq[k + 3]);
-          if (t.x >= best) { open = false; break; }
-          const float* __restrict__ pl = pc - k * 64;
-          const float* __restrict__ pr = pc + k * 64;
-          const float l0 = pl[0], l1 = pl[-64], l2 = pl[-128], l3 = pl[-192];
-          const float r0v = pr[0], r1 = pr[64], r2 = pr[128], r3 = pr[192];
-          best = fminf(best, fminf(l0 + t.x, r0v + t.x));
-          best = fminf(best, fminf(l1 + t.y, r1 + t.y));
-          best = fminf(best, fminf(l2 + t.z, r2 + t.z));
-          best = fminf(best, fminf(l3 + t.w, r3 + t.w));
+        // Groups of 4 steps, run as a wave-uniform loop (k is a scalar): a lane takes part while its next 4 rows
+        // are inside kb and (w*k)^2 < best.  (w*k)^2 comes from the LDS table (broadcast reads), the 8 probes are
+        // fetched with constant offsets from one base address before any is consumed, no clamps, no per-step
+        // branches.  A probe farther than the bound cannot lower `best` (f >= 0), so nothing has to be undone
+        // when the bound is crossed inside a group.  All values are >= +0, so min is taken on the bit patterns.
+        int kn = 1;  // first step this lane has not probed yet
+        float tx = tsq[3];  // (w*k)^2 of the group's first step; the next group's arrives with this group's reads
+        for (int k = 1;; k += 4) {
+          const bool can = (k + 3 <= kb) && (tx < best);  // once false it stays false
+          if (!__builtin_amdgcn_ballot_w64(can)) break;
+          if (can) {
+            const float4 t = *reinterpret_cast<const float4*>(&tsq[k + 3]);  // steps k+1, k+2, k+3 and k+4
+            const float* __restrict__ pl = pc - k * 64;
+            const float* __restrict__ pr = pc + k * 64;
+            const float l0 = pl[0], l1 = pl[-64], l2 = pl[-128], l3 = pl[-192];
+            const float r0v = pr[0], r1 = pr[64], r2 = pr[128], r3 = pr[192];
+            // min(l + t, r + t) == min(l, r) + t bit for bit (rounding is monotone): one add per step
+            best = minpos(best, minpos(minpos(l0, r0v) + tx, minpos(l1, r1) + t.x));
+            best = minpos(best, minpos(minpos(l2, r2) + t.y, minpos(l3, r3) + t.z));
+            tx = t.w;
+            kn = k + 4;
+          }
         }
-        for (; open && k <= kb; k++) {
-          const float tt = tsq[k + 3];
-          if (tt >= best) { open = false; break; }
-          best = fminf(best, fminf(pc[-k * 64] + tt, pc[k * 64] + tt));
+        // at most 3 steps are left below kb for a lane that was stopped by kb (a lane stopped by the bound gains
+        // nothing from them, and loses nothing)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int kq = kn + j;
+          if (kq <= kb) best = minpos(best, minpos(pc[-kq * 64], pc[kq * 64]) + tsq[kq + 2]);
         }
+        const bool open = tsq[kb + 3] < best;  // would step kb + 1 still be inside the bound?
+        int k = kb + 1;
         if (open && !(lc && rc)) {
           // rare: one side has no end inside the staged rows (objects wider than H voxels) or ends at the volume
           // border.  Keep walking: staged rows first, then global memory with the labels checked.
@@ -320,12 +339,15 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];
     float* fout = bufs[cur ^ 1];
-    if (last)
-      hipLaunchKernelGGL((edt_axis_kernel<LT, true>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
-                         astride, m, ostride, w, black_border);
-    else
-      hipLaunchKernelGGL((edt_axis_kernel<LT, false>), dim3((unsigned)grid), dim3(64, 4), 0, st, lab, fin, fout, (int)sx, n,
-                         astride, m, ostride, w, black_border);
+    // halo: a search needs k <= sqrt(best)/w rows either side, so the axis with the coarse voxel pitch gets the small halo
+    // (less re-reading); anything that does not fit continues on global memory, so this only affects speed
+    const float wmin = fminf(wx, fminf(wy, wz));
+    const bool small_halo = w >= 2.0f * wmin;
+#define KH_AXIS_LAUNCH(LASTV, HV) hipLaunchKernelGGL((edt_axis_kernel<LT, LASTV, HV>), dim3((unsigned)grid), dim3(64, 4), 0, st, \
+                                                     lab, fin, fout, (int)sx, n, astride, m, ostride, w, black_border)
+    if (last) { if (small_halo) KH_AXIS_LAUNCH(true, 8); else KH_AXIS_LAUNCH(true, 16); }
+    else { if (small_halo) KH_AXIS_LAUNCH(false, 8); else KH_AXIS_LAUNCH(false, 16); }
+#undef KH_AXIS_LAUNCH
     KH_LAUNCH_CHECK();
     cur ^= 1;
     return KH_OK;
