@@ -24,68 +24,98 @@
 
 namespace kh {
 
+// x pass: one wave per row, no workgroup barrier.  The wave reads the row once in 64-voxel chunks (the labels of
+// the first 8 chunks stay in registers), a ballot per chunk gives the "a run starts here" word, and every voxel
+// then finds the nearest run start on either side with clz / ctz on those words.
+#define KH_EDT_XCACHE 8
+template <typename LT>
+__device__ __forceinline__ float edt_x_voxel(const unsigned long long* words, int nwords, int x, int sx, float w,
+                                             int black_border) {
+  const int wi = x >> 6, bit = x & 63;
+  // left: highest flag position p <= x  (run starts at p, differing voxel at p-1)
+  int dl = -1;  // -1 = none
+  {
+    unsigned long long m = words[wi] & ((bit == 63) ? ~0ull : ((2ull << bit) - 1ull));
+    int k = wi;
+    while (m == 0 && k > 0) { k--; m = words[k]; }
+    if (m != 0) {
+      const int p = (k << 6) + (63 - __clzll((long long)m));
+      dl = x - p + 1;
+    } else if (black_border) dl = x + 1;
+  }
+  int dr = -1;
+  {
+    unsigned long long m = (bit == 63) ? 0ull : (words[wi] & ~((2ull << bit) - 1ull));
+    int k = wi;
+    while (m == 0 && k + 1 < nwords) { k++; m = words[k]; }
+    if (m != 0) {
+      const int q = (k << 6) + (__ffsll((long long)m) - 1);
+      dr = q - x;
+    } else if (black_border) dr = sx - x;
+  }
+  int d = dl;
+  if (d < 0 || (dr >= 0 && dr < d)) d = dr;
+  if (d < 0) return KH_INF;
+  const float dd = w * (float)d;
+  return dd * dd;
+}
+
 template <typename LT>
 __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, float* __restrict__ out,
                                                     int sx, int64_t nrows, float w, int black_border) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* words = reinterpret_cast<unsigned long long*>(smem);  // ceil(sx/64)+... per row
   const int nwords = (sx + 63) >> 6;
-  const int lane = threadIdx.x & 63;
-  // XCD-aware row assignment: XCD c (= blockIdx.x % 8) walks rows [c*chunk, (c+1)*chunk)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(smem) + wave * nwords;  // this wave's row
+  // XCD-aware row assignment: XCD c (= blockIdx.x % 8) walks a contiguous 1/8 of the rows; the 4 waves of a
+  // workgroup take 4 consecutive rows
   const int64_t nblk = gridDim.x;
   const int64_t per_xcd = (nblk + 7) / 8;
   const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t stride = per_xcd * 8;
-  for (int64_t row = logical; row < nrows; row += stride) {
+  for (int64_t row = logical * 4 + wave; row < nrows; row += stride * 4) {
     const LT* __restrict__ r = lab + row * sx;
     float* __restrict__ o = out + row * sx;
-    // 1. boundary flags -> LDS words
-    for (int x0 = 0; x0 < nwords * 64; x0 += 256) {
-      const int x = x0 + threadIdx.x;
-      bool flag = false;
-      if (x < sx && x > 0) flag = (r[x] != r[x - 1]);
-      const unsigned long long m = __ballot(flag);
-      if (lane == 0 && (x >> 6) < nwords) words[x >> 6] = m;
-    }
-    __syncthreads();
-    // 2. nearest label change on both sides
-    for (int x = threadIdx.x; x < sx; x += 256) {
-      const LT L = r[x];
-      float res = 0.0f;
-      if (L != 0) {
-        const int wi = x >> 6, bit = x & 63;
-        // left: highest flag position p <= x  (run starts at p, differing voxel at p-1)
-        int dl = -1;  // -1 = none
-        {
-          unsigned long long m = words[wi] & ((bit == 63) ? ~0ull : ((2ull << bit) - 1ull));
-          int k = wi;
-          while (m == 0 && k > 0) { k--; m = words[k]; }
-          if (m != 0) {
-            const int p = (k << 6) + (63 - __clzll((long long)m));
-            dl = x - p + 1;
-          } else if (black_border) dl = x + 1;
-        }
-        int dr = -1;
-        {
-          unsigned long long m = (bit == 63) ? 0ull : (words[wi] & ~((2ull << bit) - 1ull));
-          int k = wi;
-          while (m == 0 && k + 1 < nwords) { k++; m = words[k]; }
-          if (m != 0) {
-            const int q = (k << 6) + (__ffsll((long long)m) - 1);
-            dr = q - x;
-          } else if (black_border) dr = sx - x;
-        }
-        int d = dl;
-        if (d < 0 || (dr >= 0 && dr < d)) d = dr;
-        if (d < 0) res = KH_INF;
-        else {
-          const float dd = w * (float)d;
-          res = dd * dd;
-        }
+    // 1. boundary flags -> this wave's words
+    uint32_t cached[KH_EDT_XCACHE];
+    uint32_t prev_last = 0;  // label of the last voxel of the previous chunk
+#pragma unroll
+    for (int c = 0; c < KH_EDT_XCACHE; c++) {
+      if (c < nwords) {
+        const int x = (c << 6) + lane;
+        const uint32_t L = x < sx ? (uint32_t)r[x] : 0u;
+        uint32_t Lm = (uint32_t)__shfl_up((int)L, 1);
+        if (lane == 0) Lm = prev_last;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(x < sx && x > 0 && L != Lm);
+        if (lane == 0) words[c] = m;
+        prev_last = (uint32_t)__builtin_amdgcn_readlane((int)L, 63);
+        cached[c] = L;
       }
-      o[x] = res;
     }
-    __syncthreads();
+    for (int c = KH_EDT_XCACHE; c < nwords; c++) {
+      const int x = (c << 6) + lane;
+      const uint32_t L = x < sx ? (uint32_t)r[x] : 0u;
+      uint32_t Lm = (uint32_t)__shfl_up((int)L, 1);
+      if (lane == 0) Lm = prev_last;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(x < sx && x > 0 && L != Lm);
+      if (lane == 0) words[c] = m;
+      prev_last = (uint32_t)__builtin_amdgcn_readlane((int)L, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // 2. nearest label change on both sides
+#pragma unroll
+    for (int c = 0; c < KH_EDT_XCACHE; c++) {
+      if (c < nwords) {
+        const int x = (c << 6) + lane;
+        if (x < sx) o[x] = cached[c] != 0u ? edt_x_voxel<LT>(words, nwords, x, sx, w, black_border) : 0.0f;
+      }
+    }
+    for (int c = KH_EDT_XCACHE; c < nwords; c++) {
+      const int x = (c << 6) + lane;
+      if (x < sx) o[x] = r[x] != 0 ? edt_x_voxel<LT>(words, nwords, x, sx, w, black_border) : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();  // the words are rewritten by the next row
   }
 }
 
@@ -325,10 +355,11 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
   int cur = (npass % 2 == 1) ? 0 : 1;  // buffer the x pass writes
   {
     const int nwords = (int)((sx + 63) >> 6);
-    int64_t grid = nrows < 8192 ? nrows : 8192;
+    const int64_t need = (nrows + 3) / 4;  // 4 rows (one per wave) per workgroup and step
+    int64_t grid = need < 8192 ? need : 8192;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL((edt_x_kernel<LT>), dim3((unsigned)grid), dim3(256), nwords * 8, st, lab, bufs[cur],
+    hipLaunchKernelGGL((edt_x_kernel<LT>), dim3((unsigned)grid), dim3(256), 4 * nwords * 8, st, lab, bufs[cur],
                        (int)sx, nrows, wx, black_border);
     KH_LAUNCH_CHECK();
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[1], st));

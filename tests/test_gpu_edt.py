@@ -28,6 +28,8 @@ CASES = [
     ((200, 3, 2), 4, (3.7, 1.3, 2.2), np.uint32),     # non-integer anisotropy: still bit exact
     ((31, 1, 1), 3, (2, 2, 2), np.uint32),            # 1-D
     ((50, 60, 1), 6, (1, 2, 1), np.uint32),           # 2-D
+    ((90, 120, 40), 20, (2, 9, 3), np.uint32),        # coarse y: the small-halo kernel on a non-final pass
+    ((96, 150, 140), 2, (1, 1, 1), np.uint32),        # runs far longer than any halo: global-memory walk
 ]
 
 
