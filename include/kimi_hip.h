@@ -162,6 +162,9 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).
  * qstate as for kh_edf_batch.  heap_nodes: scratch for the invalidation heaps, 16 bytes per node
  * (16-byte aligned), each label owning nodes [heap_offset, heap_offset + heap_capacity).
+ * n_large: the first n_large tasks (put the biggest labels first) run with 8191 instead of 127 heap slots
+ * in LDS (128 KiB per workgroup, so one per CU: keep n_large <= the number of CUs); they are launched on an
+ * internal stream forked from / joined into `stream`, concurrently with the rest.  0 is always valid.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.                                                  */
@@ -172,8 +175,8 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
                    const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                    const uint32_t* manual_targets, float scale, float constant,
                    uint32_t* queues, void* heap_nodes,
-                   uint32_t* path_vertices, uint32_t* path_lengths, int flags, int fix_branching,
-                   void* stream);
+                   uint32_t* path_vertices, uint32_t* path_lengths, int n_large, int flags,
+                   int fix_branching, void* stream);
 
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);

@@ -80,7 +80,7 @@ def lib():
     L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp]
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
-                                 f32, f32, vp, vp, vp, vp, ci, ci, vp]
+                                 f32, f32, vp, vp, vp, vp, ci, ci, ci, vp]
     L.kh_fill_f32.argtypes = [vp, i64, f32, vp]
     L.kh_fill_u8.argtypes = [vp, i64, ci, vp]
     L.kh_gather_f32.argtypes = [vp, vp, i64, vp, vp]

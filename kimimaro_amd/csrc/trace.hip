@@ -320,13 +320,17 @@ typedef uint32_t hnode_t __attribute__((ext_vector_type(4)));
 // LDS pointers keep their address space in the type, so LDS and HBM accesses can never be merged into flat_* ones
 typedef __attribute__((address_space(3))) hnode_t lds_hnode_t;
 
-// Heap slots 0..KH_TOP-1 (the root and the first 6-level chunk under it) live in LDS and nowhere else; slots
-// >= KH_TOP live in the label's slice of HBM scratch.  Every pop starts in the LDS part, so the top read and
-// the first chunk cost an LDS round trip instead of an L2 one.
-#define KH_TOP 127
+// Heap slots 0..TOP-1 live in LDS and nowhere else; slots >= TOP live in the label's slice of HBM scratch.
+// TOPL = 1: the root and the first 6-level chunk under it (127 slots, 2 KiB) -- every label affords that.
+// TOPL = 2: two chunks (8191 slots, 128 KiB): one such workgroup fits on a CU, so it is reserved for the few
+// largest labels, whose sequential chain is the critical path of the whole launch.  Every pop starts in the
+// LDS part, so the top read and the first TOPL chunks cost LDS round trips instead of L2 ones.
+template <int TOPL_>
 struct Heap {
-  hnode_t* node;   // HBM scratch of this label (L2 resident in practice); slots < KH_TOP unused
-  lds_hnode_t* top;  // LDS, KH_TOP + 3 entries (the first chunk's lanes 62/63 read two slots past the end)
+  static constexpr int TOPL = TOPL_;
+  static constexpr uint32_t TOP = TOPL_ == 1 ? 127u : 8191u;
+  hnode_t* node;   // HBM scratch of this label (L2 resident in practice); slots < TOP unused
+  lds_hnode_t* top;  // LDS, TOP + 3 entries (the last LDS chunk's lanes 62/63 read two slots past the end)
   uint32_t cap, n;
   // per-lane constants of the 126-node speculative sub-tree (children of node m: 2m+2, 2m+3; parent of
   // m >= 2: (m-2)>>1).  Lane l holds node m = l ("slot 0", depths 1..6) and m = l+64 ("slot 1", depth 6).
@@ -341,7 +345,8 @@ __device__ __forceinline__ uint32_t sibling_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
+template <class H>
+__device__ __forceinline__ void heap_init_lane(H& h, int lane) {
   unsigned long long a0 = 0, a1 = 0;
   for (int m = lane; ; m = (m - 2) >> 1) { a0 |= 1ull << m; if (m < 2) break; }
   if (lane + 64 < 126) for (int m = (lane + 62) >> 1; ; m = (m - 2) >> 1) { a1 |= 1ull << m; if (m < 2) break; }
@@ -359,7 +364,8 @@ __device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
 // the climb length m (the ancestors with key >= k form a prefix because keys never decrease from parent
 // to child), lanes < m write their ancestor one generation down and lane m drops the new node into
 // generation m's slot.
-__device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
+template <class H>
+__device__ __forceinline__ bool heap_push_wave(H& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
   if (h.n >= h.cap) return false;
   const uint32_t pos = h.n++;
   const int sh = lane + 1 < 32 ? lane + 1 : 31;
@@ -367,11 +373,11 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t
   const bool valid = (lane < 31) && q >= 1u;
   const uint32_t ai = q - 1u;
   hnode_t a;
-  if (pos < KH_TOP) {                     // wave uniform: the whole chain is in LDS
+  if (pos < H::TOP) {                     // wave uniform: the whole chain is in LDS
     a = h.top[valid ? ai : 0u];
   } else {
-    const bool lo = !valid || ai < KH_TOP;
-    const hnode_t ag = h.node[lo ? KH_TOP : ai];
+    const bool lo = !valid || ai < H::TOP;
+    const hnode_t ag = h.node[lo ? H::TOP : ai];
     const hnode_t al = h.top[lo && valid ? ai : 0u];
     a = lo ? al : ag;
   }
@@ -381,7 +387,7 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t
   const hnode_t fresh = {kbits, vox, src, 0u};
   const hnode_t val = lane < m ? a : fresh;
   if (lane <= m) {
-    if (dest < KH_TOP) h.top[dest] = val;
+    if (dest < H::TOP) h.top[dest] = val;
     else h.node[dest] = val;
   }
   return true;
@@ -398,15 +404,15 @@ __device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t
 // to +inf): no divergent branches in the descent.  Chunk 0 is exactly the LDS part of the heap.
 // 32-bit index math is safe: the hole of chunk c sits at level 6c <= 24, so (hole+1) << 6 < 2^31.
 #define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
-template <int C>
-__device__ __forceinline__ void heap_pop_chunk(const Heap& h, uint32_t hole, uint32_t len, uint32_t vk, int lane,
+template <int C, class H>
+__device__ __forceinline__ void heap_pop_chunk(const H& h, uint32_t hole, uint32_t len, uint32_t vk, int lane,
                                                uint32_t& deepest, bool& found) {
   const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
   const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
   const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
   hnode_t n0, n1;
-  if constexpr (C == 0) { n0 = h.top[i0]; n1 = h.top[i1]; }   // i0 = lane + 1, i1 = lane + 65
-  else { n0 = h.node[e0 ? i0 : KH_TOP]; n1 = h.node[e1 ? i1 : KH_TOP]; }
+  if constexpr (C < H::TOPL) { n0 = h.top[i0]; n1 = h.top[i1]; }   // an LDS chunk: i0, i1 < TOP + 3 by construction
+  else { n0 = h.node[e0 ? i0 : H::TOP]; n1 = h.node[e1 ? i1 : H::TOP]; }
   const uint32_t k0 = e0 ? n0.x : INF_BITS, k1 = e1 ? n1.x : INF_BITS;
   // a node beats its sibling if it is the left one and left.key <= right.key, or the right one and
   // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
@@ -421,18 +427,18 @@ __device__ __forceinline__ void heap_pop_chunk(const Heap& h, uint32_t hole, uin
     uint32_t nh = 0;
     if (P1) nh = rdlane_u32(i1, __ffsll((long long)P1) - 1);
     else if (P0 >> 62) nh = rdlane_u32(i0, (P0 >> 63) ? 63 : 62);
-    if (nh != 0u && 2u * nh + 1u < len) heap_pop_chunk<C + 1>(h, nh, len, vk, lane, deepest, found);
+    if (nh != 0u && 2u * nh + 1u < len) heap_pop_chunk<C + 1, H>(h, nh, len, vk, lane, deepest, found);
   }
   // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
   // deepest such node (or the root).  Path keys are non-decreasing with depth.
   const bool mv0 = on0 && k0 < vk;
   const bool mv1 = on1 && k1 < vk;
   const uint32_t q0 = (i0 - 1u) >> 1, q1 = (i1 - 1u) >> 1;
-  if constexpr (C == 0) {
+  if constexpr (C < H::TOPL) {
     if (mv0) h.top[q0] = n0;
     if (mv1) h.top[q1] = n1;
-  } else if constexpr (C == 1) {
-    // the parent of this chunk's two depth-1 nodes (lanes 0, 1) is the hole: a depth-6 node of the LDS part
+  } else if constexpr (C == H::TOPL) {
+    // the parent of this chunk's two depth-1 nodes (lanes 0, 1) is the hole: a leaf of the LDS part
     if (mv0) { if (lane < 2) h.top[hole] = n0; else h.node[q0] = n0; }
     if (mv1) h.node[q1] = n1;
   } else {
@@ -446,26 +452,27 @@ __device__ __forceinline__ void heap_pop_chunk(const Heap& h, uint32_t hole, uin
   }
 }
 
-__device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
+template <class H>
+__device__ __forceinline__ void heap_pop_wave(H& h, int lane) {
   const uint32_t len = h.n - 1u;
   h.n = len;
   if (len == 0) return;
-  const hnode_t last = len < KH_TOP ? h.top[len] : h.node[len];  // consumed only after the descent
+  const hnode_t last = len < H::TOP ? h.top[len] : h.node[len];  // consumed only after the descent
   uint32_t deepest = 0;
   bool found = false;
-  if (len > 1u) heap_pop_chunk<0>(h, 0u, len, last.x, lane, deepest, found);
+  if (len > 1u) heap_pop_chunk<0, H>(h, 0u, len, last.x, lane, deepest, found);
   if (lane == 0) {
-    if (deepest < KH_TOP) h.top[deepest] = last;
+    if (deepest < H::TOP) h.top[deepest] = last;
     else h.node[deepest] = last;
   }
 }
 
 // wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
 // cycle split (s_memtime waits on the scalar memory counter, so the production kernel leaves it out).
-template <bool PROF>
+template <bool PROF, class H>
 __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
-                                    float scale, float constant, Heap& h, uint32_t* status, uint32_t* pushes,
+                                    float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3) {
   const int lane = threadIdx.x & 63;
   unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt = 0;
@@ -646,7 +653,7 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
   return n;
 }
 
-template <bool PROF>
+template <bool PROF, int TOPL>
 __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
                                                           uint32_t* path_vertices,
                                                           uint32_t* path_lengths, int fix_branching) {
   __shared__ Ctl ctl;
-  __shared__ hnode_t heap_top[KH_TOP + 3];
+  extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];  // (Heap<TOPL>::TOP + 3) nodes
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
-  Heap heap;
+  Heap<TOPL> heap;
   heap.node = heap_nodes + task->heap_offset;
   heap.top = (lds_hnode_t*)heap_top;
   heap.cap = task->heap_capacity;
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 0) {
-      const uint32_t c = invalidate_ball<PROF>(ctl.g, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+      const uint32_t c = invalidate_ball<PROF, Heap<TOPL>>(ctl.g, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
                                          heap, &ctl.status, &ctl.u3, ctl.cyc3);
       if (lane == 0) ctl.u1 = c;
     }
@@ -838,7 +845,7 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     t_rail += clock64() - t0; t0 = clock64();
     if (valid > 0) {
       if (wave == 0) {
-        const uint32_t c = invalidate_ball<PROF>(ctl.g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
+        const uint32_t c = invalidate_ball<PROF, Heap<TOPL>>(ctl.g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
                                            &ctl.u3, ctl.cyc3);
         if (lane == 0) ctl.u1 = c;
       }
@@ -941,11 +948,36 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
   return KH_OK;
 }
 
+namespace kh {
+template <bool PROF, int TOPL>
+static int launch_trace(int first, int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
+                        const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
+                        uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
+                        uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
+                        int fix_branching) {
+  if (count <= 0) return KH_OK;
+  const size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
+  if (TOPL > 1) {
+    static bool raised = false;  // more than 64 KiB of dynamic LDS has to be allowed once per kernel
+    if (!raised) {
+      KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, TOPL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((trace_paths_kernel<PROF, TOPL>), dim3(count), dim3(64), lds, st, tasks + first, lists, list_daf, nbrmask,
+                     g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
+                     path_lengths, fix_branching);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+}  // namespace kh
+
 extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                               const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                               const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
-                              void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths, int flags,
+                              void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths, int n_large, int flags,
                               int fix_branching, void* stream) {
   if (int rc = require_device()) return rc;
   if (ntasks <= 0) return KH_OK;
@@ -953,18 +985,38 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
+  if (n_large < 0 || n_large > ntasks) { set_error("kh_trace_paths: n_large out of range"); return KH_EINVAL; }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
-  if (flags & KH_TRACE_PROFILE)
-    hipLaunchKernelGGL(trace_paths_kernel<true>, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, tasks, lists, list_daf,
-                       nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues,
-                       (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching);
-  else
-    hipLaunchKernelGGL(trace_paths_kernel<false>, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, tasks, lists, list_daf,
-                       nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues,
-                       (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching);
-  KH_LAUNCH_CHECK();
-  return KH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = (flags & KH_TRACE_PROFILE) != 0;
+#define KH_TRACE_LAUNCH(PROFV, TOPLV, FIRST, COUNT, STREAM)                                                               \
+  launch_trace<PROFV, TOPLV>(FIRST, COUNT, STREAM, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate,    \
+                             manual_targets, scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths,  \
+                             fix_branching)
+  int rc = KH_OK;
+  if (n_large > 0) {
+    // the large-LDS workgroups (one per CU) and the ordinary ones have to be resident together: two launches on
+    // two streams, forked from and joined back into the caller's stream
+    static hipStream_t side = nullptr;
+    static hipEvent_t fork = nullptr, join = nullptr;
+    if (!side) {
+      KH_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      KH_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+      KH_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    }
+    KH_HIP_CHECK(hipEventRecord(fork, st));
+    KH_HIP_CHECK(hipStreamWaitEvent(side, fork, 0));
+    rc = prof ? KH_TRACE_LAUNCH(true, 2, 0, n_large, side) : KH_TRACE_LAUNCH(false, 2, 0, n_large, side);
+    if (rc == KH_OK) rc = prof ? KH_TRACE_LAUNCH(true, 1, n_large, ntasks - n_large, st)
+                               : KH_TRACE_LAUNCH(false, 1, n_large, ntasks - n_large, st);
+    KH_HIP_CHECK(hipEventRecord(join, side));
+    KH_HIP_CHECK(hipStreamWaitEvent(st, join, 0));
+  } else {
+    rc = prof ? KH_TRACE_LAUNCH(true, 1, 0, ntasks, st) : KH_TRACE_LAUNCH(false, 1, 0, ntasks, st);
+  }
+#undef KH_TRACE_LAUNCH
+  return rc;
 }
 
 extern "C" int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,

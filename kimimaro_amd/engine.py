@@ -33,6 +33,8 @@ class Engine:
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
+        self.large_heap_slots = 128         # labels that may run with the 128 KiB LDS heap top (<= CUs)
+        self.large_heap_min_voxels = 16384  # ... if they have at least this many voxels
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -253,11 +255,13 @@ class Engine:
         d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
-        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first
+        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; those whose
+        # heap gets deep enough to profit keep two chunks of it in LDS (one such workgroup per CU)
+        n_large = int(min(self.large_heap_slots, np.count_nonzero(cnt >= self.large_heap_min_voxels)))
         _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
                                       P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                       np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
-                                      P(d_pverts), P(d_plens), 1 if self.profile else 0,
+                                      P(d_pverts), P(d_plens), n_large, 1 if self.profile else 0,
                                       int(bool(fix_branching)), st))
         mark("paths")
         out_tasks = d_tasks.cpu().numpy().view(_abi.LABEL_T).copy()

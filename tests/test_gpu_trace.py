@@ -218,3 +218,27 @@ def test_skeletonize_fuzz_small_volumes(eng, seed):
         np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
         np.testing.assert_array_equal(got[k].edges, want[k].edges)
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+
+
+def test_skeletonize_large_lds_heap_variant():
+    """the biggest labels run with two heap chunks in LDS (kh_trace_paths n_large) on a second stream, next to the
+    ordinary workgroups: force that split on a volume whose heaps outgrow both LDS sizes."""
+    import kimimaro_amd
+    from kimimaro_amd.engine import Engine
+    from oracle import pipeline as P
+    eng2 = Engine()
+    eng2.large_heap_min_voxels = 1
+    eng2.large_heap_slots = 3
+    an = (16, 16, 40)
+    lab = voronoi_labels((96, 96, 40), 7, seed=5, pts_per_label=3, step=12.0, anisotropy=an)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True,
+                                   progress=False, _engine=eng2)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True)
+    import kimimaro_amd.engine as E
+    assert int(E.LAST_TASKS["stat_heap_pushes"].max()) > 20000   # deep heaps: both the LDS and the HBM part are used
+    assert sorted(got.keys()) == sorted(want.keys()) and len(got) >= 4
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
