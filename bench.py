@@ -20,6 +20,7 @@ Extra objects on the JSON line:
                 pass duration measured with HIP events on the launch stream (kh_edt_timed).
   roofline_trace  the per-label path kernel (where the wall clock goes): SURVEY 8d per-label bytes.
   cpu_baseline  the oracle (CPU restatement, 1 core) on a bounded sample of the same labels.
+  cpu_baseline_all_cores  the same work on a process pool over every host core (SURVEY 8d asks for both).
 """
 from __future__ import annotations
 
@@ -106,6 +107,27 @@ def cpu_baseline(cc_labels, remapping, an, params, dust_threshold, budget_s=15.0
     return {"value": done / dt, "unit": "labels/s", "cores": 1, "kind": "port",
             "sample": "%d of %d labels (%d voxels), EDT on bbox+1 and full trace per label, %.1f s of CPU, "
                       "seeded shuffle" % (done, len(segids), vox, dt)}
+
+
+def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate, budget_s=10.0, timeout_s=120.0):
+    """the same per-label work as cpu_baseline on every host core: oracle/cpu_pool_baseline.py in a child process
+    (forked worker pool over a read-only map of the component volume), under a hard timeout."""
+    import subprocess
+    import tempfile
+    if (os.cpu_count() or 1) < 2:
+        return None
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(tmpdir, "kimi_bench_cc_%d.npy" % os.getpid())
+    try:
+        np.save(path, cc_labels)
+        args = {"anisotropy": [float(a) for a in an], "params": params, "dust_threshold": int(dust_threshold),
+                "one_core_rate": float(one_core_rate), "budget_s": float(budget_s)}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_pool_baseline.py"), path, json.dumps(args)],
+                             capture_output=True, text=True, timeout=timeout_s, check=True)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
 
 
 def main():
@@ -280,9 +302,14 @@ def main():
                       "note": "latency bound: exact emulation of the reference's sequential heap flood per label"}
 
     cpu = None
+    cpu_all = None
     if not args.no_cpu_baseline and world == 1:
         try:
             cpu = cpu_baseline(cc_labels, remapping, an, params, dust)
+            try:
+                cpu_all = cpu_baseline_all_cores(cc_labels, an, params, dust, cpu["value"])
+            except Exception as e:
+                cpu_all = {"value": None, "unit": "labels/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         except Exception as e:  # the baseline must never take the bench line down
             cpu = {"value": None, "unit": "labels/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
 
@@ -298,6 +325,7 @@ def main():
                    "parallelism": "labels round-robin over %d GPU(s), skeleton all-gather-v" % world},
         "skeletons": nskel, "preamble_s": round(preamble_s, 3), "phases_s": phases,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
+        "cpu_baseline_all_cores": cpu_all,
     }
     print(json.dumps(line))
     if dist:
