@@ -205,7 +205,15 @@ int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_
              uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents,
              void* stream);
 
-/* ---- the same on HOST memory (used for the 2-D faces of fix_borders and as a cross-check),
+/* ---- f3: binary hole filling, replaces fill_voids.fill(img, in_place=True, return_fill_count=True) as
+ * called at kimimaro/trace.py:109 (third-party, source absent): a background voxel (mask == 0) stays
+ * background iff a 6-connected background path joins it to a face of the array.  mask/out: u8 [nvox]
+ * (out may not alias mask); parent: u32 [nvox] scratch; open: u8 [nvox] scratch; *filled (device i64) =
+ * number of voxels that changed.                                                                    */
+int kh_fill_voids(const uint8_t* mask, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint8_t* open,
+                  uint8_t* out, int64_t* filled, void* stream);
+
+/* ---- kh_ccl26 on HOST memory (used for the 2-D faces of fix_borders and as a cross-check),
  * restating cc3d.connected_components as called at kimimaro/utility.py:74-77.
  * Returns the number of components (ids 1..N by first appearance in F-order raster).   */
 int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,

@@ -89,6 +89,19 @@ class Engine:
         rep = d_rep[: ncomp + 1].cpu().numpy().view(np.uint32)
         return d_cc, ncomp, rep
 
+    def fill_voids(self, d_mask, shape):
+        """kh_fill_voids (fill_voids.fill, kimimaro/trace.py:109) on a u8 mask resident in HBM.
+        Returns (filled u8 mask on the device, number of voxels that changed)."""
+        t = self.torch
+        n = int(shape[0]) * int(shape[1]) * int(shape[2])
+        d_parent = self.empty(n, t.int32)
+        d_open = self.empty(n, t.uint8)
+        d_out = self.empty(n, t.uint8)
+        d_cnt = self.empty(1, t.int64)
+        _abi.check(self.lib.kh_fill_voids(self.ptr(d_mask), shape[0], shape[1], shape[2], self.ptr(d_parent), self.ptr(d_open),
+                                          self.ptr(d_out), self.ptr(d_cnt), self.stream()))
+        return d_out, int(d_cnt.cpu().numpy()[0])
+
     def to_host_volume(self, d, shape, dtype=np.uint32):
         return d.cpu().numpy().view(dtype).reshape(shape, order="F")
 

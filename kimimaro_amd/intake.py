@@ -284,16 +284,18 @@ def _trace_soma_labels(eng, jobs, d_cc, d_dbf, shape, anisotropy, remapping, par
 def _needs_soma_path(eng, d_cc, shape, box, segid, dbf_max, params):
     """kimimaro/trace.py:108-119 for a label whose DBF max exceeds soma_detection_threshold: does it take the
     soma branch?  True if the DBF max is already above soma_acceptance_threshold, or if the label has
-    internal voids (fill_voids.fill would change it and its DBF).  The void test is a host stand-in
-    (scipy.ndimage.binary_fill_holes on the label's crop, 6-connected background like fill_voids) until the GPU
-    flood fill lands (row f3).  A label without voids below the acceptance threshold continues unchanged in
-    the reference, so it stays in the shared-volume batch."""
-    import scipy.ndimage
+    internal voids (fill_voids.fill would change it and its DBF; kh_fill_voids on the label's crop).  A label
+    without voids below the acceptance threshold continues unchanged in the reference, so it stays in the
+    shared-volume batch."""
     if dbf_max > params["soma_acceptance_threshold"]:
         return True
-    crop = eng.crop(d_cc, shape, box[0], box[1]) == segid
-    filled = scipy.ndimage.binary_fill_holes(crop)
-    return bool(np.count_nonzero(filled) != np.count_nonzero(crop))
+    t = eng.torch
+    lo, hi = box
+    cshape = (hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2])
+    v = d_cc.view(shape[2], shape[1], shape[0])[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+    d_mask = (v == int(segid)).to(t.uint8).contiguous().view(-1)   # torch C order (z, y, x) == F order (x, y, z)
+    _, nfilled = eng.fill_voids(d_mask, cshape)
+    return nfilled > 0
 
 
 def paths_of(res, slot, shape):

@@ -36,12 +36,11 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     dmax = np.float32(dbf_max[1])
     soma_mode = False
     if dmax > soma_detection_threshold:  # kimimaro/trace.py:108-119
-        # fill_voids.fill stand-in (row f3: host scipy, 6-connected background) + crop re-EDT on the GPU
-        import scipy.ndimage
-        filled = scipy.ndimage.binary_fill_holes(cc != 0)
-        if int(np.count_nonzero(filled)) > int(counts[1]):
-            cc = np.asfortranarray(filled.astype(np.uint32))
-            d_cc = eng.to_device(cc)
+        # fill_voids.fill (kh_fill_voids, row f3) + crop re-EDT, both on the GPU
+        d_filled, nfilled = eng.fill_voids((d_cc != 0).to(eng.torch.uint8), shape)
+        if nfilled > 0:
+            d_cc = d_filled.to(eng.torch.int32)
+            cc = eng.to_host_volume(d_cc, shape)
             d_dbf = eng.edt(d_cc, 4, shape, anisotropy, bool(np.all(cc)))
             dbf = d_dbf.cpu().numpy().reshape(shape, order="F")
             counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, 4, d_dbf, shape, 1)

@@ -58,3 +58,25 @@ def test_faces_and_point_lookup(eng):
         np.testing.assert_array_equal(a, b)
     assert lv[(5, 6, 3)] == vol[5, 6, 3]
     np.testing.assert_array_equal(lv.host(), vol)
+
+
+@pytest.mark.parametrize("shape,seed", [((40, 36, 30), 0), ((65, 20, 9), 1), ((33, 47, 1), 2), ((1, 50, 40), 3), ((70, 70, 70), 4)])
+def test_fill_voids_matches_binary_fill_holes(eng, shape, seed):
+    """kh_fill_voids (row f3) against scipy.ndimage.binary_fill_holes: closed voids of every size are filled, voids
+    open to a face of the array and diagonal-only leaks (6-connected background) are handled alike."""
+    import scipy.ndimage
+    import torch
+    rng = np.random.default_rng(seed)
+    m = rng.random(shape) < 0.62                      # porous: many small voids, many leaks
+    c = [s // 2 for s in shape]
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), axis=-1)
+    r = np.sqrt(((g - c) ** 2).sum(-1))
+    R = max(2, min(shape) // 2 - 2)
+    m |= (r <= R) & (r >= R - 1.5)                    # a shell with a big closed void (if the array is thick enough)
+    m = np.asfortranarray(m)
+    want = scipy.ndimage.binary_fill_holes(m)
+    d = torch.from_numpy(m.reshape(-1, order="F").astype(np.uint8)).cuda()
+    d_out, n = eng.fill_voids(d, shape)
+    got = d_out.cpu().numpy().reshape(shape, order="F").astype(bool)
+    np.testing.assert_array_equal(got, want)
+    assert n == int(want.sum() - m.sum())
