@@ -148,11 +148,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
+    # KIMI_BENCH_BACKEND=gloo is a dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
+    # share devices and the skeleton exchange goes through host tensors); the measured configuration is nccl (= RCCL)
+    backend = os.environ.get("KIMI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import kimimaro_amd
     from kimimaro_amd import _abi, intake
@@ -207,7 +215,7 @@ def main():
         local = intake.skeletonize_cc(eng, cc, nlabels, remapping, params, an, dust, True, fix_borders,
                                       empty, empty, black_border=False, rank=rank, world=world, d_cc=d_cc)
         if world > 1:
-            local = gather_skeletons(local, device=eng.device)
+            local = gather_skeletons(local, device=eng.device if backend == "nccl" else None)
         result["skels"] = local
         return local
 
@@ -224,7 +232,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     nskel = len(result["skels"])
