@@ -5,21 +5,18 @@
 // oracle/kimi_oracle.c:ko_edt which this file matches bit for bit).
 //
 // MI355X-first design (not the CPU's sequential parabolic-envelope stack):
-//   * x pass: one wave ballot per 64 voxels turns "label changes here" into a bit mask
-//     staged in LDS; every voxel finds its nearest label change on either side with
-//     clz/ctz on those words -- O(1) per voxel, one coalesced read of the labels, one
-//     coalesced write of the squared distance.
-//   * y and z pass: one thread per voxel, lanes along x (so every access of the pass is a
-//     coalesced 256-B row segment).  Each voxel searches outward along the axis,
-//     best = min(best, f[j] + (w*k)^2), and stops as soon as (w*k)^2 >= best or the
-//     same-label segment ends.  The search window is ~sqrt(best)/w voxels, i.e. the local
-//     object radius: thin neurites close it in a handful of steps, and re-reads hit L1/L2
-//     (the +-k rows are shared by the 4 neighbouring rows handled by the same workgroup).
-//     The minimum is exact over the float expressions, no envelope intersections, no
-//     sequential dependency between voxels.
+//   * x pass: one wave per row; a ballot per 64 voxels turns "a run starts here" into a bit mask, every voxel
+//     finds its nearest label change on either side with clz/ctz on those words -- O(1) per voxel, one
+//     coalesced read of the labels, one coalesced write of the squared distance.
+//   * y and z pass: lanes along x (every access of the pass is a coalesced 256-B row segment), a tile of rows
+//     staged in LDS together with per-column run masks, and an exact window search per voxel:
+//     best = min(best, f[j] + (w*k)^2) walking outward until (w*k)^2 >= best or the same-label segment ends.
+//     The window is ~sqrt(best)/w voxels, i.e. the local object radius.  The minimum is exact over the float
+//     expressions, no envelope intersections, no sequential dependency between voxels.
 //   * block -> tile mapping is XCD aware: the 8 XCDs (block b runs on XCD b % 8) each get a
 //     contiguous 1/8 of the volume so the rows a block re-reads live in its own L2.
-// Memory bound: algorithmic bytes = L + 4 (x pass) and L + 8 (y, z pass) per voxel.
+// Algorithmic bytes = L + 4 (x pass) and L + 8 (y, z pass) per voxel; measured HBM traffic matches them, the
+// y / z passes are bound by instruction issue.
 #include "common.h"
 
 namespace kh {

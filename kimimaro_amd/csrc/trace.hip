@@ -9,20 +9,21 @@
 //                     rail edits      trace.py:220, 261-263
 //
 // Search = label-correcting relaxation with a near/far split (delta-stepping with an adaptive
-// threshold): work items are (frontier voxel, direction) pairs spread over the 256 lanes, distances
-// are float bit patterns updated with atomicMin, new frontier entries are (dist,voxel) pairs appended
-// with LDS counters (hipcc folds the per-lane atomicAdd into one per wave), stale entries are
-// recognised by dist[v] != entry.dist.  The distances converge to the unique Bellman fixpoint
-// d[v] = min_u fl(d[u] + w), so they equal the oracle's heap Dijkstra bit for bit regardless of the
-// relaxation order; paths are then recovered with the canonical predecessor rule of
-// oracle/kimi_oracle.c (ko_pred), 26 lanes looking at the 26 neighbours at once.
+// threshold): work items are (frontier voxel, direction) pairs spread over the lanes, distances are
+// float bit patterns updated with atomicMin, the work lists hold voxel indices only (membership bits in
+// `qstate` keep every list bounded by the label size).  The distances converge to the unique Bellman
+// fixpoint d[v] = min_u fl(d[u] + w), so they equal the oracle's heap Dijkstra bit for bit regardless of
+// the relaxation order; paths are then recovered with the canonical predecessor rule of
+// oracle/kimi_oracle.c (ko_pred / ko_walk), 26 lanes looking at the 26 neighbours at once.
 //
 // The invalidation flood is order dependent down to the tie order of
-// std::priority_queue, so it is run as an exact emulation of the libstdc++ binary heap by one lane,
-// with the 26 neighbour tests of each popped voxel evaluated by 26 lanes.
+// std::priority_queue, so it is run as an exact emulation of the libstdc++ binary heap in which the 64
+// lanes of the label's wave cooperate on every push and pop (see "The invalidation heap" below), with
+// the 26 neighbour tests of each popped voxel evaluated by 26 lanes.
 //
 // No MFMA: irregular, latency/atomic bound integer+f32 work (north_star).  Labels are independent, so
-// the chip is filled by running every label's workgroup concurrently (8 workgroups per CU).
+// the chip is filled by running every label's workgroup concurrently; the largest labels keep two
+// chunks of their heap in LDS (kh_trace_paths n_large).
 #include "common.h"
 
 namespace kh {
