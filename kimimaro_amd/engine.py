@@ -33,6 +33,7 @@ class Engine:
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
+        self._side = None     # second stream for the large-LDS workgroups when results are consumed incrementally
         self.large_heap_slots = 128         # labels that may run with the 128 KiB LDS heap top (<= CUs)
         self.large_heap_min_voxels = 16384  # ... if they have at least this many voxels
 
@@ -155,12 +156,13 @@ class Engine:
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
                    xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,
-                   return_fields=False, timings=None, soma=None):
+                   return_fields=False, timings=None, soma=None, consume=None):
         """Run find_root -> DAF -> PDRF -> path loop for the connected components `segids`.
 
         segids/counts/...: host arrays indexed by position (same order).  roots: array of linear indices or
         NONE32.  targets_before/after: list (per label) of lists of linear indices (LIFO stacks as in
-        kimimaro/trace.py:225-228).  Returns a dict with per-label path arrays.
+        kimimaro/trace.py:225-228).  Returns a dict with per-label path arrays -- or, when `consume` is given,
+        hands such dicts (one per group of labels, as the groups finish) to `consume` and returns None.
         """
         t = self.torch
         lib = self.lib
@@ -271,39 +273,69 @@ class Engine:
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; those whose
         # heap gets deep enough to profit keep two chunks of it in LDS (one such workgroup per CU)
         n_large = int(min(self.large_heap_slots, np.count_nonzero(cnt >= self.large_heap_min_voxels)))
-        _abi.check(lib.kh_trace_paths(P(d_tasks), nl, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
-                                      P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
-                                      np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
-                                      P(d_pverts), P(d_plens), n_large, 1 if self.profile else 0,
-                                      int(bool(fix_branching)), st))
-        mark("paths")
-        out_tasks = d_tasks.cpu().numpy().view(_abi.LABEL_T).copy()
+        prof = 1 if self.profile else 0
+
+        def launch(first, count, nbig, stream):
+            tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
+            _abi.check(lib.kh_trace_paths(tasks_ptr, count, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
+                                          P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
+                                          np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
+                                          P(d_pverts), P(d_plens), nbig, prof, int(bool(fix_branching)), stream))
+
+        def collect(lo, hi):
+            """results of task slots [lo, hi) (device -> host on the current stream)."""
+            isz = _abi.LABEL_T.itemsize
+            part = d_tasks[lo * isz:hi * isz].cpu().numpy().view(_abi.LABEL_T).copy()
+            bad = np.flatnonzero(part["status"])
+            if bad.size:
+                s = int(bad[0])
+                raise _abi.KimiHipError("label %d (cc id): %s" % (int(part["segid"][s]),
+                                                                   _abi.describe_status(int(part["status"][s]))))
+            # gather the used part of the path buffers: build a flat index on the host (small), gather on device
+            nverts = part["n_vertices"].astype(np.int64)
+            npaths = part["n_paths"].astype(np.int64)
+            vidx = np.concatenate([p_off[lo + s] + np.arange(nverts[s]) for s in range(hi - lo)] + [np.zeros(0, np.int64)])
+            lidx = np.concatenate([p_off[lo + s] + np.arange(npaths[s]) for s in range(hi - lo)] + [np.zeros(0, np.int64)])
+            d_vidx = t.from_numpy(vidx).to(self.device)
+            d_lidx = t.from_numpy(lidx).to(self.device)
+            verts_dev = d_pverts[d_vidx]
+            verts = verts_dev.cpu().numpy().view(np.uint32)
+            lens = d_plens[d_lidx].cpu().numpy().view(np.uint32)
+            d_radii = self.empty(max(verts.size, 1), t.float32)
+            if verts.size:
+                _abi.check(lib.kh_gather_f32(P(d_dbf), P(verts_dev.contiguous()), verts.size, P(d_radii), self.stream()))
+            radii = d_radii.cpu().numpy()[: verts.size]
+            return {"order": order[lo:hi], "tasks": part, "verts": verts, "radii": radii, "lens": lens,
+                    "voff": np.concatenate([[0], np.cumsum(nverts)]), "loff": np.concatenate([[0], np.cumsum(npaths)])}
+
         global LAST_TASKS
-        LAST_TASKS = out_tasks
-        bad = np.flatnonzero(out_tasks["status"])
-        if bad.size:
-            s = int(bad[0])
-            raise _abi.KimiHipError("label %d (cc id): %s" % (int(out_tasks["segid"][s]),
-                                                               _abi.describe_status(int(out_tasks["status"][s]))))
-        # gather the used part of the path buffers: build a flat index on the host (small), gather on device
-        nverts = out_tasks["n_vertices"].astype(np.int64)
-        npaths = out_tasks["n_paths"].astype(np.int64)
-        vidx = np.concatenate([p_off[s] + np.arange(nverts[s]) for s in range(nl)] + [np.zeros(0, np.int64)])
-        lidx = np.concatenate([p_off[s] + np.arange(npaths[s]) for s in range(nl)] + [np.zeros(0, np.int64)])
-        d_vidx = t.from_numpy(vidx).to(self.device)
-        d_lidx = t.from_numpy(lidx).to(self.device)
-        verts_dev = d_pverts[d_vidx]
-        verts = verts_dev.cpu().numpy().view(np.uint32)
-        lens = d_plens[d_lidx].cpu().numpy().view(np.uint32)
-        d_radii = self.empty(max(verts.size, 1), t.float32)
-        if verts.size:
-            _abi.check(lib.kh_gather_f32(P(d_dbf), P(verts_dev.contiguous()), verts.size, P(d_radii), st))
-        radii = d_radii.cpu().numpy()[: verts.size]
+        if consume is not None and 0 < n_large < nl:
+            # The largest labels are the tail of the run.  They go to a second stream (as large-LDS workgroups); the
+            # rest runs on the caller's stream and its results are copied back and handed to `consume` (the Skeleton
+            # assembly on the host) while the big labels are still being traced.
+            cur = t.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = t.cuda.Stream(device=self.device)
+            self._side.wait_stream(cur)
+            launch(0, n_large, n_large, C.c_void_p(self._side.cuda_stream))
+            launch(n_large, nl - n_large, 0, st)
+            small = collect(n_large, nl)
+            consume(small)                      # overlaps the big labels' kernel: no device-wide sync in here
+            cur.wait_stream(self._side)
+            big = collect(0, n_large)
+            mark("paths")
+            consume(big)
+            mark("d2h")
+            LAST_TASKS = np.concatenate([big["tasks"], small["tasks"]])
+            return None
+        launch(0, nl, n_large, st)
+        mark("paths")
+        res = collect(0, nl)
+        LAST_TASKS = res["tasks"]
         mark("d2h")
-        voff = np.concatenate([[0], np.cumsum(nverts)])
-        loff = np.concatenate([[0], np.cumsum(npaths)])
-        res = {"order": order, "tasks": out_tasks, "verts": verts, "radii": radii, "lens": lens,
-               "voff": voff, "loff": loff}
+        if consume is not None:
+            consume(res)
+            return None
         if return_fields:
             res["daf"] = d_field.cpu().numpy()
             res["pdrf"] = d_pdrf.cpu().numpy()

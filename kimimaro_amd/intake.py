@@ -240,11 +240,12 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
         ta.append(mta)
 
     sel = np.asarray(segids, dtype=np.int64)
-    res = eng.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],
+    asm = Assembler(shape, anisotropy, remapping)
+    eng.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],
                          dbf_max[sel] if len(sel) else [], first_index[sel] if len(sel) else [],
                          xmin[sel] if len(sel) else [], xmax[sel] if len(sel) else [], roots, tb, ta, params,
-                         fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings)
-    out = assemble(res, shape, anisotropy, remapping)
+                         fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings, consume=asm.add)
+    out = asm.finish()
     _mark("assemble")
     if soma_jobs:
         _trace_soma_labels(eng, soma_jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out)
@@ -336,26 +337,65 @@ def consolidate_paths(locs, lens, radii, shape):
     return verts, edges, radii[first]
 
 
+class Assembler:
+    """Skeleton assembly: kimimaro/trace.py:182-192 + intake.py:506-517, 587-593.  Results arrive in groups of
+    labels (Engine.run_labels hands them over as the groups finish on the GPU): `add` builds the per-component
+    skeletons, `finish` merges the components of every original label."""
+
+    def __init__(self, shape, anisotropy, remapping):
+        self.shape = shape
+        self.remapping = remapping
+        self.an = np.asarray(anisotropy, dtype=np.float32)
+        an = self.an
+        self.transform = np.array([[an[0], 0, 0, 0], [0, an[1], 0, 0], [0, 0, an[2], 0]], dtype=np.float32)
+        self.skeletons = defaultdict(list)
+
+    def add(self, res):
+        tasks = res["tasks"]
+        for slot in range(len(tasks)):
+            v0, v1 = res["voff"][slot], res["voff"][slot + 1]
+            if v1 == v0:
+                continue
+            locs = res["verts"][v0:v1].astype(np.int64)
+            lens = res["lens"][res["loff"][slot]:res["loff"][slot + 1]].astype(np.int64)
+            verts, edges, radii = consolidate_paths(locs, lens, res["radii"][v0:v1], self.shape)
+            if edges.shape[0] == 0:                      # Skeleton.empty(), intake.py:506
+                continue
+            orig = self.remapping[int(tasks["segid"][slot])]
+            self.skeletons[orig].append((int(tasks["segid"][slot]), verts, edges, radii))
+
+    def _skeleton(self, orig, verts, edges, radii):
+        return Skeleton(np.multiply(verts, self.an, dtype=np.float32), edges, radii=radii, segid=orig,  # intake.py:513
+                        transform=self.transform, space="physical")
+
+    def finish(self):
+        """one Skeleton per original label.  The components of a label are disjoint voxel sets, so
+        Skeleton.simple_merge(...).consolidate() (intake.py:587-593) is a concatenation re-sorted lexicographically by
+        vertex: done on integer keys here (same result as np.unique(vertices, axis=0) + edge remap, much cheaper)."""
+        sx, sy, sz = self.shape
+        merged = {}
+        for orig, parts in self.skeletons.items():
+            if len(parts) == 1:
+                _, verts, edges, radii = parts[0]
+                merged[orig] = self._skeleton(orig, verts, edges, radii)
+                continue
+            parts = sorted(parts, key=lambda p: p[0])        # component order of intake.py:444
+            verts = np.concatenate([p[1] for p in parts])
+            radii = np.concatenate([p[3] for p in parts])
+            offs = np.cumsum([0] + [p[1].shape[0] for p in parts[:-1]])
+            edges = np.concatenate([p[2].astype(np.int64) + o for p, o in zip(parts, offs)])
+            v = verts.astype(np.int64)
+            order = np.argsort((v[:, 0] * sy + v[:, 1]) * sz + v[:, 2], kind="stable")
+            rank = np.empty(order.size, dtype=np.int64)
+            rank[order] = np.arange(order.size)
+            e = rank[edges]
+            e.sort(axis=1)
+            e = e[np.argsort(e[:, 0] * order.size + e[:, 1], kind="stable")]
+            merged[orig] = self._skeleton(orig, verts[order], e.astype(np.uint32), radii[order])
+        return merged
+
+
 def assemble(res, shape, anisotropy, remapping):
-    """Skeleton assembly: kimimaro/trace.py:182-192 + intake.py:506-517, 587-593."""
-    tasks = res["tasks"]
-    skeletons = defaultdict(list)
-    an = np.asarray(anisotropy, dtype=np.float32)
-    transform = np.array([[an[0], 0, 0, 0], [0, an[1], 0, 0], [0, 0, an[2], 0]], dtype=np.float32)
-    for slot in range(len(tasks)):
-        v0, v1 = res["voff"][slot], res["voff"][slot + 1]
-        if v1 == v0:
-            continue
-        locs = res["verts"][v0:v1].astype(np.int64)
-        lens = res["lens"][res["loff"][slot]:res["loff"][slot + 1]].astype(np.int64)
-        verts, edges, radii = consolidate_paths(locs, lens, res["radii"][v0:v1], shape)
-        if edges.shape[0] == 0:                      # Skeleton.empty(), intake.py:506
-            continue
-        orig = remapping[int(tasks["segid"][slot])]
-        skel = Skeleton(np.multiply(verts, an, dtype=np.float32), edges, radii=radii, segid=orig,  # intake.py:513
-                        transform=transform, space="physical")
-        skeletons[orig].append(skel)
-    merged = {}
-    for segid, skels in skeletons.items():
-        merged[segid] = skels[0] if len(skels) == 1 else Skeleton.simple_merge(skels).consolidate()
-    return merged
+    asm = Assembler(shape, anisotropy, remapping)
+    asm.add(res)
+    return asm.finish()

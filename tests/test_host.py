@@ -70,3 +70,39 @@ def test_defaults_match_reference():
         "scale": 1.5, "const": 300, "pdrf_scale": 100000, "pdrf_exponent": 4, "soma_acceptance_threshold": 3500,
         "soma_detection_threshold": 750, "soma_invalidation_const": 300, "soma_invalidation_scale": 2}
     assert TRACE_DEFAULTS["scale"] == 10 and TRACE_DEFAULTS["pdrf_exponent"] == 16 and TRACE_DEFAULTS["max_paths"] is None
+
+
+def test_assembler_merge_equals_simple_merge_consolidate():
+    """Assembler.finish merges the (disjoint) components of a label on integer keys; it must equal
+    Skeleton.simple_merge(components).consolidate() (kimimaro/intake.py:587-593)."""
+    from kimimaro_amd.intake import Assembler, consolidate_paths
+    from kimimaro_amd.skeleton import Skeleton
+    rng = np.random.default_rng(3)
+    shape = (40, 30, 20)
+    an = (16.0, 16.0, 40.0)
+    asm = Assembler(shape, an, {1: 77, 2: 77, 3: 77, 4: 5})
+    ref = {77: [], 5: []}
+    used = set()
+    for comp, orig in ((3, 77), (1, 77), (2, 77), (4, 5)):          # arrival order != component order
+        # a random walk of distinct voxels (one path) + a second path starting on the first (shared vertex)
+        locs = []
+        while len(locs) < 30:
+            l = int(rng.integers(0, np.prod(shape)))
+            if l not in used:
+                used.add(l)
+                locs.append(l)
+        path2 = [locs[7]] + locs[20:]
+        allv = np.array(locs[:20] + path2, dtype=np.int64)
+        lens = np.array([20, len(path2)], dtype=np.int64)
+        radii = rng.random(allv.size).astype(np.float32)
+        radii[20] = radii[7]
+        verts, edges, r = consolidate_paths(allv, lens, radii, shape)
+        asm.skeletons[orig].append((comp, verts, edges, r))
+        ref[orig].append((comp, Skeleton(np.multiply(verts, np.float32(an), dtype=np.float32), edges, radii=r, segid=orig)))
+    got = asm.finish()
+    for orig, parts in ref.items():
+        want = Skeleton.simple_merge([s for _, s in sorted(parts, key=lambda p: p[0])]).consolidate()
+        np.testing.assert_array_equal(got[orig].vertices, want.vertices)
+        np.testing.assert_array_equal(got[orig].edges, want.edges)
+        np.testing.assert_array_equal(got[orig].radii, want.radii)
+        assert got[orig].id == orig and got[orig].space == "physical"
