@@ -11,6 +11,7 @@ its own workgroup (kimimaro/intake.py:434-517 runs them one after the other on c
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -318,10 +319,14 @@ class Engine:
                 self._side = t.cuda.Stream(device=self.device)
             self._side.wait_stream(cur)
             launch(0, n_large, n_large, C.c_void_p(self._side.cuda_stream))
-            launch(n_large, nl - n_large, 0, st)
-            small = collect(n_large, nl)
-            consume(small)                      # overlaps the big labels' kernel: no device-wide sync in here
-            cur.wait_stream(self._side)
+            try:
+                launch(n_large, nl - n_large, 0, st)
+                small = collect(n_large, nl)
+                consume(small)                  # overlaps the big labels' kernel: no device-wide sync in here
+            finally:
+                cur.wait_stream(self._side)     # the scratch of this call must outlive the side stream's kernel
+                if sys.exc_info()[0] is not None:
+                    self._side.synchronize()
             big = collect(0, n_large)
             mark("paths")
             consume(big)
