@@ -153,8 +153,8 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     one process drives one GPU; multi-GPU runs shard the connected components round robin over the
     ranks of torch.distributed (see kimimaro_amd.distributed).
     """
-    if fill_holes or fix_avocados or voxel_graph is not None:
-        raise NotImplementedError("fill_holes / fix_avocados / voxel_graph: optional pre-passes outside the "
+    if fix_avocados or voxel_graph is not None:
+        raise NotImplementedError("fix_avocados / voxel_graph: optional pre-passes outside the "
                                   "MI355X hot-path scope (SURVEY.md section 8, rows out of scope)")
     eng = _engine or Engine()  # raises HipUnavailableError without a GPU: no CPU fallback
     anisotropy = np.array(anisotropy, dtype=np.float32)
@@ -168,6 +168,8 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
         return {}
 
     d_cc, nlabels, remapping = compute_cc_labels_device(eng, all_labels)  # row f1 on the GPU
+    if fill_holes:
+        fill_all_holes_device(eng, d_cc, all_labels.shape, nlabels)              # intake.py:168-169
     cc = LazyVolume(eng, d_cc, all_labels.shape)
     before = _points_to_labels(extra_targets_before, cc)
     after = _points_to_labels(extra_targets_after, cc)
@@ -175,6 +177,38 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     return skeletonize_cc(eng, cc, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                           fix_branching, fix_borders, before, after, black_border=(minlabel == maxlabel),
                           timings=_timings, d_cc=d_cc)
+
+
+def fill_all_holes_device(eng, d_cc, shape, nlabels):
+    """kimimaro/intake.py:747-795 on the component volume resident in HBM (modified in place): the holes of every
+    component are filled with kh_fill_voids on the component's bounding box, in ascending label order; a component
+    that gets swallowed is not processed itself any more.  Bounding boxes are those before any filling, as in the
+    reference (find_objects is called once, intake.py:767).  Returns the number of voxels filled."""
+    t = eng.torch
+    nvox = int(shape[0]) * int(shape[1]) * int(shape[2])
+    counts, _, _, xmin, xmax = eng.label_stats(d_cc, 4, t.zeros(nvox, dtype=t.float32, device=eng.device), shape, nlabels)
+    yz = eng.last_yz_extent
+    in_set = np.ones(nlabels + 1, dtype=bool)
+    in_set[0] = False
+    v = d_cc.view(shape[2], shape[1], shape[0])      # torch C order (z, y, x) == F order (x, y, z)
+    filled_total = 0
+    for label in range(1, nlabels + 1):
+        if not in_set[label] or counts[label] == 0:
+            continue
+        lo = (int(xmin[label]), int(yz[label, 0]), int(yz[label, 2]))
+        hi = (int(xmax[label]) + 1, int(yz[label, 1]) + 1, int(yz[label, 3]) + 1)
+        cshape = (hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2])
+        sub = v[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+        d_filled, n = eng.fill_voids((sub == label).to(t.uint8).contiguous().view(-1), cshape)
+        if n == 0:
+            continue
+        filled_total += n
+        fb = d_filled.view(cshape[2], cshape[1], cshape[0]).bool()
+        for other in t.unique(sub[fb]).cpu().numpy():
+            if other != label and other > 0:
+                in_set[int(other)] = False
+        sub[fb] = label
+    return filled_total
 
 
 def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,

@@ -8,7 +8,8 @@ labels -- is checked against an independently structured implementation.
 
 Not restated (rows f2/f3 of SURVEY.md section 8 are handled where noted):
 soma mode is restated with a fill_voids stand-in (scipy.ndimage.binary_fill_holes) and a documented
-guess of dijkstra3d's free_space_radius (source absent); voxel_graph, fill_holes, fix_avocados raise
+guess of dijkstra3d's free_space_radius (source absent); fill_holes is restated with the same stand-in;
+voxel_graph and fix_avocados raise
 NotImplementedError.
 """
 from __future__ import annotations
@@ -240,14 +241,38 @@ def find_objects(cc_labels):
     return [(s and s[::-1]) for s in all_slices]
 
 
+def fill_all_holes(cc_labels):
+    """kimimaro/intake.py:747-795: fill the holes of every component (fill_voids.fill stand-in:
+    scipy.ndimage.binary_fill_holes, 6-connected background) in ascending label order; a component that gets
+    swallowed is not processed itself any more.  Bounding boxes are those of the labels before any filling."""
+    import scipy.ndimage
+    labels_set = set(int(l) for l in np.unique(cc_labels))
+    labels_set.discard(0)
+    all_slices = find_objects(cc_labels)
+    for label in sorted(labels_set.copy()):
+        if label not in labels_set:
+            continue
+        slices = all_slices[label - 1]
+        if slices is None:
+            continue
+        binary = scipy.ndimage.binary_fill_holes(cc_labels[slices] == label)
+        if int(binary.sum()) == int((cc_labels[slices] == label).sum()):
+            continue
+        sub = set(int(l) for l in np.unique(cc_labels[slices] * binary))
+        sub.discard(label)
+        labels_set -= sub
+        cc_labels[slices] = cc_labels[slices] * ~binary + label * binary
+    return cc_labels
+
+
 def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 1, 1),
                 object_ids=None, dust_threshold=1000, progress=False, fix_branching=True,
                 in_place=False, fix_borders=True, parallel=1, parallel_chunk_size=100,
                 extra_targets_before=[], extra_targets_after=[], fill_holes=False,
                 fix_avocados=False, voxel_graph=None, stats=None):
     """kimimaro/intake.py:58-221 + skeletonize_subset :434-517 (serial path)."""
-    if fill_holes or fix_avocados or voxel_graph is not None:
-        raise NotImplementedError("fill_holes / fix_avocados / voxel_graph are out of the restated scope")
+    if fix_avocados or voxel_graph is not None:
+        raise NotImplementedError("fix_avocados / voxel_graph are out of the restated scope")
     anisotropy = np.array(anisotropy, dtype=np.float32)
     all_labels = format_labels(all_labels)
     if object_ids is not None:
@@ -258,6 +283,8 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     if minlabel == 0 and maxlabel == 0:
         return {}
     cc_labels, remapping = compute_cc_labels(all_labels)
+    if fill_holes:
+        cc_labels = fill_all_holes(cc_labels)                                    # intake.py:168-169
 
     before = _points_to_labels(extra_targets_before, cc_labels)
     after = _points_to_labels(extra_targets_after, cc_labels)

@@ -242,3 +242,31 @@ def test_skeletonize_large_lds_heap_variant():
         np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
         np.testing.assert_array_equal(got[k].edges, want[k].edges)
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+
+
+def test_skeletonize_fill_holes(eng):
+    """fill_holes=True (kimimaro/intake.py:168-169, 747-795): a label enclosed by another one is swallowed, a
+    background void is filled, a cavity open to the face of the volume is not."""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    shape = (48, 44, 40)
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), axis=-1).astype(np.float64)
+    lab = np.zeros(shape, dtype=np.uint32)
+    lab[np.linalg.norm(g - (16, 20, 20), axis=-1) < 13] = 7      # a ball ...
+    lab[np.linalg.norm(g - (16, 20, 20), axis=-1) < 5] = 9       # ... with another label inside
+    lab[np.linalg.norm(g - (18, 28, 22), axis=-1) < 2.5] = 0     # ... and a background void
+    lab[np.linalg.norm(g - (36, 20, 20), axis=-1) < 9] = 11      # a second ball
+    lab[34:39, 18:23, 0:21] = 0                                  # with a tunnel open to the z = 0 face
+    lab = np.asfortranarray(lab)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 4
+    kw = dict(anisotropy=(1, 1, 1), dust_threshold=50, fix_borders=False, fill_holes=True)
+    got = kimimaro_amd.skeletonize(lab, params, progress=False, _engine=eng, **kw)
+    want = P.skeletonize(lab, params, **kw)
+    plain = P.skeletonize(lab, params, anisotropy=(1, 1, 1), dust_threshold=50, fix_borders=False)
+    assert sorted(want.keys()) == [7, 11] and 9 in plain            # label 9 was swallowed
+    assert sorted(got.keys()) == sorted(want.keys())
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
