@@ -269,9 +269,9 @@ def main():
     names = ["edt_x_kernel<uint32>", "edt_axis_kernel<uint32> (y pass)", "edt_axis_kernel<uint32> (z pass)"]
     achieved = pass_bytes[k] / (pass_ms[k] * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs, gfx950 x2 FETCH correction calibrated on the x pass): profiles/r01b_c3_edt_pmc.json.  Only valid for c3.
+    # runs, gfx950 x2 FETCH correction calibrated on the x pass): profiles/r01c_c3_edt_pmc.json.  Only valid for c3.
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01b_c3_edt_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r01c_c3_edt_pmc.json")
     if args.workload == "c3" and os.path.exists(pmc):
         kern = json.load(open(pmc))["kernels"]
         tag = ["edt_x_kernel", "edt_axis_kernel<unsigned int, false", "edt_axis_kernel<unsigned int, true"][k]
@@ -280,7 +280,7 @@ def main():
             traffic = hit[0]["hbm_bytes_corrected"]
     roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01b_c3_edt_pmc.json (PMC pass, not live)" if traffic else None,
+                "traffic_source": "profiles/r01c_c3_edt_pmc.json (PMC pass, not live)" if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
