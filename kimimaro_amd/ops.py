@@ -4,12 +4,10 @@ read like the reference's own tests (automated_test.py).  numpy in, numpy out; e
 runs the HIP kernel(s) through the C ABI, and downloads."""
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 
 from . import _abi
-from .engine import Engine, NONE32
+from .engine import Engine
 
 _engine = None
 

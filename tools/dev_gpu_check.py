@@ -9,7 +9,6 @@ import kimimaro_amd
 from shapes import voronoi_labels
 
 eng = Engine()
-import os
 eng.profile = bool(int(os.environ.get("KH_PROFILE", "0")))
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 if which == "c2":
