@@ -270,3 +270,43 @@ def test_skeletonize_fill_holes(eng):
         np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
         np.testing.assert_array_equal(got[k].edges, want[k].edges)
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.uint64, np.int64])
+def test_skeletonize_label_dtypes_and_object_ids(eng, dtype):
+    """the public mirror takes the label dtypes kimimaro takes (kimimaro/intake.py:315-342, utility.py:58-83) and
+    object_ids (intake.py:519-535); the skeletons are keyed by the original ids."""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    an = (4, 4, 10)
+    base = voronoi_labels((48, 40, 24), 9, seed=21, pts_per_label=3, step=8.0, anisotropy=an)   # ids 1000..1008
+    lab = np.asfortranarray((base - 1000 + 3).astype(dtype))                                     # ids 3..11
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 10
+    kw = dict(anisotropy=an, dust_threshold=50, fix_borders=True, object_ids=[3, 5, 6, 11])
+    got = kimimaro_amd.skeletonize(lab, params, progress=False, _engine=eng, **kw)
+    want = P.skeletonize(lab, params, **kw)
+    assert sorted(got.keys()) == sorted(want.keys()) and set(got.keys()) <= {3, 5, 6, 11} and len(got) >= 3
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+
+
+def test_skeletonize_2d_bool_with_extra_targets(eng):
+    """2-D boolean input (format_labels adds the third axis) and extra_targets_before / after (intake.py:497-504)."""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    m = random_walk_tube((90, 70, 1), 5, steps=40, step=4.0, radius=(2.0, 4.0))[:, :, 0].astype(bool)
+    pts = np.argwhere(m)
+    before = [tuple(int(v) for v in pts[len(pts) // 3]) + (0,)]
+    after = [tuple(int(v) for v in pts[2 * len(pts) // 3]) + (0,)]
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 3
+    kw = dict(anisotropy=(1, 1, 1), dust_threshold=10, fix_borders=False, extra_targets_before=before,
+              extra_targets_after=after)
+    got = kimimaro_amd.skeletonize(m, params, progress=False, _engine=eng, **kw)
+    want = P.skeletonize(m, params, **kw)
+    assert sorted(got.keys()) == sorted(want.keys()) == [1]
+    np.testing.assert_array_equal(got[1].vertices, want[1].vertices)
+    np.testing.assert_array_equal(got[1].edges, want[1].edges)
