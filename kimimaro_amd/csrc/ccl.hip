@@ -64,12 +64,17 @@ __global__ __launch_bounds__(256) void ccl_link_kernel(const LT* __restrict__ la
     const int64_t i = x + (int64_t)sx * y + sxy * z;
     const LT L = lab[i];
     if (L == 0) continue;
-    // the 13 neighbours that precede i in the raster: (-1,0,0), (*, -1, 0), (*, *, -1)
+    // the 13 neighbours that precede i in the raster: (-1,0,0), (*, -1, 0), (*, *, -1).  If the left neighbour has
+    // the same label it links every preceding neighbour with dx <= 0 itself (they are among ITS 13), so only the
+    // dx = +1 column is left for this voxel: 5 unions instead of 13 inside an object.
+    const bool left = x > 0 && lab[i - 1] == L;
+    if (left) ccl_union(parent, (uint32_t)i, (uint32_t)(i - 1));
 #pragma unroll
-    for (int k = 0; k < 13; k++) {
-      const int dx = (k == 0) ? -1 : ((k - 1) % 3) - 1;
-      const int dy = (k == 0) ? 0 : (k < 4 ? -1 : ((k - 4) / 3) - 1);
+    for (int k = 1; k < 13; k++) {
+      const int dx = ((k - 1) % 3) - 1;
+      const int dy = k < 4 ? -1 : ((k - 4) / 3) - 1;
       const int dz = (k < 4) ? 0 : -1;
+      if (left && dx <= 0) continue;
       const int nx = x + dx, ny = y + dy, nz = z + dz;
       if (nx < 0 || nx >= sx || ny < 0 || ny >= sy || nz < 0) continue;
       const int64_t j = i + dx + (int64_t)sx * dy + sxy * dz;
