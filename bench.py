@@ -9,6 +9,11 @@ targets -> find_root -> DAF -> PDRF -> TEASAR path loop for every component -> D
 Skeleton assembly -> (N > 1) all-gather-v of the skeletons.  Only format_labels and the H2D copy of the
 input are outside the timed region (`preamble_s`).
 
+N > 1 (default --scaling weak): every rank holds and skeletonizes its own volume of the workload's size (rank 0's
+volume is broadcast once, rank r mirrors it along the axes given by the bits of r and offsets the label ids), value =
+components of all N volumes / max-over-ranks step time.  --scaling strong shards the components of ONE volume round robin
+over the ranks (BASELINE.json configs[3]); its wall clock is bounded by the largest component, see DESIGN.md section 6.
+
 Workload (config.workload): "c3" = 512x512x512, 2124 chains, anisotropy (16,16,40), default
 teasar_params, dust_threshold=1000, fix_borders=True, fix_branching=True  (BASELINE.json configs[2],
 the configuration the metric is quoted on).  "c2" = 512x512x100 / 333 labels (configs[1]).
@@ -138,6 +143,10 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("KIMI_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-borders", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("KIMI_BENCH_SCALING", "weak"),
+                    help="N > 1: weak = every GPU skeletonizes its own volume of the workload's size (a mirrored copy "
+                         "with its own label ids; total work grows with N); strong = ONE volume, its components dealt "
+                         "round robin over the GPUs (BASELINE.json configs[3]; bounded by the largest component)")
     args = ap.parse_args()
 
     import torch
@@ -185,8 +194,16 @@ def main():
         except Exception as e:  # pragma: no cover
             print("bench: broadcast of the volume failed (%r); generating locally" % (e,), file=sys.stderr)
             lab, an = make_volume(args.workload)
+        if args.scaling == "weak":
+            # one volume per GPU: rank r works on the copy mirrored along the axes given by the bits of r (same object
+            # statistics, same largest component, different geometry) with label ids of its own, so that the gathered
+            # result holds the skeletons of all N volumes.  No component is shared between ranks.
+            flips = [a for a in range(3) if (rank >> a) & 1]
+            lab = np.asfortranarray(np.flip(lab, axis=flips)) if flips else lab
+            lab = np.where(lab != 0, lab + np.uint32(1000000 * rank), 0).astype(np.uint32, order="F")
     else:
         lab, an = make_volume(args.workload)
+    shard_rank, shard_world = (rank, world) if args.scaling == "strong" else (0, 1)
     shape = lab.shape
     an = np.asarray(an, dtype=np.float32)
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
@@ -213,7 +230,7 @@ def main():
         d_cc, nlabels, remapping = components()
         cc = intake.LazyVolume(eng, d_cc, shape)
         local = intake.skeletonize_cc(eng, cc, nlabels, remapping, params, an, dust, True, fix_borders,
-                                      empty, empty, black_border=False, rank=rank, world=world, d_cc=d_cc)
+                                      empty, empty, black_border=False, rank=shard_rank, world=shard_world, d_cc=d_cc)
         if world > 1:
             local = gather_skeletons(local, device=eng.device if backend == "nccl" else None)
         result["skels"] = local
@@ -241,7 +258,8 @@ def main():
     counts = np.bincount(cc_labels.ravel(order="K"))
     ncomp = int((counts[1:] > dust).sum())
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
-    value = ncomp / (ms_per_step / 1e3)
+    units = ncomp * (world if args.scaling == "weak" else 1)   # weak: every rank has a volume with the same component count
+    value = units / (ms_per_step / 1e3)
 
     if rank != 0:
         if dist:
@@ -326,13 +344,15 @@ def main():
     line = {
         "metric": "labels/sec on a dense connectomics-shaped volume (skeletonize hot path, labels resident in HBM)",
         "value": round(value, 3), "unit": "labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "
                                "default teasar_params, fix_branching=True, fix_borders=%s, dust_threshold=%d"
                                % (args.workload, shape[0], shape[1], shape[2], WORKLOADS[args.workload][1], ncomp,
                                   tuple(float(a) for a in an), fix_borders, dust),
-                   "parallelism": "labels round-robin over %d GPU(s), skeleton all-gather-v" % world},
+                   "parallelism": ("one such volume per GPU (mirrored copies, own label ids) on %d GPU(s), no data-path "
+                                   "collective, skeleton all-gather-v at the end" % world) if args.scaling == "weak" else
+                                  ("components of ONE volume round-robin over %d GPU(s), skeleton all-gather-v" % world)},
         "skeletons": nskel, "preamble_s": round(preamble_s, 3), "phases_s": phases,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
