@@ -30,6 +30,7 @@ CASES = [
     ((50, 60, 1), 6, (1, 2, 1), np.uint32),           # 2-D
     ((90, 120, 40), 20, (2, 9, 3), np.uint32),        # coarse y: the small-halo kernel on a non-final pass
     ((96, 150, 140), 2, (1, 1, 1), np.uint32),        # runs far longer than any halo: global-memory walk
+    ((1100, 7, 3), 9, (2, 3, 5), np.uint16),          # rows longer than the x pass keeps in registers (8 x 64 voxels)
 ]
 
 
