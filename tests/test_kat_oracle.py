@@ -137,3 +137,20 @@ def test_joinability():  # :281-333: with fix_borders two overlapping chunks sha
         vb = {tuple(v[1:]) for v in sb[1].vertices[sb[1].vertices[:, 0] == 0].tolist()}
         if va and vb:
             assert va & vb
+
+
+def test_fill_all_holes_swallows_enclosed_components():
+    """oracle restatement of kimimaro/intake.py:747-795: an enclosed component and a background void are filled with
+    the enclosing label, a cavity open to the array face is not, later labels that were swallowed are skipped."""
+    from oracle import pipeline as P
+    cc = np.zeros((20, 20, 20), dtype=np.uint32, order="F")
+    cc[2:18, 2:18, 2:18] = 1
+    cc[6:10, 6:10, 6:10] = 2          # enclosed component
+    cc[12:14, 12:14, 12:14] = 0       # enclosed background void
+    cc[8:10, 8:10, 0:5] = 0           # tunnel to the z = 0 face (and beyond label 1's box: stays open)
+    cc[0:2, 0:2, 0:2] = 3             # separate small component
+    out = P.fill_all_holes(cc.copy(order="F"))
+    assert set(np.unique(out)) == {0, 1, 3}
+    assert (out[6:10, 6:10, 6:10] == 1).all() and (out[12:14, 12:14, 12:14] == 1).all()
+    assert (out[8:10, 8:10, 0:2] == 0).all()
+    assert (out[0:2, 0:2, 0:2] == 3).all()
