@@ -220,15 +220,17 @@ def test_skeletonize_fuzz_small_volumes(eng, seed):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
-def test_skeletonize_large_lds_heap_variant():
+@pytest.mark.parametrize("slots", [3, 128])
+def test_skeletonize_large_lds_heap_variant(slots):
     """the biggest labels run with two heap chunks in LDS (kh_trace_paths n_large) on a second stream, next to the
-    ordinary workgroups: force that split on a volume whose heaps outgrow both LDS sizes."""
+    ordinary workgroups: force that split (3 of 7 labels) and the all-large case on a volume whose heaps outgrow
+    both LDS sizes."""
     import kimimaro_amd
     from kimimaro_amd.engine import Engine
     from oracle import pipeline as P
     eng2 = Engine()
     eng2.large_heap_min_voxels = 1
-    eng2.large_heap_slots = 3
+    eng2.large_heap_slots = slots
     an = (16, 16, 40)
     lab = voronoi_labels((96, 96, 40), 7, seed=5, pts_per_label=3, step=12.0, anisotropy=an)
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
