@@ -540,11 +540,46 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
     unsigned long long m = ballot64(want);
     if (PROF) { c_fire += clock64() - tt; tt = clock64(); }
     const uint32_t ndb = __float_as_uint(nd);
+    // The pushes of one fired voxel go to consecutive leaves, in direction order.  About three quarters of them do
+    // not climb (measured: 76 % on the largest label of the bench volume): such a push writes its own leaf and
+    // nothing else, and whether it climbs depends on its parent only.  So every pending lane looks at the parent
+    // of the leaf it would get, the leading run of non-climbing pushes is appended with one store per lane, the
+    // first climbing one goes through the ordinary push, and the rest is looked at again (its parents may have
+    // changed).  A new leaf is nobody's parent here because the heap is larger than the batch.
     while (m) {
-      const int k = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      if (!heap_push_wave(h, rdlane_u32(ndb, k), rdlane_u32(q, k), si, lane)) ovf = true;
-      npush++;
+      const uint32_t base = h.n;
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      if (base < 64u || base + cnt > h.cap) {   // small heap (new leaves could be parents) or no room: one by one
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (!heap_push_wave(h, rdlane_u32(ndb, k), rdlane_u32(q, k), si, lane)) ovf = true;
+        npush++;
+        continue;
+      }
+      const bool mine = (m >> lane) & 1ull;
+      const uint32_t leaf = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t par = (leaf - 1u) >> 1;
+      const bool plo = !mine || par < H::TOP;
+      const uint32_t kg = h.node[plo ? H::TOP : par].x;
+      const uint32_t kl = h.top[plo && mine ? par : 0u].x;
+      const bool stay = mine && (plo ? kl : kg) < ndb;          // __push_heap climbs while parent.key >= key
+      const unsigned long long climbers = m & ~ballot64(stay);
+      const int c = climbers ? __ffsll((long long)climbers) - 1 : 64;   // first lane whose push climbs
+      const unsigned long long run = c < 64 ? (m & ((1ull << c) - 1ull)) : m;
+      if ((run >> lane) & 1ull) {
+        const hnode_t fresh = {ndb, q, si, 0u};
+        if (leaf < H::TOP) h.top[leaf] = fresh;
+        else h.node[leaf] = fresh;
+      }
+      const uint32_t nrun = (uint32_t)__popcll(run);
+      h.n = base + nrun;
+      npush += nrun;
+      m &= ~run;
+      if (c < 64) {
+        m &= ~(1ull << c);
+        if (!heap_push_wave(h, rdlane_u32(ndb, c), rdlane_u32(q, c), si, lane)) ovf = true;
+        npush++;
+      }
     }
     if (PROF) c_push += clock64() - tt;
   }
