@@ -49,4 +49,5 @@ if tk is not None:
     print("worst label: count", tk["count"][i], "paths", tk["n_paths"][i], "kcyc", tk["cyc_target"][i], tk["cyc_rail"][i], tk["cyc_inval"][i], "pushes", tk["stat_heap_pushes"][i], "settled", tk["stat_settled"][i])
     print("kcyc pop/push/fire sums:", tk["cyc_pop"].astype(np.int64).sum(), tk["cyc_push"].astype(np.int64).sum(), tk["cyc_fire"].astype(np.int64).sum())
     print("worst label kcyc pop/push/fire:", tk["cyc_pop"][i], tk["cyc_push"][i], tk["cyc_fire"][i])
+    print("pushes of the 128 largest labels (large-LDS kernel):", tk["stat_heap_pushes"][:128].astype(np.int64).sum())
     print("pushes total", tk["stat_heap_pushes"].astype(np.int64).sum(), "settled total", tk["stat_settled"].astype(np.int64).sum(), "paths", tk["n_paths"].sum())
