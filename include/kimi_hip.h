@@ -124,6 +124,17 @@ typedef struct kh_label_t {
   float soma_radius;     /* dbf_max * soma_invalidation_scale + soma_invalidation_const (float32, trace.py:127) */
   float soma_scale;      /* soma_invalidation_scale */
   float soma_const;      /* soma_invalidation_const */
+  /* order-free invalidation sweep (csrc/sweep.h); nlev == 0 switches it off for the label */
+  uint32_t nlev;         /* in: number of distinct keys below the label's largest ball radius (levels it can touch) */
+  float sweep_rmax;      /* in: a call whose largest radius exceeds this uses the heap emulation */
+  uint32_t ev_offset;    /* in: start of its event arena, in units of 256 bytes */
+  uint32_t ev_chunks;    /* in: event chunks in its arena */
+  uint32_t ev_shift;     /* in: log2(slots per chunk), 4..7 (8 bytes per slot, slot 0 links the level's chunks) */
+  uint32_t stat_sweep_calls;  /* out: invalidation calls tried by the sweep */
+  uint32_t stat_sweep_bails;  /* out: ... of which fell back to the heap emulation */
+  uint32_t stat_sweep_levels; /* out: levels processed */
+  uint32_t stat_sweep_events; /* out: events processed (low 32 bits) */
+  uint32_t stat_sweep_why;    /* out: OR of the bail reasons (sweep.h SW_BAIL_*) */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
@@ -162,21 +173,31 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).
  * qstate as for kh_edf_batch.  heap_nodes: scratch for the invalidation heaps, 16 bytes per node
  * (16-byte aligned), each label owning nodes [heap_offset, heap_offset + heap_capacity).
- * n_large: the first n_large tasks (put the biggest labels first) run with 8191 instead of 127 heap slots
- * in LDS (128 KiB per workgroup, so one per CU: keep n_large <= the number of CUs); they are launched on an
- * internal stream forked from / joined into `stream`, concurrently with the rest.  0 is always valid.
+ * Invalidation runs as the order-free level sweep of csrc/sweep.h whenever that certifies the call (the result is
+ * then independent of the heap's tie order, hence equal to the reference's), and as the exact emulation of
+ * std::priority_queue otherwise.  The sweep needs: level_rank = u32 [ra, rb, rc] table (x fastest) of the rank of
+ * the key of offset (a, b, c) among the distinct keys (kh_level_keys + sort/unique by the caller), cstate = one
+ * zeroed u64 per voxel (zero again on exit), event_arena = 256-byte aligned scratch addressed by ev_offset /
+ * ev_chunks / ev_shift / nlev of each task; max_nlev = the largest task.nlev (sizes the LDS of the launch,
+ * <= KH_SWEEP_MAX_LEVELS).  level_rank == NULL switches the sweep off (heap emulation only).
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.                                                  */
 #define KH_TRACE_PROFILE 1
+#define KH_SWEEP_MAX_LEVELS 24576
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                    const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                    const uint32_t* manual_targets, float scale, float constant,
                    uint32_t* queues, void* heap_nodes,
-                   uint32_t* path_vertices, uint32_t* path_lengths, int n_large, int flags,
-                   int fix_branching, void* stream);
+                   uint32_t* path_vertices, uint32_t* path_lengths,
+                   const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
+                   uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream);
+
+/* keys[a + ra*(b + rb*c)] = the flood's key of the voxel offset (a, b, c): sqrt(fl(fl((wx*a)^2 + (wy*b)^2) + (wz*c)^2)),
+ * float operation order of dijkstra_invalidation.hpp:310-316.  Device array of ra*rb*rc floats.              */
+int kh_level_keys(int64_t ra, int64_t rb, int64_t rc, float wx, float wy, float wz, float* keys, void* stream);
 
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);

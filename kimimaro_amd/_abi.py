@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
 SYMBOLS = [
     "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
     "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
-    "kh_gather_f32", "kh_init_alive", "kh_invalidate_cube", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
+    "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
 
 
@@ -29,7 +29,7 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 36 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 46 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
@@ -40,8 +40,12 @@ LABEL_T = np.dtype([
     ("cyc_target", "<u4"), ("cyc_rail", "<u4"), ("cyc_inval", "<u4"),
     ("cyc_pop", "<u4"), ("cyc_push", "<u4"), ("cyc_fire", "<u4"),
     ("soma_mode", "<u4"), ("fsr", "<f4"), ("soma_radius", "<f4"), ("soma_scale", "<f4"), ("soma_const", "<f4"),
+    ("nlev", "<u4"), ("sweep_rmax", "<f4"), ("ev_offset", "<u4"), ("ev_chunks", "<u4"), ("ev_shift", "<u4"),
+    ("stat_sweep_calls", "<u4"), ("stat_sweep_bails", "<u4"), ("stat_sweep_levels", "<u4"), ("stat_sweep_events", "<u4"),
+    ("stat_sweep_why", "<u4"),
 ])
-assert LABEL_T.itemsize == 144
+assert LABEL_T.itemsize == 184
+SWEEP_MAX_LEVELS = 24576  # KH_SWEEP_MAX_LEVELS
 
 ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
            8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",
@@ -80,7 +84,8 @@ def lib():
     L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp]
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
-                                 f32, f32, vp, vp, vp, vp, ci, ci, ci, vp]
+                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, ci, ci, vp]
+    L.kh_level_keys.argtypes = [i64, i64, i64, f32, f32, f32, vp, vp]
     L.kh_fill_f32.argtypes = [vp, i64, f32, vp]
     L.kh_fill_u8.argtypes = [vp, i64, ci, vp]
     L.kh_gather_f32.argtypes = [vp, vp, i64, vp, vp]

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkimi_hip.so")
 SOURCES = ["common.hip", "edt.hip", "prep.hip", "trace.hip", "ccl.hip"]
-DEPS = SOURCES + ["common.h", os.path.join("..", "..", "include", "kimi_hip.h")]
+DEPS = SOURCES + ["common.h", "sweep.h", os.path.join("..", "..", "include", "kimi_hip.h")]
 
 
 def needs_build():

@@ -25,6 +25,7 @@
 // the chip is filled by running every label's workgroup concurrently; the largest labels keep two
 // chunks of their heap in LDS (kh_trace_paths n_large).
 #include "common.h"
+#include "sweep.h"
 
 namespace kh {
 
@@ -690,8 +691,52 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
   return n;
 }
 
+// everything the order-free sweep needs besides the per-label task record
+struct SweepGlobal {
+  const uint32_t* rank;         // level table [ra * rb * rc], nullptr = sweep disabled
+  int ra, rb, rc;
+  unsigned long long* cstate;   // one word per voxel, all zero on entry and on exit
+  unsigned char* arena;         // event arenas (per label: kh_label_t.ev_offset, in units of 256 bytes)
+};
+
+// One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
+// certifies the call, the heap emulation (wave 0) otherwise.  Returns the number of voxels invalidated.
+template <bool PROF, class H>
+__device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
+                                               const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
+                                               float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
+                                               uint32_t* sweep_stats) {
+  const int tid = threadIdx.x;
+  bool ok = false;
+  if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
+    uint32_t cnt = 0;
+    ok = sweep_ball(*sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt);
+    if (tid == 0) {
+      sweep_stats[0]++;
+      sweep_stats[2] += sw->sh->levels;
+      sweep_stats[3] += sw->sh->events;
+      if (!ok) { sweep_stats[1]++; sweep_stats[4] |= sw->sh->bail; }
+      if (sw->sh->maxnev > task->cyc_pop) task->cyc_pop = sw->sh->maxnev;   // diagnostic: busiest level
+      if (sw->sh->bump > task->cyc_push) task->cyc_push = sw->sh->bump;      // diagnostic: arena blocks used
+      ctl->u1 = cnt;
+    }
+  }
+  if (!ok) {
+    __syncthreads();
+    if (tid < 64) {
+      const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+                                                  &ctl->status, &ctl->u3, ctl->cyc3);
+      if (tid == 0) ctl->u1 = c;
+    }
+  }
+  __syncthreads();
+  const uint32_t c = ctl->u1;
+  __syncthreads();
+  return c;
+}
+
 template <bool PROF, int TOPL>
-__global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
+__global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,
@@ -699,9 +744,13 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
                                                           const uint32_t* __restrict__ manual_targets,
                                                           float scale, float constant, uint32_t* queues, hnode_t* heap_nodes,
                                                           uint32_t* path_vertices,
-                                                          uint32_t* path_lengths, int fix_branching) {
+                                                          uint32_t* path_lengths, int fix_branching, SweepGlobal sg) {
   __shared__ Ctl ctl;
-  extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];  // (Heap<TOPL>::TOP + 3) nodes
+  __shared__ Sweep sw;
+  __shared__ SweepShared swsh;
+  __shared__ uint32_t sweep_stats[5];
+  // (Heap<TOPL>::TOP + 3) nodes for the heap emulation; the sweep's level words and lists use the same bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
@@ -734,20 +783,42 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
   uint32_t valid = nf;
   uint32_t npaths = 0, nverts = 0;
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
-  if (tid == 0) { ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g; }
+  if (tid == 0) {
+    ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
+    for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
+    const uint32_t nlev = task->nlev;
+    sw.g = &ctl.g;
+    sw.nbrmask = nbrmask;
+    sw.alive = alive;
+    sw.cstate = sg.cstate;
+    sw.rank = nlev ? sg.rank : nullptr;
+    sw.ra = sg.ra; sw.rb = sg.rb;
+    // the heap's HBM slice (4 * nf + 1024 nodes of 16 bytes) is free while the sweep runs: source records
+    // (<= nf), then the three lists of the current level (nf + 64 entries each)
+    sw.srcs = reinterpret_cast<const uint4*>(heap.node);
+    sw.ncap = nf + 64u;
+    sw.wa = reinterpret_cast<unsigned long long*>(heap.node + nf);
+    sw.np = sw.wa + sw.ncap;
+    sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);
+    unsigned char* ar = sg.arena + (size_t)task->ev_offset * 256u;
+    sw.chunks = reinterpret_cast<uint2*>(ar);
+    sw.chcap = task->ev_chunks;
+    sw.shift = (int)task->ev_shift;
+    sw.killed = q.a;                                         // the search work lists are free during an invalidation
+    sw.nlev = nlev;
+    sw.chain = reinterpret_cast<uint32_t*>(heap_top);
+    sw.words = sw.chain + SW_CHAIN;
+    sw.lvbits = sw.words + nlev;
+    sw.sh = &swsh;
+  }
   __syncthreads();
   if (soma) {
     // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
     if (tid == 0) pverts[0] = root;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (wave == 0) {
-      const uint32_t c = invalidate_ball<PROF, Heap<TOPL>>(ctl.g, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                         heap, &ctl.status, &ctl.u3, ctl.cyc3);
-      if (lane == 0) ctl.u1 = c;
-    }
-    __syncthreads();
-    valid -= ctl.u1;                                    // trace.py:211 counts what is left
+    valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+                                          heap, list, nf, sweep_stats);   // trace.py:211 counts what is left
   }
   const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
   if (nb + na >= max_paths) {                           // trace.py:217-218
@@ -880,15 +951,9 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     }
     // ---- invalidation, trace.py:253-259
     t_rail += clock64() - t0; t0 = clock64();
-    if (valid > 0) {
-      if (wave == 0) {
-        const uint32_t c = invalidate_ball<PROF, Heap<TOPL>>(ctl.g, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, &ctl.status,
-                                           &ctl.u3, ctl.cyc3);
-        if (lane == 0) ctl.u1 = c;
-      }
-      __syncthreads();
-      valid -= ctl.u1;
-    }
+    if (valid > 0)
+      valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list, nf,
+                                            sweep_stats);
     // ---- rails, trace.py:261-263
     t_inval += clock64() - t0;
     if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
@@ -911,9 +976,14 @@ __global__ __launch_bounds__(64) void trace_paths_kernel(kh_label_t* tasks, cons
     task->cyc_target = (uint32_t)(t_target >> 10);
     task->cyc_rail = (uint32_t)(t_rail >> 10);
     task->cyc_inval = (uint32_t)(t_inval >> 10);
-    task->cyc_pop = (uint32_t)(ctl.cyc3[0] >> 10);
-    task->cyc_push = (uint32_t)(ctl.cyc3[1] >> 10);
+    if (PROF) task->cyc_pop = (uint32_t)(ctl.cyc3[0] >> 10);
+    if (PROF) task->cyc_push = (uint32_t)(ctl.cyc3[1] >> 10);
     task->cyc_fire = (uint32_t)(ctl.cyc3[2] >> 10);
+    task->stat_sweep_calls = sweep_stats[0];
+    task->stat_sweep_bails = sweep_stats[1];
+    task->stat_sweep_levels = sweep_stats[2];
+    task->stat_sweep_events = sweep_stats[3];
+    task->stat_sweep_why = sweep_stats[4];
   }
 }
 
@@ -987,74 +1057,87 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
 }
 
 namespace kh {
-template <bool PROF, int TOPL>
-static int launch_trace(int first, int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
+template <bool PROF>
+static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
-                        int fix_branching) {
+                        int fix_branching, const SweepGlobal& sg, uint32_t max_nlev) {
   if (count <= 0) return KH_OK;
-  const size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
-  if (TOPL > 1) {
-    static bool raised = false;  // more than 64 KiB of dynamic LDS has to be allowed once per kernel
-    if (!raised) {
-      KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, TOPL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      raised = true;
-    }
+  size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
+  if (sg.rank && swl > lds) lds = swl;
+  if (lds > 48 * 1024) {
+    // more than 48 KiB of dynamic LDS has to be allowed per kernel (and per device; the attribute is cheap to set)
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((trace_paths_kernel<PROF, TOPL>), dim3(count), dim3(64), lds, st, tasks + first, lists, list_daf, nbrmask,
+  hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(256), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                     path_lengths, fix_branching);
+                     path_lengths, fix_branching, sg);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
+
+// key of the offset (a, b, c) exactly as the flood computes it (dijkstra_invalidation.hpp:310-316)
+__global__ __launch_bounds__(256) void level_keys_kernel(int ra, int rb, int rc, float wx, float wy, float wz, float* keys) {
+  const int64_t n = (int64_t)ra * rb * rc;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int a = (int)(i % ra), b = (int)((i / ra) % rb), c = (int)(i / ((int64_t)ra * rb));
+  const float fa = wx * (float)a, fb = wy * (float)b, fc = wz * (float)c;
+  float s = fa * fa;
+  const float t = fb * fb;
+  const float u = fc * fc;
+  s = s + t;
+  s = s + u;
+  keys[i] = sqrtf(s);
+}
 }  // namespace kh
+
+extern "C" int kh_level_keys(int64_t ra, int64_t rb, int64_t rc, float wx, float wy, float wz, float* keys, void* stream) {
+  if (int rc2 = require_device()) return rc2;
+  if (ra <= 0 || rb <= 0 || rc <= 0 || ra * rb * rc >= (1ll << 31)) { set_error("kh_level_keys: bad table size"); return KH_EINVAL; }
+  const int64_t n = ra * rb * rc;
+  hipLaunchKernelGGL(level_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)ra, (int)rb,
+                     (int)rc, wx, wy, wz, keys);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
 
 extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                               const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                               const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
-                              void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths, int n_large, int flags,
-                              int fix_branching, void* stream) {
-  if (int rc = require_device()) return rc;
+                              void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
+                              const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
+                              uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream) {
+  if (int rc2 = require_device()) return rc2;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
-  if (n_large < 0 || n_large > ntasks) { set_error("kh_trace_paths: n_large out of range"); return KH_EINVAL; }
+  if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_MAX_LEVELS ||
+                     ((uintptr_t)event_arena & 255) != 0)) {
+    set_error("kh_trace_paths: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
+    return KH_EINVAL;
+  }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
+  SweepGlobal sg;
+  sg.rank = level_rank;
+  sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
+  sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
+  sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
-#define KH_TRACE_LAUNCH(PROFV, TOPLV, FIRST, COUNT, STREAM)                                                               \
-  launch_trace<PROFV, TOPLV>(FIRST, COUNT, STREAM, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate,    \
-                             manual_targets, scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths,  \
-                             fix_branching)
-  int rc = KH_OK;
-  if (n_large > 0) {
-    // the large-LDS workgroups (one per CU) and the ordinary ones have to be resident together: two launches on
-    // two streams, forked from and joined back into the caller's stream
-    static hipStream_t side = nullptr;
-    static hipEvent_t fork = nullptr, join = nullptr;
-    if (!side) {
-      KH_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      KH_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-      KH_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-    }
-    KH_HIP_CHECK(hipEventRecord(fork, st));
-    KH_HIP_CHECK(hipStreamWaitEvent(side, fork, 0));
-    rc = prof ? KH_TRACE_LAUNCH(true, 2, 0, n_large, side) : KH_TRACE_LAUNCH(false, 2, 0, n_large, side);
-    if (rc == KH_OK) rc = prof ? KH_TRACE_LAUNCH(true, 1, n_large, ntasks - n_large, st)
-                               : KH_TRACE_LAUNCH(false, 1, n_large, ntasks - n_large, st);
-    KH_HIP_CHECK(hipEventRecord(join, side));
-    KH_HIP_CHECK(hipStreamWaitEvent(st, join, 0));
-  } else {
-    rc = prof ? KH_TRACE_LAUNCH(true, 1, 0, ntasks, st) : KH_TRACE_LAUNCH(false, 1, 0, ntasks, st);
-  }
-#undef KH_TRACE_LAUNCH
-  return rc;
+  return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
+                                   scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
+                                   (uint32_t)max_nlev)
+              : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
+                                    scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
+                                    (uint32_t)max_nlev);
 }
 
 extern "C" int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,

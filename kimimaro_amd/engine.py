@@ -34,9 +34,12 @@ class Engine:
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
-        self._side = None     # second stream for the large-LDS workgroups when results are consumed incrementally
-        self.large_heap_slots = 128         # labels that may run with the 128 KiB LDS heap top (<= CUs)
-        self.large_heap_min_voxels = 16384  # ... if they have at least this many voxels
+        self._side = None     # second stream: the biggest labels run there while the others are collected
+        self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
+        self.split_min_voxels = 16384       # ... if they have at least this many voxels
+        self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
+        self.sweep_table_limit = 1 << 24    # largest level table (entries)
+        self._level_tables = {}
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -154,6 +157,33 @@ class Engine:
         v = d.view(shape[2], shape[1], shape[0])[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
         return np.asfortranarray(v.contiguous().cpu().numpy().view(dtype).transpose(2, 1, 0))
 
+    # -- level table of the order-free invalidation sweep (csrc/sweep.h) -------------
+    def level_table(self, shape, anisotropy, rmax):
+        """(d_rank int32 [ra*rb*rc], (ra, rb, rc), keys host f32 sorted, radius covered) for balls up to `rmax`.
+        rank[a + ra*(b + rb*c)] = index of the flood's key of offset (a, b, c) among the distinct keys; the keys
+        are computed by the device with the flood's own float operations (kh_level_keys), sorting and ranking is
+        plumbing (torch.unique).  The table is clipped to `sweep_table_limit` entries."""
+        t = self.torch
+        w = [float(np.float32(a)) for a in anisotropy]
+        dims = [int(min(int(rmax / w[i]) + 2, int(shape[i]))) for i in range(3)]
+        while dims[0] * dims[1] * dims[2] > self.sweep_table_limit:
+            rmax *= 0.8
+            dims = [int(min(int(rmax / w[i]) + 2, int(shape[i]))) for i in range(3)]
+        # every offset with a key below `covered` is inside the table (one row of slack for the rounding of the key)
+        covered = min([w[i] * (dims[i] - 1) for i in range(3) if dims[i] < shape[i]] + [float("inf")])
+        key = (tuple(w), tuple(dims))
+        hit = self._level_tables.get(key)
+        if hit is None:
+            n = dims[0] * dims[1] * dims[2]
+            d_keys = self.empty(n, t.float32)
+            _abi.check(self.lib.kh_level_keys(dims[0], dims[1], dims[2], w[0], w[1], w[2], self.ptr(d_keys), self.stream()))
+            uniq, inverse = t.unique(d_keys, sorted=True, return_inverse=True)
+            hit = (inverse.to(t.int32).contiguous(), tuple(dims), uniq.cpu().numpy())
+            if len(self._level_tables) > 8:
+                self._level_tables.clear()
+            self._level_tables[key] = hit
+        return hit[0], hit[1], hit[2], covered
+
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
                    xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,
@@ -213,6 +243,35 @@ class Engine:
         if soma is not None:  # per label (caller order): soma_mode, fsr, soma_radius, soma_scale, soma_const
             for key in ("soma_mode", "fsr", "soma_radius", "soma_scale", "soma_const"):
                 tasks[key] = np.asarray(soma[key])[order]
+        # order-free invalidation sweep: level table + per-label event arenas
+        d_rank, rdims, max_nlev = None, (0, 0, 0), 0
+        ev_total = 0
+        if self.sweep and nl > 0:
+            rmax_t = (np.float32(params["scale"]) * dm + np.float32(params["const"])).astype(np.float32)   # f32 ops as pyx:393-395
+            finite = rmax_t[np.isfinite(rmax_t)]
+            if finite.size and float(finite.max()) > 0:
+                d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, float(finite.max()))
+                nlev = np.searchsorted(keys, rmax_t, side="left").astype(np.int64)   # keys below the radius: levels 0..nlev-1
+                ok = np.isfinite(rmax_t) & (rmax_t <= covered) & (nlev <= _abi.SWEEP_MAX_LEVELS) & (nlev > 0)
+                nlev = np.where(ok, nlev, 0)
+                # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
+                # ever used + about 12 events per voxel, with slack
+                shift = np.where(cnt >= 32768, 7, 6).astype(np.int64)
+                chunks = np.minimum(2 * nlev + ((20 * cnt) >> shift) + 64, (1 << 22) - 2)
+                units = np.where(nlev > 0, ((chunks * 8) << shift) // 256, 0)
+                ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
+                ev_total = int(units.sum())
+                self.last_arena_bytes = ev_total * 256
+                if ev_total >= 2 ** 32:
+                    raise ValueError("kimimaro_amd: event arena offsets exceed 32 bits; shard the labels")
+                tasks["nlev"] = nlev
+                tasks["sweep_rmax"] = np.where(ok, rmax_t, 0).astype(np.float32)
+                tasks["ev_offset"] = ev_off
+                tasks["ev_chunks"] = np.where(nlev > 0, chunks, 0)
+                tasks["ev_shift"] = shift
+                max_nlev = int(nlev.max())
+                if max_nlev == 0:
+                    d_rank = None
         tgt = []
         tgt_off = np.zeros(nl, dtype=np.int64)
         for s, o in enumerate(order):
@@ -269,19 +328,24 @@ class Engine:
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
         d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
+        d_cstate = t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device)
+        d_arena = self.empty(max(ev_total, 1) * 32 + 32, t.int64)   # units of 256 bytes, 256-byte aligned start
+        arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
-        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; those whose
-        # heap gets deep enough to profit keep two chunks of it in LDS (one such workgroup per CU)
-        n_large = int(min(self.large_heap_slots, np.count_nonzero(cnt >= self.large_heap_min_voxels)))
+        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
+        # are consumed incrementally they go to a second stream and the others are collected while they still run
+        n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
         prof = 1 if self.profile else 0
+        rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
 
-        def launch(first, count, nbig, stream):
+        def launch(first, count, stream):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
             _abi.check(lib.kh_trace_paths(tasks_ptr, count, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
                                           P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
-                                          P(d_pverts), P(d_plens), nbig, prof, int(bool(fix_branching)), stream))
+                                          P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
+                                          P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), stream))
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
@@ -318,9 +382,9 @@ class Engine:
             if self._side is None:
                 self._side = t.cuda.Stream(device=self.device)
             self._side.wait_stream(cur)
-            launch(0, n_large, n_large, C.c_void_p(self._side.cuda_stream))
+            launch(0, n_large, C.c_void_p(self._side.cuda_stream))
             try:
-                launch(n_large, nl - n_large, 0, st)
+                launch(n_large, nl - n_large, st)
                 small = collect(n_large, nl)
                 consume(small)                  # overlaps the big labels' kernel: no device-wide sync in here
             finally:
@@ -333,7 +397,7 @@ class Engine:
             mark("d2h")
             LAST_TASKS = np.concatenate([big["tasks"], small["tasks"]])
             return None
-        launch(0, nl, n_large, st)
+        launch(0, nl, st)
         mark("paths")
         res = collect(0, nl)
         LAST_TASKS = res["tasks"]

@@ -220,17 +220,18 @@ def test_skeletonize_fuzz_small_volumes(eng, seed):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
-@pytest.mark.parametrize("slots", [3, 128])
-def test_skeletonize_large_lds_heap_variant(slots):
-    """the biggest labels run with two heap chunks in LDS (kh_trace_paths n_large) on a second stream, next to the
-    ordinary workgroups: force that split (3 of 7 labels) and the all-large case on a volume whose heaps outgrow
-    both LDS sizes."""
+@pytest.mark.parametrize("sweep,slots", [(False, 3), (False, 128), (True, 3), (True, 128)])
+def test_skeletonize_sweep_and_heap_paths(sweep, slots):
+    """The invalidation has two implementations: the order-free level sweep (csrc/sweep.h) and the exact emulation
+    of the reference's heap (the sweep's fall-back).  Both must give the oracle's skeletons; the volume is one
+    whose heaps outgrow the LDS part.  `slots` forces the two-stream split of the labels (3 of 7, and all)."""
     import kimimaro_amd
     from kimimaro_amd.engine import Engine
     from oracle import pipeline as P
     eng2 = Engine()
-    eng2.large_heap_min_voxels = 1
-    eng2.large_heap_slots = slots
+    eng2.split_min_voxels = 1
+    eng2.split_slots = slots
+    eng2.sweep = sweep
     an = (16, 16, 40)
     lab = voronoi_labels((96, 96, 40), 7, seed=5, pts_per_label=3, step=12.0, anisotropy=an)
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
@@ -238,7 +239,13 @@ def test_skeletonize_large_lds_heap_variant(slots):
                                    progress=False, _engine=eng2)
     want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True)
     import kimimaro_amd.engine as E
-    assert int(E.LAST_TASKS["stat_heap_pushes"].max()) > 20000   # deep heaps: both the LDS and the HBM part are used
+    tk = E.LAST_TASKS
+    if sweep:
+        assert int(tk["stat_sweep_calls"].sum()) > 0
+        assert int(tk["stat_sweep_calls"].sum() - tk["stat_sweep_bails"].sum()) > 0   # the sweep certified calls
+    else:
+        assert int(tk["stat_sweep_calls"].sum()) == 0
+        assert int(tk["stat_heap_pushes"].max()) > 20000   # deep heaps: both the LDS and the HBM part are used
     assert sorted(got.keys()) == sorted(want.keys()) and len(got) >= 4
     for k in got:
         np.testing.assert_array_equal(got[k].vertices, want[k].vertices)

@@ -16,7 +16,10 @@ if which == "c2":
 else:
     shape, nl, pts, seed, an = (512, 512, 512), 2124, 16, 3, (16, 16, 40)
 t = time.time()
-lab = voronoi_labels(shape, nl, seed=seed, pts_per_label=pts, step=24.0, anisotropy=an)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+lab, an = bench.make_volume(which)
+shape = lab.shape
 print("gen", time.time() - t, flush=True)
 d = eng.to_device(lab)
 n = lab.size
@@ -40,7 +43,7 @@ print("skeletonize: %d skeletons in %.3f s -> %.1f labels/s" % (len(sk), t1 - t0
 prev = timings[0][1]
 for name, ts in timings[1:]:
     print("  %-14s %.3f s" % (name, ts - prev)); prev = ts
-print("verts", sum(s.vertices.shape[0] for s in sk.values()))
+print("verts", sum(s.vertices.shape[0] for s in sk.values()), "arena MB", getattr(eng, "last_arena_bytes", 0) / 1e6)
 import kimimaro_amd.engine as E
 tk = E.LAST_TASKS
 if tk is not None:
@@ -49,5 +52,19 @@ if tk is not None:
     print("worst label: count", tk["count"][i], "paths", tk["n_paths"][i], "kcyc", tk["cyc_target"][i], tk["cyc_rail"][i], tk["cyc_inval"][i], "pushes", tk["stat_heap_pushes"][i], "settled", tk["stat_settled"][i])
     print("kcyc pop/push/fire sums:", tk["cyc_pop"].astype(np.int64).sum(), tk["cyc_push"].astype(np.int64).sum(), tk["cyc_fire"].astype(np.int64).sum())
     print("worst label kcyc pop/push/fire:", tk["cyc_pop"][i], tk["cyc_push"][i], tk["cyc_fire"][i])
-    print("pushes of the 128 largest labels (large-LDS kernel):", tk["stat_heap_pushes"][:128].astype(np.int64).sum())
+    print("sweep: calls", tk["stat_sweep_calls"].sum(), "bails", tk["stat_sweep_bails"].sum(), "levels", tk["stat_sweep_levels"].astype(np.int64).sum(),
+          "events", tk["stat_sweep_events"].astype(np.int64).sum(), "why", np.bitwise_or.reduce(tk["stat_sweep_why"]))
+    print("worst label sweep: calls", tk["stat_sweep_calls"][i], "bails", tk["stat_sweep_bails"][i], "levels", tk["stat_sweep_levels"][i], "events", tk["stat_sweep_events"][i])
+    b = np.flatnonzero(tk["stat_sweep_bails"])
+    for why in (1, 2, 4, 8, 16, 32):
+        bb = np.flatnonzero(tk["stat_sweep_why"] & why)
+        print("  why", why, "labels", bb.size, "counts", tk["count"][bb][:12], "nlev", tk["nlev"][bb][:12], "shift", tk["ev_shift"][bb][:12], "maxnev", tk["cyc_pop"][bb][:12], "blocks used", tk["cyc_push"][bb][:12], "of", tk["ev_chunks"][bb][:12], "bails", tk["stat_sweep_bails"][bb][:12], "calls", tk["stat_sweep_calls"][bb][:12])
+    nb_ = np.flatnonzero(tk["stat_sweep_bails"] == 0)
+    tot_ = tk["cyc_target"].astype(np.int64) + tk["cyc_rail"] + tk["cyc_inval"]
+    if nb_.size:
+        j = nb_[np.argmax(tot_[nb_])]
+        print("slowest label WITHOUT bails: count", tk["count"][j], "paths", tk["n_paths"][j], "kcyc target/rail/inval", tk["cyc_target"][j], tk["cyc_rail"][j], tk["cyc_inval"][j],
+              "levels", tk["stat_sweep_levels"][j], "events", tk["stat_sweep_events"][j], "-> ms at 2.4 GHz: %.1f" % (tot_[j] * 1024 / 2.4e6))
+        print("sum over labels without bails: kcyc target/rail/inval", tk["cyc_target"][nb_].astype(np.int64).sum(), tk["cyc_rail"][nb_].astype(np.int64).sum(), tk["cyc_inval"][nb_].astype(np.int64).sum())
+    print("labels with bails:", b.size, "their voxels", tk["count"][b].sum(), "of", tk["count"].sum(), "largest such", tk["count"][b].max() if b.size else 0)
     print("pushes total", tk["stat_heap_pushes"].astype(np.int64).sum(), "settled total", tk["stat_settled"].astype(np.int64).sum(), "paths", tk["n_paths"].sum())
