@@ -50,11 +50,18 @@ int kh_device_count(void);
 
 /* ---- a1: edt.edt(labels, anisotropy, black_border) ---------------------------------
  * replaces: edt.edt as called at kimimaro/intake.py:178-183 and kimimaro/trace.py:112-117.
- * labels: u8/u16/u32 [sx,sy,sz]; out: f32 same shape; workspace: f32 same shape (ping-pong).
+ * labels: u8/u16/u32 [sx,sy,sz]; out: f32 same shape; workspace: f32 of the same shape (ping-pong buffer, sx*sy*sz floats).
  * Squared distances are accumulated exactly as documented in oracle/kimi_oracle.c (ko_edt). */
 int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
            float wx, float wy, float wz, int black_border,
            float* workspace, float* out, void* stream);
+
+/* kh_edt for an array of `ndim` (1..3) dimensions, the trailing axes having extent 1: edt.edt on a 2-D array is a
+ * 2-D transform -- with black_border the missing axes have no border (kimimaro/intake.py:568 calls it on the six
+ * faces of the volume).  kh_edt == kh_edt_nd(ndim = 3).                                                       */
+int kh_edt_nd(const void* labels, int label_bytes, int ndim, int64_t sx, int64_t sy, int64_t sz,
+              float wx, float wy, float wz, int black_border,
+              float* workspace, float* out, void* stream);
 
 /* kh_edt with each pass bracketed by HIP events on `stream`; ms3 (HOST pointer) receives the
  * x / y / z pass durations in milliseconds.  Synchronises the stream (measurement only).       */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
 
 # every symbol include/kimi_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
+    "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_nd", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
     "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
     "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
@@ -77,6 +77,7 @@ def lib():
     L.kh_last_error.argtypes = [C.c_char_p, ci]
     L.kh_device_count.restype = ci
     L.kh_edt.argtypes = [vp, ci, i64, i64, i64, f32, f32, f32, ci, vp, vp, vp]
+    L.kh_edt_nd.argtypes = [vp, ci, ci, i64, i64, i64, f32, f32, f32, ci, vp, vp, vp]
     L.kh_edt_timed.argtypes = [vp, ci, i64, i64, i64, f32, f32, f32, ci, vp, vp, vp, vp]
     L.kh_label_stats.argtypes = [vp, ci, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.kh_scatter_lists.argtypes = [vp, ci, i64, vp, i64, vp, vp, vp, vp]

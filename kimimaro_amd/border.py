@@ -7,7 +7,7 @@ targets; the last one of each label is its root (intake.py:486-488), so that ske
 chunks meet at the same face voxel.
 
 Host side (faces are 2-D, ~1e5 pixels): numpy + two host helpers of libkimi_hip.so (CCL and
-find_border_targets restated in C++); the 2-D EDT runs on the MI355X (kh_edt with sz=1).
+find_border_targets restated in C++); the 2-D EDT runs on the MI355X (kh_edt_nd, ndim = 2).
 The sets of the reference are kept as Python sets of int tuples, inserted in the same order, so that
 CPython's iteration order -- which decides the root (intake.py:583,488) -- is reproduced.
 """
@@ -76,7 +76,7 @@ def compute_border_targets(cc_labels, anisotropy, eng=None, edt2d=None, faces=No
             dt_plane = edt2d(cc_plane, (wx, wy), True)
         else:
             d = eng.to_device(cc_plane)
-            dt_plane = eng.edt(d, 4, (cc_plane.shape[0], cc_plane.shape[1], 1), (wx, wy, 1.0), True)
+            dt_plane = eng.edt(d, 4, (cc_plane.shape[0], cc_plane.shape[1], 1), (wx, wy, 1.0), True, ndim=2)
             dt_plane = dt_plane.cpu().numpy().reshape(cc_plane.shape, order="F")
         plane_targets = find_border_targets(dt_plane, cc_plane, wx, wy, n)
         # get_mapping(plane, cc_plane): cc id -> label of the 3-D component on this face

@@ -340,12 +340,14 @@ __global__ void edt_finish_kernel(const float* __restrict__ in, float* __restric
 }
 
 template <typename LT>
-static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                     int black_border, float* ws, float* out, hipStream_t st, hipEvent_t* ev = nullptr) {
   const int64_t nrows = sy * sz;
   const int64_t nvox = sx * nrows;
-  const bool do_y = (sy > 1) || black_border;
-  const bool do_z = (sz > 1) || black_border;
+  // an axis beyond the array's dimensionality is not an axis: edt.edt on a 2-D plane is a 2-D transform, the
+  // border of a missing axis does not exist (kimimaro/intake.py:568 calls it on the faces of the volume)
+  const bool do_y = ndim >= 2 && ((sy > 1) || black_border);
+  const bool do_z = ndim >= 3 && ((sz > 1) || black_border);
   // ping-pong so that the final pass lands in `out`
   const int npass = 1 + (do_y ? 1 : 0) + (do_z ? 1 : 0);
   float* bufs[2] = {out, ws};
@@ -396,20 +398,29 @@ static int edt_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, float wx,
 
 }  // namespace kh
 
-extern "C" int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
-                      float wz, int black_border, float* workspace, float* out, void* stream) {
+extern "C" int kh_edt_nd(const void* labels, int label_bytes, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                         float wz, int black_border, float* workspace, float* out, void* stream) {
   if (int rc = kh::require_device()) return rc;
   if (!labels || !out || !workspace || sx <= 0 || sy <= 0 || sz <= 0 || sx * sy * sz >= (1ll << 32)) {
     kh::set_error("kh_edt: bad arguments (null pointer, empty volume or >= 2^32 voxels)");
     return KH_EINVAL;
   }
+  if (ndim < 1 || ndim > 3 || (ndim < 3 && sz != 1) || (ndim < 2 && sy != 1)) {
+    kh::set_error("kh_edt_nd: ndim must be 1..3 and the axes beyond it must have extent 1");
+    return KH_EINVAL;
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (label_bytes) {
-    case 1: return kh::edt_impl<uint8_t>((const uint8_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
-    case 2: return kh::edt_impl<uint16_t>((const uint16_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
-    case 4: return kh::edt_impl<uint32_t>((const uint32_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
+    case 1: return kh::edt_impl<uint8_t>((const uint8_t*)labels, ndim, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
+    case 2: return kh::edt_impl<uint16_t>((const uint16_t*)labels, ndim, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
+    case 4: return kh::edt_impl<uint32_t>((const uint32_t*)labels, ndim, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st);
     default: kh::set_error("kh_edt: label_bytes must be 1, 2 or 4"); return KH_EINVAL;
   }
+}
+
+extern "C" int kh_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                      float wz, int black_border, float* workspace, float* out, void* stream) {
+  return kh_edt_nd(labels, label_bytes, 3, sx, sy, sz, wx, wy, wz, black_border, workspace, out, stream);
 }
 
 // Same as kh_edt, but brackets each pass with HIP events on `stream` and returns the three pass
@@ -427,9 +438,9 @@ extern "C" int kh_edt_timed(const void* labels, int label_bytes, int64_t sx, int
   for (int i = 0; i < 4; i++) KH_HIP_CHECK(hipEventCreate(&ev[i]));
   int rc;
   switch (label_bytes) {
-    case 1: rc = kh::edt_impl<uint8_t>((const uint8_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
-    case 2: rc = kh::edt_impl<uint16_t>((const uint16_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
-    case 4: rc = kh::edt_impl<uint32_t>((const uint32_t*)labels, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
+    case 1: rc = kh::edt_impl<uint8_t>((const uint8_t*)labels, 3, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
+    case 2: rc = kh::edt_impl<uint16_t>((const uint16_t*)labels, 3, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
+    case 4: rc = kh::edt_impl<uint32_t>((const uint32_t*)labels, 3, sx, sy, sz, wx, wy, wz, black_border, workspace, out, st, ev); break;
     default: kh::set_error("kh_edt_timed: label_bytes must be 1, 2 or 4"); rc = KH_EINVAL;
   }
   if (rc == KH_OK) {

@@ -40,6 +40,7 @@ class Engine:
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         self._level_tables = {}
+        self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -122,17 +123,18 @@ class Engine:
         return np.asfortranarray(f.contiguous().cpu().numpy().view(np.uint32).T)  # -> (x,y) / (x,z) / (y,z)
 
     # -- a1 -------------------------------------------------------------------
-    def edt(self, d_labels, label_bytes, shape, anisotropy, black_border, out=None, workspace=None):
+    def edt(self, d_labels, label_bytes, shape, anisotropy, black_border, out=None, workspace=None, ndim=3):
+        """ndim: dimensionality of the caller's array (trailing axes of extent 1 beyond it are not axes)."""
         sx, sy, sz = shape
         n = sx * sy * sz
         t = self.torch
         if out is None:
             out = self.empty(n, t.float32)
         if workspace is None:
-            workspace = self.empty(2 * n, t.float32)  # f32 ping-pong volume + two u16 run-limit volumes
-        _abi.check(self.lib.kh_edt(self.ptr(d_labels), label_bytes, sx, sy, sz, float(anisotropy[0]),
-                                   float(anisotropy[1]), float(anisotropy[2]), int(bool(black_border)),
-                                   self.ptr(workspace), self.ptr(out), self.stream()))
+            workspace = self.empty(n, t.float32)  # ping-pong buffer of the passes (include/kimi_hip.h)
+        _abi.check(self.lib.kh_edt_nd(self.ptr(d_labels), label_bytes, int(ndim), sx, sy, sz, float(anisotropy[0]),
+                                      float(anisotropy[1]), float(anisotropy[2]), int(bool(black_border)),
+                                      self.ptr(workspace), self.ptr(out), self.stream()))
         return out
 
     def label_stats(self, d_labels, label_bytes, d_dbf, shape, nlabels):
@@ -187,7 +189,7 @@ class Engine:
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
                    xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,
-                   return_fields=False, timings=None, soma=None, consume=None):
+                   return_fields=False, timings=None, soma=None, consume=None, scratch_scale=1):
         """Run find_root -> DAF -> PDRF -> path loop for the connected components `segids`.
 
         segids/counts/...: host arrays indexed by position (same order).  roots: array of linear indices or
@@ -214,9 +216,11 @@ class Engine:
         total = int(cnt.sum())
         qcap = cnt + 64
         q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
-        hcap = 4 * cnt + 1024
+        # heap / path scratch are sized for the common case; a label that overflows them is traced again on its own
+        # with `scratch_scale` times as much (below) -- the reference has no such limits
+        hcap = np.maximum((4 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256)  # (the sweep's lists live here too)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
-        pcap = np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536))
+        pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
         if max(total, int(qcap.sum()), int(hcap.sum()), int(pcap.sum())) >= 2 ** 32:
             raise ValueError("kimimaro_amd: scratch offsets exceed 32 bits; shard the labels")
@@ -351,11 +355,16 @@ class Engine:
             """results of task slots [lo, hi) (device -> host on the current stream)."""
             isz = _abi.LABEL_T.itemsize
             part = d_tasks[lo * isz:hi * isz].cpu().numpy().view(_abi.LABEL_T).copy()
-            bad = np.flatnonzero(part["status"])
-            if bad.size:
-                s = int(bad[0])
+            overflow = (part["status"] & 7) != 0          # work list / heap / path buffer too small: traced again below
+            bad = np.flatnonzero((part["status"] & ~np.uint32(7)) != 0)
+            if bad.size or (overflow.any() and scratch_scale >= 64):
+                s = int(bad[0]) if bad.size else int(np.flatnonzero(overflow)[0])
                 raise _abi.KimiHipError("label %d (cc id): %s" % (int(part["segid"][s]),
                                                                    _abi.describe_status(int(part["status"][s]))))
+            for s in np.flatnonzero(overflow):
+                retry.append(int(order[lo + s]))
+                part["n_vertices"][s] = 0
+                part["n_paths"][s] = 0
             # gather the used part of the path buffers: build a flat index on the host (small), gather on device
             nverts = part["n_vertices"].astype(np.int64)
             npaths = part["n_paths"].astype(np.int64)
@@ -372,6 +381,20 @@ class Engine:
             radii = d_radii.cpu().numpy()[: verts.size]
             return {"order": order[lo:hi], "tasks": part, "verts": verts, "radii": radii, "lens": lens,
                     "voff": np.concatenate([[0], np.cumsum(nverts)]), "loff": np.concatenate([[0], np.cumsum(npaths)])}
+
+        retry = []   # positions (caller order) of the labels whose scratch overflowed
+
+        def run_retry(sink):
+            if not retry:
+                return
+            pick = np.asarray(retry, dtype=np.int64)
+            sub = lambda a: [a[i] for i in pick] if a is not None else None
+            subsoma = None if soma is None else {k: np.asarray(v)[pick] for k, v in soma.items()}
+            self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[pick], counts[pick],
+                            np.asarray(dbf_max)[pick], np.asarray(first_index)[pick], np.asarray(xmin)[pick],
+                            np.asarray(xmax)[pick], np.asarray(roots, dtype=np.uint32)[pick], sub(targets_before),
+                            sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
+                            consume=sink, scratch_scale=scratch_scale * 8)
 
         global LAST_TASKS
         if consume is not None and 0 < n_large < nl:
@@ -395,16 +418,41 @@ class Engine:
             mark("paths")
             consume(big)
             mark("d2h")
-            LAST_TASKS = np.concatenate([big["tasks"], small["tasks"]])
+            tasks_done = np.concatenate([big["tasks"], small["tasks"]])
+            run_retry(consume)
+            LAST_TASKS = tasks_done
             return None
         launch(0, nl, st)
         mark("paths")
         res = collect(0, nl)
-        LAST_TASKS = res["tasks"]
         mark("d2h")
         if consume is not None:
             consume(res)
+            run_retry(consume)
+            LAST_TASKS = res["tasks"]
             return None
+        if retry:
+            # splice the re-traced labels into the result (callers without a sink: single labels, tests)
+            redo = []
+            run_retry(redo.append)
+            pos_of = {int(o): s for s, o in enumerate(res["order"])}
+            per_v = [res["verts"][res["voff"][s]:res["voff"][s + 1]] for s in range(nl)]
+            per_r = [res["radii"][res["voff"][s]:res["voff"][s + 1]] for s in range(nl)]
+            per_l = [res["lens"][res["loff"][s]:res["loff"][s + 1]] for s in range(nl)]
+            for sub in redo:
+                for s2, o2 in enumerate(sub["order"]):
+                    s = pos_of[retry[int(o2)]]
+                    per_v[s] = sub["verts"][sub["voff"][s2]:sub["voff"][s2 + 1]]
+                    per_r[s] = sub["radii"][sub["voff"][s2]:sub["voff"][s2 + 1]]
+                    per_l[s] = sub["lens"][sub["loff"][s2]:sub["loff"][s2 + 1]]
+                    for f in ("n_paths", "n_vertices", "status"):
+                        res["tasks"][f][s] = sub["tasks"][f][s2]
+            res["verts"] = np.concatenate(per_v) if per_v else res["verts"]
+            res["radii"] = np.concatenate(per_r) if per_r else res["radii"]
+            res["lens"] = np.concatenate(per_l) if per_l else res["lens"]
+            res["voff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_v])])
+            res["loff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_l])])
+        LAST_TASKS = res["tasks"]
         if return_fields:
             res["daf"] = d_field.cpu().numpy()
             res["pdrf"] = d_pdrf.cpu().numpy()

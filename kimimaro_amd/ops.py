@@ -26,6 +26,7 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False, parallel=1, voxel_grap
     eng = engine()
     lab = np.asarray(labels)
     shape0 = lab.shape
+    ndim = max(1, min(lab.ndim, 3))
     if lab.dtype == bool:
         lab = lab.view(np.uint8)
     if lab.dtype.kind not in "ui" or lab.dtype.itemsize > 4:
@@ -34,7 +35,7 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False, parallel=1, voxel_grap
         lab = lab[..., np.newaxis]
     lab = np.asfortranarray(lab)
     an = list(anisotropy) + [1.0] * (3 - len(anisotropy))
-    out = eng.edt(eng.to_device(lab), lab.dtype.itemsize, lab.shape, an, black_border)
+    out = eng.edt(eng.to_device(lab), lab.dtype.itemsize, lab.shape, an, black_border, ndim=ndim)
     return out.cpu().numpy().reshape(lab.shape, order="F").reshape(shape0, order="F")
 
 

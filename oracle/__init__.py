@@ -31,6 +31,7 @@ def lib():
         i64, f32, u64, vp = C.c_int64, C.c_float, C.c_uint64, C.c_void_p
         L.ko_weights26.argtypes = [f32, f32, f32, vp]
         L.ko_edt.argtypes = [vp, C.c_int, i64, i64, i64, f32, f32, f32, C.c_int, vp]
+        L.ko_edt_nd.argtypes = [vp, C.c_int, C.c_int, i64, i64, i64, f32, f32, f32, C.c_int, vp]
         L.ko_edf.argtypes = [vp, i64, i64, i64, f32, f32, f32, u64, f32, vp, vp, vp]
         L.ko_pdrf.argtypes = [vp, vp, i64, f32, C.c_int, f32, f32, vp]
         L.ko_target_order.argtypes = [vp, vp, i64, vp]
@@ -113,8 +114,8 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False):
     lab = _f3(labels)
     an = list(np.asarray(anisotropy, dtype=np.float32)) + [np.float32(1)] * (3 - len(anisotropy))
     out = np.zeros(lab.shape, dtype=np.float32, order="F")
-    _check(lib().ko_edt(_p(lab), lab.dtype.itemsize, lab.shape[0], lab.shape[1], lab.shape[2],
-                        an[0], an[1], an[2], int(bool(black_border)), _p(out)))
+    _check(lib().ko_edt_nd(_p(lab), lab.dtype.itemsize, max(1, min(nd, 3)), lab.shape[0], lab.shape[1], lab.shape[2],
+                           an[0], an[1], an[2], int(bool(black_border)), _p(out)))
     return out.reshape(labels.shape, order="F") if nd < 3 else out
 
 

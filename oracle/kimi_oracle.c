@@ -115,8 +115,16 @@ static void ko_edt_axis(const void* labels, int lb, float* f, int64_t n, int64_t
   }
 }
 
+int ko_edt_nd(const void* labels, int label_bytes, int ndim, int64_t sx, int64_t sy, int64_t sz,
+              float wx, float wy, float wz, int black_border, float* out);
 int ko_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz,
            float wx, float wy, float wz, int black_border, float* out) {
+  return ko_edt_nd(labels, label_bytes, 3, sx, sy, sz, wx, wy, wz, black_border, out);
+}
+/* ndim = dimensionality of the caller's array: edt.edt on a 2-D array is a 2-D transform, a missing axis has no
+ * border (kimimaro/intake.py:568 calls it on the faces of the volume with black_border=True).               */
+int ko_edt_nd(const void* labels, int label_bytes, int ndim, int64_t sx, int64_t sy, int64_t sz,
+              float wx, float wy, float wz, int black_border, float* out) {
   if (!(label_bytes == 1 || label_bytes == 2 || label_bytes == 4 || label_bytes == 8)) return KO_EINVAL;
   const int64_t sxy = sx * sy;
   /* x pass: two sweeps */
@@ -145,11 +153,11 @@ int ko_edt(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t 
   if (!tmp) return KO_ENOMEM;
   ko_edt_steps[0] = ko_edt_steps[1] = 0;
   ko_edt_axis_id = 0;
-  if (sy > 1 || black_border)
+  if (ndim >= 2 && (sy > 1 || black_border))
     for (int64_t z = 0; z < sz; z++) for (int64_t x = 0; x < sx; x++)
       ko_edt_axis(labels, label_bytes, out, sy, sx, x + sxy * z, wy, black_border, tmp);
   ko_edt_axis_id = 1;
-  if (sz > 1 || black_border)
+  if (ndim >= 3 && (sz > 1 || black_border))
     for (int64_t y = 0; y < sy; y++) for (int64_t x = 0; x < sx; x++)
       ko_edt_axis(labels, label_bytes, out, sz, sxy, x + sx * y, wz, black_border, tmp);
   free(tmp);

@@ -7,7 +7,8 @@ so that the HIP product path -- which works on whole-volume arrays and batches
 labels -- is checked against an independently structured implementation.
 
 Not restated (rows f2/f3 of SURVEY.md section 8 are handled where noted):
-soma mode is restated with a fill_voids stand-in (scipy.ndimage.binary_fill_holes) and a documented
+The Skeleton operations and the border targets are restated in oracle/skeleton.py and oracle/border.py (nothing here
+imports the product).  soma mode is restated with a fill_voids stand-in (scipy.ndimage.binary_fill_holes) and a documented
 guess of dijkstra3d's free_space_radius (source absent); fill_holes is restated with the same stand-in;
 voxel_graph and fix_avocados raise
 NotImplementedError.
@@ -20,7 +21,8 @@ import numpy as np
 import scipy.ndimage
 
 import oracle as K
-from kimimaro_amd.skeleton import Skeleton
+from oracle.skeleton import Skeleton
+from oracle import border as _border
 
 DEFAULT_TEASAR_PARAMS = {  # kimimaro/intake.py:47-56
     "scale": 1.5,
@@ -206,20 +208,20 @@ def find_root(labels, anisotropy):
 
 
 def format_labels(labels):
-    """kimimaro/intake.py:315-342."""
-    labels = np.copy(labels, order="F")
-    if labels.dtype == bool:
-        labels = labels.view(np.uint8)
-    original_shape = labels.shape
-    while labels.ndim < 3:
-        labels = labels[..., np.newaxis]
-    while labels.ndim > 3:
-        if labels.shape[-1] == 1:
-            labels = labels[..., 0]
-        else:
+    """kimimaro/intake.py:315-342: a Fortran-ordered copy with exactly three axes (missing axes are appended with
+    extent 1, surplus trailing axes of extent 1 are dropped, anything else is an error); bool becomes uint8."""
+    lab = np.array(labels, order="F")
+    if lab.dtype == bool:
+        lab = lab.view(np.uint8)
+    given = lab.shape
+    if lab.ndim < 3:
+        lab = lab.reshape(given + (1,) * (3 - lab.ndim), order="F")
+    elif lab.ndim > 3:
+        if any(n != 1 for n in given[3:]):
             raise DimensionError(
-                "Input labels may be no more than three non-trivial dimensions. Got: {}".format(original_shape))
-    return labels
+                "Input labels may be no more than three non-trivial dimensions. Got: {}".format(given))
+        lab = lab.reshape(given[:3], order="F")
+    return lab
 
 
 def compute_cc_labels(all_labels):
@@ -297,8 +299,7 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
 
     border_targets = defaultdict(list)
     if fix_borders:
-        from kimimaro_amd.border import compute_border_targets
-        border_targets = compute_border_targets(cc_labels, anisotropy, edt2d=K.edt)
+        border_targets = _border.compute_border_targets(cc_labels, anisotropy, K.edt, K.connected_components)
 
     skeletons = defaultdict(list)
     for segid in cc_segids:

@@ -91,3 +91,41 @@ def test_edt_full_size_properties(eng):
         gx, gy, gz = np.nonzero(sub)
         d2 = ((gx + x0 - x) * 16.0) ** 2 + ((gy + y0 - y) * 16.0) ** 2 + ((gz + z0 - z) * 40.0) ** 2
         assert np.isclose(np.sqrt(d2.min()), got[x, y, z], rtol=1e-6)
+
+
+@pytest.mark.parametrize("an", [(1, 1), (40, 32), (16, 40)])
+def test_edt_2d_black_border(eng, an):
+    """kh_edt_nd with ndim = 2: a 2-D transform, bit-exact vs the oracle (which is pinned to scipy's EDT of the padded
+    plane in tests/test_oracle_golden.py); a z pass over the missing axis would cap every value at wz."""
+    import oracle
+    rng = np.random.default_rng(11)
+    lab = np.zeros((70, 45), np.uint32, order="F")
+    lab[3:60, 5:40] = 1
+    lab[20:30, :] = 2
+    lab[rng.random(lab.shape) < 0.02] = 0
+    d = eng.to_device(lab[..., np.newaxis])
+    out = eng.edt(d, 4, (lab.shape[0], lab.shape[1], 1), (an[0], an[1], 1.0), True, ndim=2)
+    got = out.cpu().numpy().reshape(lab.shape, order="F")
+    want = oracle.edt(lab, an, True)
+    np.testing.assert_array_equal(got, want)
+    assert got.max() > 3 * min(an)
+
+
+def test_border_targets_match_oracle_on_nonconvex_faces(eng):
+    """kimimaro_amd.border.compute_border_targets (2-D CCL + GPU 2-D EDT + host arg-max) against the oracle's
+    independent restatement (oracle/border.py) on faces with L- and ring-shaped components."""
+    import oracle
+    from kimimaro_amd.border import compute_border_targets
+    from oracle import border as B
+    lab = np.zeros((40, 36, 12), np.uint32, order="F")
+    lab[1:36, 2:9, :] = 7
+    lab[25:36, 2:30, :] = 7
+    lab[3:20, 14:34, 2:12] = 9
+    lab[8:15, 19:29, 2:12] = 0      # ring on the z = -1 face
+    an = (16, 16, 40)
+    cc, _ = oracle.connected_components(lab)
+    got = compute_border_targets(cc, an, eng=eng)
+    want = B.compute_border_targets(cc, an, oracle.edt, oracle.connected_components)
+    assert sorted(got.keys()) == sorted(want.keys()) and len(want) >= 2
+    for k in want:
+        assert [tuple(p) for p in got[k].tolist()] == [tuple(p) for p in want[k].tolist()], k

@@ -253,6 +253,28 @@ def test_skeletonize_sweep_and_heap_paths(sweep, slots):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
+def test_scratch_overflow_is_retried():
+    """a label whose heap / path scratch overflows is traced again on its own with more room (the reference has no
+    such limits); the others keep their results.  Scratch shrunk 64-fold, heap path only."""
+    import kimimaro_amd
+    from kimimaro_amd.engine import Engine
+    from oracle import pipeline as P
+    eng2 = Engine()
+    eng2.sweep = False
+    eng2.scratch_divisor = 64
+    an = (16, 16, 40)
+    lab = voronoi_labels((64, 64, 32), 6, seed=9, pts_per_label=3, step=10.0, anisotropy=an)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 50
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=False, fix_branching=False,
+                                   progress=False, _engine=eng2)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=False, fix_branching=False)
+    assert sorted(got.keys()) == sorted(want.keys()) and len(got) >= 3
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+
+
 def test_skeletonize_fill_holes(eng):
     """fill_holes=True (kimimaro/intake.py:168-169, 747-795): a label enclosed by another one is swallowed, a
     background void is filled, a cavity open to the face of the volume is not."""

@@ -130,18 +130,62 @@ def test_edt_multilabel_bruteforce():
         assert (got[lab == 0] == 0).all()
 
 
-def test_border_targets_golden():
-    from kimimaro_amd.border import find_border_targets
+@pytest.mark.parametrize("which", ["product host helper", "oracle"])
+def test_border_targets_golden(which):
+    """find_border_targets of the compiled reference (24 planes, dict order included) against the product's host
+    helper (libkimi_hip.so, no device needed) and against the oracle's independent numpy restatement."""
+    if which == "oracle":
+        from oracle.border import find_border_targets as fbt
+        find = lambda dt, cc, wx, wy: fbt(dt, cc, wx, wy)
+    else:
+        from kimimaro_amd.border import find_border_targets as fbt
+        find = lambda dt, cc, wx, wy: fbt(dt, cc, wx, wy, int(cc.max()))
     z = np.load(os.path.join(G, "border_targets.npz"))
     for i in range(int(z["n"])):
         cc, dt = np.asfortranarray(z["cc_%d" % i]), np.asfortranarray(z["dt_%d" % i])
         wx, wy = z["w_%d" % i]
-        got = find_border_targets(dt, cc, wx, wy, int(cc.max()))
+        got = find(dt, cc, wx, wy)
         keys = z["keys_%d" % i]
         vals = z["vals_%d" % i]
         assert list(got.keys()) == keys.tolist(), i            # dict insertion order too
         for k, v in zip(keys.tolist(), vals.tolist()):
             assert (int(got[k][0]), int(got[k][1])) == tuple(v), (i, k)
+
+
+@pytest.mark.parametrize("an", [(1, 1), (40, 32), (16, 40)])
+def test_edt_2d_black_border_is_a_2d_transform(an):
+    """edt.edt on a 2-D array with black_border=True (kimimaro/intake.py:568): the distance to the nearest other
+    label or to the frame of the PLANE -- equal to scipy's EDT of the zero-padded plane; a third axis does not exist
+    (an (sx, sy, 1) transform with a z pass would cap every value at wz)."""
+    import scipy.ndimage as ndi
+    m = np.zeros((21, 17), np.uint8, order="F")
+    m[2:19, 3:14] = 1
+    m[8:12, 0:17] = 1
+    m[0:21, 7:9] = 1
+    got = K.edt(m, an, black_border=True)
+    want = ndi.distance_transform_edt(np.pad(m, 1), sampling=an)[1:-1, 1:-1]
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    assert got.max() > 3 * min(an)
+
+
+def test_compute_border_targets_nonconvex_face():
+    """oracle.border.compute_border_targets on faces where the distance maximum (not only the tie-breaker) decides:
+    an L-shaped and a ring-shaped component; the target of every face is the arg-max of scipy's padded 2-D EDT."""
+    import scipy.ndimage as ndi
+    from oracle import border as B
+    lab = np.zeros((24, 20, 6), np.uint32, order="F")
+    lab[1:22, 2:7, :] = 7          # L shape: thick stem ...
+    lab[14:22, 2:18, :] = 7        # ... and thicker foot
+    an = (16, 16, 40)
+    cc, _ = K.connected_components(lab)
+    t = B.compute_border_targets(cc, an, K.edt, K.connected_components)
+    face = (lab[:, :, 0] > 0).astype(np.uint8)
+    dt = ndi.distance_transform_edt(np.pad(face, 1), sampling=an[:2])[1:-1, 1:-1]
+    best = np.argwhere(dt == dt.max())
+    comp = int(cc[best[0][0], best[0][1], 0])
+    pts = {tuple(int(v) for v in p) for p in t[comp]}
+    assert any(p[2] == 0 and dt[p[0], p[1]] == dt.max() for p in pts), (pts, best)
+    assert dt.max() > 16 * 2
 
 
 def _expected_corner_cube(coord, radius, shape, anisotropy=(1.0, 1.0, 1.0)):
