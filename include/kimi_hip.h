@@ -185,13 +185,14 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * std::priority_queue otherwise.  The sweep needs: level_rank = u32 [ra, rb, rc] table (x fastest) of the rank of
  * the key of offset (a, b, c) among the distinct keys (kh_level_keys + sort/unique by the caller), cstate = one
  * zeroed u64 per voxel (zero again on exit), event_arena = 256-byte aligned scratch addressed by ev_offset /
- * ev_chunks / ev_shift / nlev of each task; max_nlev = the largest task.nlev (sizes the LDS of the launch,
- * <= KH_SWEEP_MAX_LEVELS).  level_rank == NULL switches the sweep off (heap emulation only).
+ * ev_chunks / ev_shift / nlev of each task; max_nlev = the largest task.nlev that is <= KH_SWEEP_LDS_LEVELS (sizes
+ * the LDS of the launch); a task with more levels keeps its 4-byte level words and the bitmap (nlev / 8 bytes), rounded
+ * up to 256 bytes, at the front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.                                                  */
 #define KH_TRACE_PROFILE 1
-#define KH_SWEEP_MAX_LEVELS 24576
+#define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,

@@ -45,7 +45,8 @@ LABEL_T = np.dtype([
     ("stat_sweep_why", "<u4"),
 ])
 assert LABEL_T.itemsize == 184
-SWEEP_MAX_LEVELS = 24576  # KH_SWEEP_MAX_LEVELS
+SWEEP_LDS_LEVELS = 16384  # KH_SWEEP_LDS_LEVELS
+SWEEP_MAX_LEVELS = 1 << 22  # labels with more levels than this use the heap emulation only
 
 ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
            8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",

@@ -163,11 +163,14 @@ __global__ __launch_bounds__(256) void ccl_number_roots_kernel(const uint32_t* _
   }
 }
 
-__global__ __launch_bounds__(256) void ccl_relabel_kernel(const uint32_t* __restrict__ parent, int64_t n, uint32_t* out) {
+__global__ __launch_bounds__(256) void ccl_relabel_kernel(uint32_t* parent, int64_t n, uint32_t* out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const uint32_t p = parent[i];
-    if (p == CCL_NONE) out[i] = 0;
-    else if (p != (uint32_t)i) out[i] = out[p];  // roots were written by ccl_number_roots_kernel
+    const uint32_t p = ccl_ld(parent, (uint32_t)i);
+    if (p == CCL_NONE) { out[i] = 0; continue; }
+    if (p == (uint32_t)i) continue;             // roots were written by ccl_number_roots_kernel
+    // parent[i] is an ancestor but not necessarily the root: a path-halving store of another thread's find may have
+    // landed after the flatten pass wrote the root (seen on a 10^6-voxel component: a few voxels kept label 0)
+    out[i] = out[ccl_find(parent, (uint32_t)i)];
   }
 }
 

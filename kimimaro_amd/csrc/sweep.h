@@ -82,6 +82,11 @@ struct Sweep {
 
 
 __device__ __forceinline__ void sweep_bail(const Sweep& s, uint32_t why) { atomicOr(&s.sh->bail, why); }
+// The level words and the bitmap are updated with atomics (LDS, or L2 when they live in HBM): read them the same way,
+// a plain load could be served from a stale line of the CU's vector cache.
+__device__ __forceinline__ uint32_t sweep_ld(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // distance of voxel (qx, qy, qz) from the source, with the float operation order of dijkstra_invalidation.hpp:310-316
 __device__ __forceinline__ bool sweep_eval(const Sweep& s, const uint4 src, int qx, int qy, int qz, uint32_t& rk) {
@@ -111,7 +116,7 @@ __device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint
   uint32_t* word = &s.words[lv];
   const uint32_t CH = 1u << s.shift;
   for (;;) {
-    const uint32_t w = *reinterpret_cast<volatile uint32_t*>(word);
+    const uint32_t w = sweep_ld(word);
     const uint32_t fill = w & 1023u;
     if (fill < CH) {
       if (atomicCAS(word, w, w + 1u) != w) continue;
@@ -308,7 +313,7 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
       const uint32_t w0 = next_from >> 5;
       for (uint32_t base = w0; base < nwords; base += 64u) {
         const uint32_t idx = base + (uint32_t)lane;
-        uint32_t v = idx < nwords ? s.lvbits[idx] : 0u;
+        uint32_t v = idx < nwords ? sweep_ld(&s.lvbits[idx]) : 0u;
         if (idx == w0) v &= ~((1u << (next_from & 31u)) - 1u);
         const unsigned long long ball = __builtin_amdgcn_ballot_w64(v != 0u);
         if (ball) {
@@ -322,9 +327,8 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
         if (sh->bail) found = SW_NONE;   // the only place the loop's exit is decided: every thread reads sh->lvl
         sh->lvl = found;
         if (found != SW_NONE) {
-          const uint32_t w = s.words[found];
-          s.words[found] = EMPTY;
-          s.lvbits[found >> 5] &= ~(1u << (found & 31u));
+          const uint32_t w = atomicExch(&s.words[found], EMPTY);
+          atomicAnd(&s.lvbits[found >> 5], ~(1u << (found & 31u)));
           // the level's chunks, newest first (a chain of dependent loads: one per chunk)
           uint32_t n = 0;
           for (uint32_t id = w >> 10; id != SW_NOCHUNK; id = s.chunks[(size_t)id << s.shift].x) {

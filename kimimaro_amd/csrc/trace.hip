@@ -24,6 +24,8 @@
 // No MFMA: irregular, latency/atomic bound integer+f32 work (north_star).  Labels are independent, so
 // the chip is filled by running every label's workgroup concurrently; the largest labels keep two
 // chunks of their heap in LDS (kh_trace_paths n_large).
+#include <stdlib.h>
+
 #include "common.h"
 #include "sweep.h"
 
@@ -697,6 +699,7 @@ struct SweepGlobal {
   int ra, rb, rc;
   unsigned long long* cstate;   // one word per voxel, all zero on entry and on exit
   unsigned char* arena;         // event arenas (per label: kh_label_t.ev_offset, in units of 256 bytes)
+  uint32_t lds_levels;          // labels with more levels keep their level words in the arena instead of LDS
 };
 
 // One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
@@ -801,13 +804,17 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
     sw.np = sw.wa + sw.ncap;
     sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);
     unsigned char* ar = sg.arena + (size_t)task->ev_offset * 256u;
-    sw.chunks = reinterpret_cast<uint2*>(ar);
+    // level words + non-empty bitmap: LDS when they fit the launch's allotment, else the front of the arena (same
+    // code path: the pointers are generic)
+    const size_t wbytes = (((size_t)nlev * 4u + ((size_t)(nlev >> 5) + 2u) * 4u) + 255u) & ~(size_t)255u;
+    const bool in_lds = nlev <= sg.lds_levels;
+    sw.chunks = reinterpret_cast<uint2*>(in_lds ? ar : ar + wbytes);
     sw.chcap = task->ev_chunks;
     sw.shift = (int)task->ev_shift;
     sw.killed = q.a;                                         // the search work lists are free during an invalidation
     sw.nlev = nlev;
     sw.chain = reinterpret_cast<uint32_t*>(heap_top);
-    sw.words = sw.chain + SW_CHAIN;
+    sw.words = in_lds ? sw.chain + SW_CHAIN : reinterpret_cast<uint32_t*>(ar);
     sw.lvbits = sw.words + nlev;
     sw.sh = &swsh;
   }
@@ -1072,7 +1079,9 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
     KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(256), lds, st, tasks, lists, list_daf, nbrmask,
+  const char* thr_env = getenv("KH_TRACE_THREADS");   // developer knob
+  const unsigned nthreads = thr_env ? (unsigned)atoi(thr_env) : 256u;
+  hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
                      path_lengths, fix_branching, sg);
   KH_LAUNCH_CHECK();
@@ -1118,7 +1127,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
-  if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_MAX_LEVELS ||
+  if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
                      ((uintptr_t)event_arena & 255) != 0)) {
     set_error("kh_trace_paths: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
     return KH_EINVAL;
@@ -1130,6 +1139,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
+  sg.lds_levels = (uint32_t)max_nlev;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,

@@ -262,7 +262,8 @@ class Engine:
                 # ever used + about 12 events per voxel, with slack
                 shift = np.where(cnt >= 32768, 7, 6).astype(np.int64)
                 chunks = np.minimum(2 * nlev + ((20 * cnt) >> shift) + 64, (1 << 22) - 2)
-                units = np.where(nlev > 0, ((chunks * 8) << shift) // 256, 0)
+                wunits = np.where(nlev > _abi.SWEEP_LDS_LEVELS, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
+                units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
                 ev_total = int(units.sum())
                 self.last_arena_bytes = ev_total * 256
@@ -273,9 +274,10 @@ class Engine:
                 tasks["ev_offset"] = ev_off
                 tasks["ev_chunks"] = np.where(nlev > 0, chunks, 0)
                 tasks["ev_shift"] = shift
-                max_nlev = int(nlev.max())
-                if max_nlev == 0:
+                if int(nlev.max()) == 0:
                     d_rank = None
+                fits = nlev[nlev <= _abi.SWEEP_LDS_LEVELS]
+                max_nlev = int(fits.max()) if fits.size else 0
         tgt = []
         tgt_off = np.zeros(nl, dtype=np.int64)
         for s, o in enumerate(order):

@@ -80,3 +80,16 @@ def test_fill_voids_matches_binary_fill_holes(eng, shape, seed):
     got = d_out.cpu().numpy().reshape(shape, order="F").astype(bool)
     np.testing.assert_array_equal(got, want)
     assert n == int(want.sum() - m.sum())
+
+
+def test_ccl_one_huge_component_repeatable(eng):
+    """a single 10^6-voxel component (the reference's test_square plate): every voxel gets the component's id, run
+    after run (a path-halving store landing after the flatten pass once left a few voxels with label 0)."""
+    lab = np.ones((1000, 1000, 1), dtype=np.uint8, order="F")
+    lab[-1, 0] = 0
+    lab[0, -1] = 0
+    for _ in range(4):
+        d_cc, n, _ = eng.ccl(lab)
+        cc = d_cc.cpu().numpy().view(np.uint32)
+        assert n == 1
+        assert int(np.count_nonzero(cc == 1)) == 999998 and int(np.count_nonzero(cc == 0)) == 2

@@ -1,6 +1,7 @@
-"""The reference's end-to-end known-answer tests (automated_test.py) through the HIP product path.
-Sizes are reduced where one huge single label would make the (sequential per label) invalidation take
-minutes; every case is additionally compared with the oracle pipeline (bit exact)."""
+"""The reference's end-to-end known-answer tests (automated_test.py) through the HIP product path, at the
+reference's own sizes (test_square 1000 x 1000, test_cube 128^3, test_fix_borders_{z,x,y} 256^3, test_joinability
+256 x 256 x 20) with its own assertions; where the oracle pipeline is fast enough the result is additionally
+compared with it bit for bit."""
 import numpy as np
 import pytest
 
@@ -34,10 +35,10 @@ def test_empty_and_sparse(eng):  # automated_test.py:17-31
 
 
 @pytest.mark.parametrize("corners", ["anti", "main"])
-def test_square(eng, corners):  # :48-87 at 320x320
+def test_square(eng, corners):  # :48-87
     import kimimaro_amd
     from oracle import pipeline as P
-    n = 320
+    n = 1000
     labels = np.ones((n, n), dtype=np.uint8)
     if corners == "anti":
         labels[-1, 0] = 0
@@ -55,10 +56,10 @@ def test_square(eng, corners):  # :48-87 at 320x320
     same(skels, P.skeletonize(labels, teasar_params=TP, fix_borders=False))
 
 
-def test_cube(eng):  # :89-102 at 48^3
+def test_cube(eng):  # :89-102
     import kimimaro_amd
     from oracle import pipeline as P
-    n = 48
+    n = 128
     labels = np.ones((n, n, n), dtype=np.uint8)
     labels[0, 0, 0] = 0
     labels[-1, -1, -1] = 0
@@ -79,19 +80,49 @@ def test_solid_image_fix_borders(eng):  # :33-37 at 40^3 (black_border EDT, bord
     same(skels, P.skeletonize(labels, fix_borders=True))
 
 
-def test_fix_borders_z(eng):  # :116-143 at 96^3
+FB = dict(teasar_params={"const": 250, "scale": 10, "pdrf_exponent": 4, "pdrf_scale": 100000},
+          dust_threshold=1000, fix_branching=True, fix_borders=True)
+
+
+def test_fix_borders_z(eng):  # :116-143, the reference's exact expectation: a straight line through (129, 129, *)
+    import kimimaro_amd
+    labels = np.zeros((256, 256, 256), dtype=np.uint8)
+    labels[64:196, 64:196, :] = 128
+    skels = kimimaro_amd.skeletonize(labels, anisotropy=(40, 32, 20), _engine=eng, **FB)
+    skel = skels[128]
+    assert skel.space == "physical"
+    skel = skel.voxel_space()
+    assert np.all(skel.vertices[:, 0] == 129)
+    assert np.all(skel.vertices[:, 1] == 129)
+    assert np.all(skel.vertices[:, 2] == np.arange(256))
+    assert skel.space == "voxel"
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_fix_borders_x_y(eng, axis):  # :145-199
+    import kimimaro_amd
+    labels = np.zeros((256, 256, 256), dtype=np.uint8)
+    if axis == 0:
+        labels[:, 64:196, 64:196] = 128
+    else:
+        labels[64:196, :, 64:196] = 128
+    skel = kimimaro_amd.skeletonize(labels, anisotropy=(1, 1, 1), _engine=eng, **FB)[128]
+    for a in range(3):
+        want = np.arange(256) if a == axis else 129
+        assert np.all(skel.vertices[:, a] == want), a
+
+
+def test_fix_borders_z_matches_oracle(eng):  # the same shape at 96^3, bit exact against the oracle pipeline
     import kimimaro_amd
     from oracle import pipeline as P
     labels = np.zeros((96, 96, 96), dtype=np.uint8)
     labels[24:74, 24:74, :] = 128
-    kw = dict(teasar_params={"const": 250, "scale": 10, "pdrf_exponent": 4, "pdrf_scale": 100000},
-              anisotropy=(40, 32, 20), dust_threshold=1000, fix_branching=True, fix_borders=True)
-    skels = kimimaro_amd.skeletonize(labels, _engine=eng, **kw)
+    skels = kimimaro_amd.skeletonize(labels, anisotropy=(40, 32, 20), _engine=eng, **FB)
     skel = skels[128].voxel_space()
     assert np.all(skel.vertices[:, 0] == skel.vertices[0, 0])
     assert np.all(skel.vertices[:, 1] == skel.vertices[0, 1])
     assert np.all(skel.vertices[:, 2] == np.arange(96))
-    same(skels, P.skeletonize(labels, **kw))
+    same(skels, P.skeletonize(labels, anisotropy=(40, 32, 20), **FB))
 
 
 def test_parallel_quadrants(eng):  # :234-259 (4 labels; `parallel` has no meaning on one GPU)
@@ -119,20 +150,33 @@ def test_dimensions_and_object_ids(eng):  # :261-279
     assert list(skels.keys()) == [9]
 
 
-def test_joinability(eng):  # :281-333: two chunks with a 1-voxel overlap meet at the same face voxel iff fix_borders
+@pytest.mark.parametrize("axis", ["x", "y"])
+def test_joinability(eng, axis):  # :281-333: two chunks with a 1-voxel overlap meet at the same face voxel iff fix_borders
     import kimimaro_amd
-    from shapes import random_walk_tube
-    vol = random_walk_tube((64, 48, 48), 314, steps=80, step=3.0, radius=(2.5, 5.0)).astype(np.uint32)
-    a, b = vol[:33], vol[32:]
-    params = dict(TP)
-    params["const"] = 4
-    sa = kimimaro_amd.skeletonize(a, params, dust_threshold=50, fix_borders=True, _engine=eng)
-    sb = kimimaro_amd.skeletonize(b, params, dust_threshold=50, fix_borders=True, _engine=eng)
-    if 1 in sa and 1 in sb:
-        va = sa[1].vertices[sa[1].vertices[:, 0] == 32][:, 1:]
-        vb = sb[1].vertices[sb[1].vertices[:, 0] == 0][:, 1:]
-        if len(va) and len(vb):
-            assert {tuple(v) for v in va.tolist()} & {tuple(v) for v in vb.tolist()}
+    from kimimaro_amd.skeleton import Skeleton
+
+    def run(labels, fix_borders):
+        return kimimaro_amd.skeletonize(labels, {"const": 10, "scale": 10, "pdrf_exponent": 4, "pdrf_scale": 100000},
+                                        anisotropy=(1, 1, 1), dust_threshold=0, fix_branching=True, fix_borders=fix_borders,
+                                        _engine=eng)
+
+    labels = np.zeros((256, 256, 20), dtype=np.uint8)
+    if axis == "x":
+        labels[32:160, :, :] = 1
+    else:
+        labels[:, 32:160, :] = 1
+
+    def both(fix_borders):
+        s1 = run(labels[:, :, :10], fix_borders)[1]
+        s2 = run(labels[:, :, 9:], fix_borders)[1]
+        s2.vertices[:, 2] += 9
+        return Skeleton.simple_merge([s1, s2]).consolidate()
+
+    fb = both(True)
+    assert len(fb.components()) == 1
+    plain = both(False)
+    assert not (fb.vertices.shape == plain.vertices.shape and np.array_equal(fb.vertices, plain.vertices)
+                and np.array_equal(fb.edges, plain.edges))
 
 
 def test_full_size_c2_properties(eng):
