@@ -106,3 +106,23 @@ def test_assembler_merge_equals_simple_merge_consolidate():
         np.testing.assert_array_equal(got[orig].edges, want.edges)
         np.testing.assert_array_equal(got[orig].radii, want.radii)
         assert got[orig].id == orig and got[orig].space == "physical"
+
+
+def test_oracle_pool_equals_serial_oracle():
+    """oracle/pool.py (per-component work on a forked pool, DBF on the component's box grown by one voxel and cut back
+    to the reference's crop) gives exactly oracle.pipeline.skeletonize's result."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from shapes import voronoi_labels
+    from oracle import pool, pipeline as P
+    an = (16, 16, 40)
+    lab = voronoi_labels((48, 48, 24), 6, seed=3, pts_per_label=3, step=8.0, anisotropy=an)
+    params = dict(P.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 60
+    a, _, _ = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True, workers=2)
+    b = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True)
+    assert sorted(a) == sorted(b) and len(a) >= 3
+    for k in a:
+        np.testing.assert_array_equal(a[k].vertices, b[k].vertices)
+        np.testing.assert_array_equal(a[k].edges, b[k].edges)
+        np.testing.assert_array_equal(a[k].radii, b[k].radii)
