@@ -9,14 +9,17 @@ targets -> find_root -> DAF -> PDRF -> TEASAR path loop for every component -> D
 Skeleton assembly -> (N > 1) all-gather-v of the skeletons.  Only format_labels and the H2D copy of the
 input are outside the timed region (`preamble_s`).
 
-N > 1 (default --scaling weak): every rank holds and skeletonizes its own volume of the workload's size (rank 0's
-volume is broadcast once, rank r mirrors it along the axes given by the bits of r and offsets the label ids), value =
-components of all N volumes / max-over-ranks step time.  --scaling strong shards the components of ONE volume round robin
-over the ranks (BASELINE.json configs[3]); its wall clock is bounded by the largest component, see DESIGN.md section 6.
+N > 1 (default --scaling strong = BASELINE.json configs[3]): ONE volume, its connected components dealt over the ranks
+(largest first to the least loaded rank, kimimaro_amd.intake.shard_components), every rank recomputes the whole-volume
+preamble, the skeletons are all-gathered; value = components of the volume / max-over-ranks step time.  The same run
+then measures the weak mode as well (every rank its own volume of the workload's size: rank 0's volume mirrored along
+the axes given by the bits of r, label ids offset) and prints it as the extra object "weak_scaling".
 
 Workload (config.workload): "c3" = 512x512x512, 2124 chains, anisotropy (16,16,40), default
 teasar_params, dust_threshold=1000, fix_borders=True, fix_branching=True  (BASELINE.json configs[2],
-the configuration the metric is quoted on).  "c2" = 512x512x100 / 333 labels (configs[1]).
+the configuration the metric is quoted on).  "c2" = 512x512x100 / 333 labels (configs[1]).  "c5" = 1024^3, 8192
+chains, anisotropy (8,8,40) (configs[4]; needs the per-rank sharding of N >= 2 ranks: one GPU cannot hold the
+per-label scratch of all its components).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
@@ -45,6 +48,7 @@ WORKLOADS = {
     "c1": ((64, 64, 64), 8, 4, 1, (1, 1, 1)),
     "c2": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
     "c3": ((512, 512, 512), 2124, 16, 3, (16, 16, 40)),
+    "c5": ((1024, 1024, 1024), 8192, 24, 5, (8, 8, 40)),
     "mini": ((128, 128, 64), 40, 8, 4, (16, 16, 40)),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -98,11 +102,13 @@ def cpu_baseline(cc_labels, remapping, an, params, dust_threshold, budget_s=15.0
     vox = 0
     for sid in segids:
         slc = slices[sid - 1][::-1]
-        grown = tuple(slice(max(0, s.start - 1), min(n, s.stop + 1)) for s, n in zip(slc, cc_labels.shape))
+        glo = [max(0, s.start - 1) for s in slc]
+        grown = tuple(slice(g, min(n, s.stop + 1)) for g, s, n in zip(glo, slc, cc_labels.shape))
+        inner = tuple(slice(s.start - g, s.stop - g) for s, g in zip(slc, glo))
         crop = np.asfortranarray(cc_labels[grown])
-        dbf = oracle.edt(crop, an, black_border=False)
-        mask = crop == sid
-        dbf = np.where(mask, dbf, 0.0).astype(np.float32)
+        dbf = oracle.edt(crop, an, black_border=False)[inner]   # exact for the label's own voxels; traced on the reference's crop
+        mask = np.asfortranarray(crop[inner] == sid)
+        dbf = np.asfortranarray(np.where(mask, dbf, 0.0).astype(np.float32))
         P.trace(mask, dbf, anisotropy=an, fix_branching=True, **params)
         done += 1
         vox += int(counts[sid])
@@ -143,10 +149,11 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("KIMI_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-borders", action="store_true")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("KIMI_BENCH_SCALING", "weak"),
-                    help="N > 1: weak = every GPU skeletonizes its own volume of the workload's size (a mirrored copy "
-                         "with its own label ids; total work grows with N); strong = ONE volume, its components dealt "
-                         "round robin over the GPUs (BASELINE.json configs[3]; bounded by the largest component)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("KIMI_BENCH_SCALING", "strong"),
+                    help="N > 1: strong (default, BASELINE.json configs[3]) = ONE volume, its components dealt over the GPUs "
+                         "(largest first to the least loaded rank); weak = every GPU skeletonizes its own volume of the "
+                         "workload's size (a mirrored copy with its own label ids).  The mode that is not selected is "
+                         "measured as well (fewer steps) and printed as an extra object.")
     args = ap.parse_args()
 
     import torch
@@ -183,75 +190,94 @@ def main():
         shape0, _, _, _, an = WORKLOADS[args.workload]
         try:
             if rank == 0:
-                lab, an = make_volume(args.workload)
-                d_vol = eng.to_device(lab)
+                base_lab, an = make_volume(args.workload)
+                d_vol = eng.to_device(base_lab)
             else:
                 d_vol = torch.empty(int(np.prod(shape0)), dtype=torch.int32, device=eng.device)
             dist.broadcast(d_vol, src=0)
             if rank != 0:
-                lab = d_vol.cpu().numpy().view(np.uint32).reshape(shape0, order="F")
+                base_lab = d_vol.cpu().numpy().view(np.uint32).reshape(shape0, order="F")
             del d_vol
         except Exception as e:  # pragma: no cover
             print("bench: broadcast of the volume failed (%r); generating locally" % (e,), file=sys.stderr)
-            lab, an = make_volume(args.workload)
-        if args.scaling == "weak":
+            base_lab, an = make_volume(args.workload)
+    else:
+        base_lab, an = make_volume(args.workload)
+    an = np.asarray(an, dtype=np.float32)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    dust = 1000
+    fix_borders = not args.no_fix_borders
+    from collections import defaultdict
+    empty = defaultdict(list)
+    result = {}
+    state = {}
+
+    def prepare(mode):
+        """the label volume of this rank for `mode`, resident in HBM (outside the timed region)."""
+        lab = base_lab
+        if mode == "weak" and world > 1:
             # one volume per GPU: rank r works on the copy mirrored along the axes given by the bits of r (same object
             # statistics, same largest component, different geometry) with label ids of its own, so that the gathered
             # result holds the skeletons of all N volumes.  No component is shared between ranks.
             flips = [a for a in range(3) if (rank >> a) & 1]
             lab = np.asfortranarray(np.flip(lab, axis=flips)) if flips else lab
             lab = np.where(lab != 0, lab + np.uint32(1000000 * rank), 0).astype(np.uint32, order="F")
-    else:
-        lab, an = make_volume(args.workload)
-    shard_rank, shard_world = (rank, world) if args.scaling == "strong" else (0, 1)
-    shape = lab.shape
-    an = np.asarray(an, dtype=np.float32)
-    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
-    dust = 1000
-    fix_borders = not args.no_fix_borders
-
-    t = time.perf_counter()
-    lab = intake.format_labels(lab, in_place=True)
-    d_lab = eng.to_device(lab)  # the input volume is resident in HBM before the timed region
-    eng.sync()
-    preamble_s = time.perf_counter() - t
-    flat_lab = lab.reshape(-1, order="F")
-    from collections import defaultdict
-    empty = defaultdict(list)
-
-    result = {}
+        t = time.perf_counter()
+        lab = intake.format_labels(lab, in_place=True)
+        state["lab"] = lab
+        state["d_lab"] = eng.to_device(lab)  # the input volume is resident in HBM before the timed region
+        eng.sync()
+        state["flat"] = lab.reshape(-1, order="F")
+        state["shard"] = (rank, world) if mode == "strong" else (0, 1)
+        return time.perf_counter() - t
 
     def components():
-        d_cc, n, rep = eng.ccl_device(d_lab, lab.dtype.itemsize, shape)  # kimimaro/utility.py:58-83 on the GPU
-        orig = flat_lab[rep[1:].astype(np.int64)]
+        lab = state["lab"]
+        d_cc, n, rep = eng.ccl_device(state["d_lab"], lab.dtype.itemsize, lab.shape)  # kimimaro/utility.py:58-83 on the GPU
+        orig = state["flat"][rep[1:].astype(np.int64)]
         return d_cc, n, {i + 1: orig[i].item() for i in range(n)}
 
     def step():
         d_cc, nlabels, remapping = components()
-        cc = intake.LazyVolume(eng, d_cc, shape)
+        cc = intake.LazyVolume(eng, d_cc, state["lab"].shape)
         local = intake.skeletonize_cc(eng, cc, nlabels, remapping, params, an, dust, True, fix_borders,
-                                      empty, empty, black_border=False, rank=shard_rank, world=shard_world, d_cc=d_cc)
+                                      empty, empty, black_border=False, rank=state["shard"][0], world=state["shard"][1], d_cc=d_cc)
         if world > 1:
             local = gather_skeletons(local, device=eng.device if backend == "nccl" else None)
         result["skels"] = local
         return local
 
-    for _ in range(args.warmup):
-        step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def measure(warmup, steps):
+        for _ in range(warmup):
+            step()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed
+
+    # the other scaling mode first (short), the selected one last so that everything below describes the selected one
+    other = None
+    if world > 1:
+        omode = "weak" if args.scaling == "strong" else "strong"
+        prepare(omode)
+        osteps = max(1, min(args.steps, 2))
+        oel = measure(1, osteps)
+        other = {"mode": omode, "elapsed": oel, "steps": osteps, "skeletons": len(result["skels"])}
+    preamble_s = prepare(args.scaling)
+    elapsed = measure(args.warmup, args.steps)
+    lab = state["lab"]
+    shape = lab.shape
     nskel = len(result["skels"])
     d_cc, nlabels, remapping = components()
     cc_labels = eng.to_host_volume(d_cc, shape)
@@ -260,6 +286,13 @@ def main():
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     units = ncomp * (world if args.scaling == "weak" else 1)   # weak: every rank has a volume with the same component count
     value = units / (ms_per_step / 1e3)
+    if other is not None:
+        oms = other["elapsed"] / other["steps"] * 1e3
+        ounits = ncomp * (world if other["mode"] == "weak" else 1)
+        other = {"scaling": other["mode"], "value": round(ounits / (oms / 1e3), 3), "unit": "labels/s", "ms_per_step": round(oms, 3),
+                 "steps": other["steps"], "warmup": 1, "skeletons": other["skeletons"],
+                 "note": ("every GPU its own volume of the workload's size (mirrored copies, own label ids)" if other["mode"] == "weak"
+                          else "components of ONE volume dealt over the GPUs")}
 
     if rank != 0:
         if dist:
@@ -324,10 +357,19 @@ def main():
     settled = tk["stat_settled"].astype(np.float64).sum()
     trace_bytes = (4 + 9) * nf + 10 * nf + 12 * nf + 12 * nf + 12 * settled + 2 * nf
     tr_s = phases.get("paths", float("nan"))
+    calls = int(tk["stat_sweep_calls"].astype(np.int64).sum())
+    bails = int(tk["stat_sweep_bails"].astype(np.int64).sum())
+    sweep = {"invalidation_calls": calls, "certified": calls - bails, "fell_back_to_heap": bails,
+             "levels": int(tk["stat_sweep_levels"].astype(np.int64).sum()), "events": int(tk["stat_sweep_events"].astype(np.int64).sum()),
+             "labels_with_fallback": int(np.count_nonzero(tk["stat_sweep_bails"])),
+             "voxels_of_labels_with_fallback": int(tk["count"][tk["stat_sweep_bails"] > 0].astype(np.int64).sum()),
+             "voxels": int(tk["count"].astype(np.int64).sum()),
+             "note": "order-free level sweep (csrc/sweep.h); a call it cannot certify is redone by the exact heap emulation"}
     roofline_trace = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / tr_s / 1e9, 3),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / tr_s / 1e9 / HBM_PEAK_GBS, 6),
                       "traffic": None, "seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
-                      "note": "latency bound: exact emulation of the reference's sequential heap flood per label"}
+                      "note": "latency bound: level-synchronous sweep per label; the wall clock is the largest label whose call "
+                              "needed the exact heap emulation"}
 
     cpu = None
     cpu_all = None
@@ -352,11 +394,15 @@ def main():
                                   tuple(float(a) for a in an), fix_borders, dust),
                    "parallelism": ("one such volume per GPU (mirrored copies, own label ids) on %d GPU(s), no data-path "
                                    "collective, skeleton all-gather-v at the end" % world) if args.scaling == "weak" else
-                                  ("components of ONE volume round-robin over %d GPU(s), skeleton all-gather-v" % world)},
-        "skeletons": nskel, "preamble_s": round(preamble_s, 3), "phases_s": phases,
+                                  ("components of ONE volume dealt over %d GPU(s) (largest first to the least loaded rank), "
+                                   "skeleton all-gather-v" % world)},
+        "skeletons": nskel, "labels_per_s_by_label_count": round(nskel * (world if args.scaling == "weak" else 1) / (ms_per_step / 1e3), 3),
+        "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
     }
+    if other is not None:
+        line["weak_scaling" if other["scaling"] == "weak" else "strong_scaling"] = other
     print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
-"""Multi-GPU: one process per GPU, connected components sharded round robin (kimimaro/intake.py:388-389
-does the same over its process pool), finished skeletons collected with an all-gather-v.
+"""Multi-GPU: one process per GPU, the connected components of ONE volume dealt over the ranks (kimimaro/intake.py:388-389
+deals them round robin over its process pool; here largest first to the least loaded rank, intake.shard_components),
+finished skeletons collected with an all-gather-v.
 
 No data-path collective: every rank holds the whole label volume (768 MiB at 512^3 -- nothing next
 to 288 GB of HBM), computes the whole-volume EDT redundantly (sub-millisecond class work) and traces
@@ -19,7 +20,8 @@ from .skeleton import Skeleton
 
 def pack_skeletons(skels):
     """{label: Skeleton} -> bytes (npz container of flat arrays)."""
-    labels = np.array(sorted(skels.keys()), dtype=np.int64)
+    keys = sorted(int(k) for k in skels.keys())
+    labels = np.array(keys, dtype=np.uint64 if keys and keys[-1] >= 2 ** 63 else np.int64)   # segment ids may be uint64
     nv = np.array([skels[int(l)].vertices.shape[0] for l in labels], dtype=np.int64)
     ne = np.array([skels[int(l)].edges.shape[0] for l in labels], dtype=np.int64)
     cat = lambda parts, shape, dt: (np.concatenate(parts, axis=0) if parts else np.zeros(shape, dt))
@@ -80,6 +82,11 @@ def gather_skeletons(local, device=None):
     return merge_rank_results([unpack_skeletons(b) for b in blobs])
 
 
-def shard(items, rank, world):
-    """round robin, kimimaro/intake.py:388-389."""
-    return list(items)[rank::world]
+def shard(items, rank, world, weights=None):
+    """the items of rank `rank`: round robin like kimimaro/intake.py:388-389 without weights; with weights (voxel counts)
+    largest first to the least loaded rank (the rule of intake.shard_components)."""
+    items = list(items)
+    if weights is None:
+        return items[rank::world]
+    from .intake import shard_components
+    return shard_components(items, {i: w for i, w in zip(items, weights)}, rank, world)

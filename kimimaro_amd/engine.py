@@ -218,7 +218,7 @@ class Engine:
         q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
         # heap / path scratch are sized for the common case; a label that overflows them is traced again on its own
         # with `scratch_scale` times as much (below) -- the reference has no such limits
-        hcap = np.maximum((4 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256)  # (the sweep's lists live here too)
+        hcap = np.maximum((3 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256)  # (the sweep's lists live here too)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
         pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
@@ -261,7 +261,7 @@ class Engine:
                 # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
                 # ever used + about 12 events per voxel, with slack
                 shift = np.where(cnt >= 32768, 7, 6).astype(np.int64)
-                chunks = np.minimum(2 * nlev + ((20 * cnt) >> shift) + 64, (1 << 22) - 2)
+                chunks = np.minimum(nlev + nlev // 2 + ((14 * cnt) >> shift) + 64, (1 << 22) - 2)
                 wunits = np.where(nlev > _abi.SWEEP_LDS_LEVELS, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
                 units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)

@@ -211,6 +211,22 @@ def fill_all_holes_device(eng, d_cc, shape, nlabels):
     return filled_total
 
 
+def shard_components(cc_segids, counts, rank, world):
+    """The components rank `rank` of `world` traces.  The reference deals them round robin (kimimaro/intake.py:388-389:
+    cc_segids[i::parallel]); the cost of a component grows with its voxel count and the tail of the size distribution is
+    heavy, so here they are dealt largest first to the rank with the least voxels so far (LPT; ties -> lowest rank).
+    Deterministic: every rank computes the same assignment from the same counts."""
+    order = sorted(cc_segids, key=lambda s: (-int(counts[s]), s))
+    load = [0] * world
+    mine = []
+    for s in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += int(counts[s])
+        if r == rank:
+            mine.append(s)
+    return sorted(mine)
+
+
 def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                    fix_branching, fix_borders, before, after, black_border, timings=None,
                    rank=0, world=1, d_cc=None):
@@ -248,7 +264,7 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     params = dict(TRACE_DEFAULTS)
     params.update(teasar_params)
     if world > 1:
-        cc_segids = cc_segids[rank::world]  # intake.py:388-389 round robin
+        cc_segids = shard_components(cc_segids, counts, rank, world)
 
     soma_jobs = []
     segids, roots, tb, ta = [], [], [], []

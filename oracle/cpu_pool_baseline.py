@@ -28,11 +28,13 @@ def _task(sid):
     if sid == 0:
         return 0
     slc = _SLICES[sid - 1][::-1]
-    grown = tuple(slice(max(0, s.start - 1), min(n, s.stop + 1)) for s, n in zip(slc, _CC.shape))
+    glo = [max(0, s.start - 1) for s in slc]
+    grown = tuple(slice(g, min(n, s.stop + 1)) for g, s, n in zip(glo, slc, _CC.shape))
+    inner = tuple(slice(s.start - g, s.stop - g) for s, g in zip(slc, glo))
     crop = np.asfortranarray(_CC[grown])
-    dbf = oracle.edt(crop, _AN, black_border=False)
-    mask = crop == sid
-    dbf = np.where(mask, dbf, 0.0).astype(np.float32)
+    dbf = oracle.edt(crop, _AN, black_border=False)[inner]
+    mask = np.asfortranarray(crop[inner] == sid)
+    dbf = np.asfortranarray(np.where(mask, dbf, 0.0).astype(np.float32))
     P.trace(mask, dbf, anisotropy=_AN, fix_branching=True, **_PARAMS)
     return 1
 
