@@ -207,6 +207,20 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
  * float operation order of dijkstra_invalidation.hpp:310-316.  Device array of ra*rb*rc floats.              */
 int kh_level_keys(int64_t ra, int64_t rb, int64_t rc, float wx, float wy, float wz, float* keys, void* stream);
 
+/* ---- a9 on its own: kimimaro.skeletontricks.roll_invalidation_ball_inside_component(labels, DBF, scale, const,
+ * anisotropy, path) (skeletontricks.pyx:373-418 -> dijkstra_invalidation.hpp:239-332) for ONE object, the device routine
+ * of the path loop behind its own entry point.  task: a kh_label_t of the object (count, xmin, xmax, list_offset,
+ * q_offset / q_capacity, heap_offset / heap_capacity and the sweep fields as for kh_trace_paths); alive: u8 per voxel,
+ * 1 for the object's voxels that are still valid (mutated in place like the reference's `labels`); path: u32 linear
+ * indices of the path vertices; *invalidated (device int64) = number of voxels invalidated by the call.
+ * The ball radius of vertex v is f32(f32(scale * dbf[v]) + constant).  Sweep arguments as for kh_trace_paths.      */
+int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask,
+                       int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                       const float* dbf, uint8_t* alive, uint32_t* queues, void* heap_nodes,
+                       const uint32_t* path, int64_t npath, float scale, float constant,
+                       const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
+                       uint64_t* cstate, void* event_arena, int64_t* invalidated, void* stream);
+
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);
 int kh_fill_u8(uint8_t* p, int64_t n, int v, void* stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
 SYMBOLS = [
     "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_nd", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
     "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
-    "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
+    "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_invalidate_ball", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
 
 
@@ -87,6 +87,8 @@ def lib():
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
                                  f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, ci, ci, vp]
+    L.kh_invalidate_ball.argtypes = [vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, i64, f32, f32,
+                                     vp, i64, i64, i64, i64, vp, vp, vp, vp]
     L.kh_level_keys.argtypes = [i64, i64, i64, f32, f32, f32, vp, vp]
     L.kh_fill_f32.argtypes = [vp, i64, f32, vp]
     L.kh_fill_u8.argtypes = [vp, i64, ci, vp]

@@ -738,6 +738,40 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   return c;
 }
 
+// thread 0: fill the workgroup's Sweep record for `task` (LDS carve-out `lds` = the dynamic shared memory)
+__device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* ctl, const SweepGlobal& sg, const kh_label_t* task,
+                                            const uint32_t* nbrmask, uint8_t* alive, hnode_t* heap_node, uint32_t* killed,
+                                            uint32_t nf, unsigned char* lds) {
+  const uint32_t nlev = task->nlev;
+  sw.g = &ctl->g;
+  sw.nbrmask = nbrmask;
+  sw.alive = alive;
+  sw.cstate = sg.cstate;
+  sw.rank = nlev ? sg.rank : nullptr;
+  sw.ra = sg.ra; sw.rb = sg.rb;
+  // the heap's HBM slice (>= 3 * nf + 256 nodes of 16 bytes) is free while the sweep runs: source records
+  // (<= nf), then the three lists of the current level (nf + 64 entries each)
+  sw.srcs = reinterpret_cast<const uint4*>(heap_node);
+  sw.ncap = nf + 64u;
+  sw.wa = reinterpret_cast<unsigned long long*>(heap_node + nf);
+  sw.np = sw.wa + sw.ncap;
+  sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);
+  unsigned char* ar = sg.arena + (size_t)task->ev_offset * 256u;
+  // level words + non-empty bitmap: LDS when they fit the launch's allotment, else the front of the arena (same
+  // code path: the pointers are generic)
+  const size_t wbytes = (((size_t)nlev * 4u + ((size_t)(nlev >> 5) + 2u) * 4u) + 255u) & ~(size_t)255u;
+  const bool in_lds = nlev <= sg.lds_levels;
+  sw.chunks = reinterpret_cast<uint2*>(in_lds ? ar : ar + wbytes);
+  sw.chcap = task->ev_chunks;
+  sw.shift = (int)task->ev_shift;
+  sw.killed = killed;                                      // the search work lists are free during an invalidation
+  sw.nlev = nlev;
+  sw.chain = reinterpret_cast<uint32_t*>(lds);
+  sw.words = in_lds ? sw.chain + SW_CHAIN : reinterpret_cast<uint32_t*>(ar);
+  sw.lvbits = sw.words + nlev;
+  sw.sh = swsh;
+}
+
 template <bool PROF, int TOPL>
 __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
@@ -789,34 +823,7 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
   if (tid == 0) {
     ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    const uint32_t nlev = task->nlev;
-    sw.g = &ctl.g;
-    sw.nbrmask = nbrmask;
-    sw.alive = alive;
-    sw.cstate = sg.cstate;
-    sw.rank = nlev ? sg.rank : nullptr;
-    sw.ra = sg.ra; sw.rb = sg.rb;
-    // the heap's HBM slice (4 * nf + 1024 nodes of 16 bytes) is free while the sweep runs: source records
-    // (<= nf), then the three lists of the current level (nf + 64 entries each)
-    sw.srcs = reinterpret_cast<const uint4*>(heap.node);
-    sw.ncap = nf + 64u;
-    sw.wa = reinterpret_cast<unsigned long long*>(heap.node + nf);
-    sw.np = sw.wa + sw.ncap;
-    sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);
-    unsigned char* ar = sg.arena + (size_t)task->ev_offset * 256u;
-    // level words + non-empty bitmap: LDS when they fit the launch's allotment, else the front of the arena (same
-    // code path: the pointers are generic)
-    const size_t wbytes = (((size_t)nlev * 4u + ((size_t)(nlev >> 5) + 2u) * 4u) + 255u) & ~(size_t)255u;
-    const bool in_lds = nlev <= sg.lds_levels;
-    sw.chunks = reinterpret_cast<uint2*>(in_lds ? ar : ar + wbytes);
-    sw.chcap = task->ev_chunks;
-    sw.shift = (int)task->ev_shift;
-    sw.killed = q.a;                                         // the search work lists are free during an invalidation
-    sw.nlev = nlev;
-    sw.chain = reinterpret_cast<uint32_t*>(heap_top);
-    sw.words = in_lds ? sw.chain + SW_CHAIN : reinterpret_cast<uint32_t*>(ar);
-    sw.lvbits = sw.words + nlev;
-    sw.sh = &swsh;
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top);
   }
   __syncthreads();
   if (soma) {
@@ -995,6 +1002,47 @@ __global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// a9 on its own: roll_invalidation_ball_inside_component (skeletontricks.pyx:373-418) for ONE object, the same device
+// routine the path loop uses (order-free sweep, heap emulation as the fall-back).
+__global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, const uint32_t* __restrict__ lists,
+                                                              const uint32_t* __restrict__ nbrmask, Geometry g,
+                                                              const float* __restrict__ dbf, uint8_t* alive, uint32_t* queues,
+                                                              hnode_t* heap_nodes, const uint32_t* __restrict__ path, uint32_t npath,
+                                                              float scale, float constant, SweepGlobal sg, long long* invalidated) {
+  __shared__ Ctl ctl;
+  __shared__ Sweep sw;
+  __shared__ SweepShared swsh;
+  __shared__ uint32_t sweep_stats[5];
+  extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t nf = task->count;
+  Heap<1> heap;
+  heap.node = heap_nodes + task->heap_offset;
+  heap.top = (lds_hnode_t*)heap_top;
+  heap.cap = task->heap_capacity;
+  heap.n = 0;
+  heap_init_lane(heap, lane);
+  if (tid == 0) {
+    ctl.status = 0; ctl.u1 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
+    for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top);
+  }
+  __syncthreads();
+  const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+                                               lists + task->list_offset, nf, sweep_stats);
+  if (tid == 0) {
+    *invalidated = (long long)c;
+    task->status |= ctl.status;
+    task->stat_heap_pushes = ctl.u3;
+    task->stat_sweep_calls = sweep_stats[0];
+    task->stat_sweep_bails = sweep_stats[1];
+    task->stat_sweep_levels = sweep_stats[2];
+    task->stat_sweep_events = sweep_stats[3];
+    task->stat_sweep_why = sweep_stats[4];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a10: roll_invalidation_cube.  One workgroup per path vertex; bytes are cleared with a 32-bit
 // atomicAnd so each voxel is counted exactly once however many boxes overlap.
 __global__ __launch_bounds__(256) void invalidate_cube_kernel(uint8_t* mask, const float* __restrict__ dbf, int sx, int sy,
@@ -1148,6 +1196,42 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
               : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                     scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
                                     (uint32_t)max_nlev);
+}
+
+extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,
+                                  int64_t sz, float wx, float wy, float wz, const float* dbf, uint8_t* alive, uint32_t* queues,
+                                  void* heap_nodes, const uint32_t* path, int64_t npath, float scale, float constant,
+                                  const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
+                                  uint64_t* cstate, void* event_arena, int64_t* invalidated, void* stream) {
+  if (int rc2 = require_device()) return rc2;
+  if (!task || !lists || !nbrmask || !dbf || !alive || !queues || !heap_nodes || !path || !invalidated || npath < 0 ||
+      npath >= (1ll << 32) || sx * sy * sz >= (1ll << 32) || ((uintptr_t)heap_nodes & 15) != 0) {
+    set_error("kh_invalidate_ball: bad arguments");
+    return KH_EINVAL;
+  }
+  if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
+                     ((uintptr_t)event_arena & 255) != 0)) {
+    set_error("kh_invalidate_ball: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
+    return KH_EINVAL;
+  }
+  Geometry g;
+  make_geometry(g, sx, sy, sz, wx, wy, wz);
+  SweepGlobal sg;
+  sg.rank = level_rank;
+  sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
+  sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
+  sg.arena = reinterpret_cast<unsigned char*>(event_arena);
+  sg.lds_levels = (uint32_t)max_nlev;
+  size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
+  if (level_rank && swl > lds) lds = swl;
+  if (lds > 48 * 1024)
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&invalidate_ball_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(invalidate_ball_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, task, lists, nbrmask, g, dbf, alive, queues,
+                     (hnode_t*)heap_nodes, path, (uint32_t)npath, scale, constant, sg, (long long*)invalidated);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
 }
 
 extern "C" int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,

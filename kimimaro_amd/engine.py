@@ -186,6 +186,89 @@ class Engine:
             self._level_tables[key] = hit
         return hit[0], hit[1], hit[2], covered
 
+    # -- one binary object on its own (the function-level mirrors of ops.py) ---------------
+    def single_object(self, mask, anisotropy, rmax=0.0, dbf=None):
+        """Device context of ONE binary object given as a host mask (x, y, z; Fortran order): component volume (0 / 1),
+        voxel list, neighbour masks, per-label scratch and -- for ball radii up to `rmax` -- the level table and the
+        event arena of the invalidation sweep.  Returns a dict of device tensors + the kh_label_t record."""
+        t = self.torch
+        lib = self.lib
+        P = self.ptr
+        m = np.asarray(mask)
+        while m.ndim < 3:
+            m = m[..., np.newaxis]
+        shape = tuple(int(v) for v in m.shape)
+        nvox = shape[0] * shape[1] * shape[2]
+        cc = np.asfortranarray((m != 0).astype(np.uint32))
+        d_cc = self.to_device(cc)
+        d_dbf = self.to_device(np.asfortranarray(dbf, dtype=np.float32).reshape(shape, order="F")) if dbf is not None \
+            else t.zeros(nvox, dtype=t.float32, device=self.device)
+        counts, dbf_max, first, xmin, xmax = self.label_stats(d_cc, 4, d_dbf, shape, 1)
+        cnt = int(counts[1])
+        task = np.zeros(1, dtype=_abi.LABEL_T)
+        task["segid"] = 1
+        task["count"] = cnt
+        # the reference runs on the array it is given: the x faces of THAT array matter to the heap order
+        # (dijkstra_invalidation.hpp:116-123), not the object's own extent
+        task["xmin"], task["xmax"] = 0, shape[0] - 1
+        task["source"] = first[1]
+        task["root"] = NONE32
+        task["q_capacity"] = cnt + 64
+        hcap = 27 * cnt + 4096          # every push of the flood fits: a voxel is pushed by at most 26 neighbours
+        task["heap_capacity"] = hcap
+        task["path_capacity"] = 4 * cnt + 1024
+        ctx = {"shape": shape, "nvox": nvox, "count": cnt, "d_cc": d_cc, "d_dbf": d_dbf, "dbf_max": float(dbf_max[1])}
+        d_slot = t.from_numpy(np.array([-1, 0], dtype=np.int32)).to(self.device)
+        d_off = t.zeros(1, dtype=t.int32, device=self.device)
+        d_cur = self.empty(1, t.int32)
+        d_lists = self.empty(max(cnt, 1), t.int32)
+        d_nbr = self.empty(nvox, t.int32)
+        st = self.stream()
+        _abi.check(lib.kh_scatter_lists(P(d_cc), 4, nvox, P(d_slot), 1, P(d_off), P(d_cur), P(d_lists), st))
+        _abi.check(lib.kh_neighbor_mask(P(d_cc), 4, shape[0], shape[1], shape[2], P(d_nbr), st))
+        ctx.update(d_slot=d_slot, d_lists=d_lists, d_nbr=d_nbr, d_queues=self.empty(4 * (cnt + 64), t.int32),
+                   d_heap=self.empty(2 * hcap, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
+        d_rank, rdims, max_nlev, ev_units = None, (0, 0, 0), 0, 0
+        rmax = float(np.float32(rmax))
+        if self.sweep and cnt > 0 and np.isfinite(rmax) and rmax > 0:
+            d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, rmax)
+            nlev = int(np.searchsorted(keys, np.float32(rmax), side="left"))
+            if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
+                shift = 7 if cnt >= 32768 else 6
+                chunks = min(nlev + nlev // 2 + ((14 * cnt) >> shift) + 64, (1 << 22) - 2)
+                wunits = (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256 if nlev > _abi.SWEEP_LDS_LEVELS else 0
+                ev_units = wunits + ((chunks * 8) << shift) // 256
+                task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
+                max_nlev = nlev if nlev <= _abi.SWEEP_LDS_LEVELS else 0
+            else:
+                d_rank = None
+        d_arena = self.empty(max(ev_units, 1) * 32 + 32, t.int64)
+        ctx.update(d_rank=d_rank, rdims=rdims, max_nlev=max_nlev, d_arena=d_arena,
+                   arena_ptr=C.c_void_p((d_arena.data_ptr() + 255) & ~255),
+                   d_cstate=t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device),
+                   d_task=t.from_numpy(task.view(np.uint8).reshape(-1).copy()).to(self.device), task=task)
+        return ctx
+
+    def invalidate_ball(self, ctx, d_alive, path_locs, scale, const, anisotropy):
+        """kh_invalidate_ball on the object of `ctx` (Engine.single_object): d_alive (u8, device) is mutated.
+        Returns (voxels invalidated, task record after the call)."""
+        t = self.torch
+        P = self.ptr
+        shape = ctx["shape"]
+        d_path = t.from_numpy(np.asarray(path_locs, dtype=np.uint32).view(np.int32).copy()).to(self.device)
+        d_cnt = t.zeros(1, dtype=t.int64, device=self.device)
+        rank_ptr = P(ctx["d_rank"]) if ctx["d_rank"] is not None else C.c_void_p(0)
+        rd = ctx["rdims"]
+        _abi.check(self.lib.kh_invalidate_ball(P(ctx["d_task"]), P(ctx["d_lists"]), P(ctx["d_nbr"]), shape[0], shape[1], shape[2],
+                                               float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(ctx["d_dbf"]),
+                                               P(d_alive), P(ctx["d_queues"]), P(ctx["d_heap"]), P(d_path), int(d_path.numel()),
+                                               np.float32(scale), np.float32(const), rank_ptr, rd[0], rd[1], rd[2], ctx["max_nlev"],
+                                               P(ctx["d_cstate"]), ctx["arena_ptr"], P(d_cnt), self.stream()))
+        task = ctx["d_task"].cpu().numpy().view(_abi.LABEL_T).copy()
+        if int(task["status"][0]):
+            raise _abi.KimiHipError("kh_invalidate_ball: %s" % _abi.describe_status(int(task["status"][0])))
+        return int(d_cnt.item()), task
+
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
                    xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,

@@ -75,3 +75,28 @@ def roll_invalidation_cube(labels, DBF, path, scale, const, anisotropy=(1, 1, 1)
                                           eng.ptr(d_cnt), eng.stream()))
     flat[...] = d_mask.cpu().numpy()
     return int(d_cnt.item()), labels
+
+
+def roll_invalidation_ball_inside_component(labels, DBF, scale, const, anisotropy=(1, 1, 1), path=(), voxel_connectivity_graph=None):
+    """kimimaro.skeletontricks.roll_invalidation_ball_inside_component (skeletontricks.pyx:373-418), call site
+    kimimaro/trace.py:253-259: `labels` (uint8 / bool, Fortran order) is the mask of ONE object and is zeroed in place
+    inside the rolling ball of every path vertex (radius scale * DBF[v] + const); returns (invalidated, labels)."""
+    if voxel_connectivity_graph is not None:
+        raise NotImplementedError("voxel_connectivity_graph")
+    if not labels.flags.f_contiguous:
+        raise ValueError("roll_invalidation_ball_inside_component: labels must be Fortran ordered (skeletontricks.pyx:398)")
+    eng = engine()
+    lab = labels.view(np.uint8)
+    dbf = np.asfortranarray(DBF, dtype=np.float32)
+    pts = np.asarray(path, dtype=np.int64).reshape(-1, 3)
+    if pts.shape[0] == 0:
+        return 0, labels
+    sx, sy = lab.shape[0], lab.shape[1]
+    locs = pts[:, 0] + sx * (pts[:, 1] + sy * pts[:, 2])
+    f = np.float32
+    radii = (f(scale) * dbf.reshape(-1, order="F")[locs]).astype(np.float32) + f(const)     # f32 ops, pyx:393-395
+    ctx = eng.single_object(lab, anisotropy, rmax=float(radii.max()), dbf=dbf)
+    d_alive = eng.torch.from_numpy(np.ascontiguousarray(lab.reshape(-1, order="F"))).to(eng.device)
+    cnt, _ = eng.invalidate_ball(ctx, d_alive, locs, scale, const, anisotropy)
+    lab.reshape(-1, order="F")[...] = d_alive.cpu().numpy()
+    return cnt, labels

@@ -252,7 +252,136 @@ def gen_edt():
     print("edt_scipy:", n)
 
 
-if __name__ == "__main__":
+# ---------------------------------------------------------------------------------------------------------------
+# trace_paths.npz: the reference's OWN trace() (kimimaro/trace.py:36-267, loaded from /root/reference) run on small
+# shapes.  Its skeletontricks is the compiled reference (oracle/_ref: the real heap invalidation, the real
+# CachedTargetFinder, zero2inf / inf2zero); its missing third-party imports are stubbed with the oracle's
+# restatements (edt.edt -> oracle.edt, dijkstra3d.* -> oracle, fill_voids.fill -> scipy stand-in, osteoid.Skeleton ->
+# oracle.skeleton.Skeleton).  What is pinned is therefore the CONTROL FLOW of trace() / compute_paths() (target
+# stacks, soma branch, max_paths, rail edits, invalidation calls) as the reference executes it.  Only inputs and the
+# resulting path lists are stored.
+def load_reference_trace_full(st):
+    import scipy.ndimage
+    import oracle as K
+    from oracle.skeleton import Skeleton
+
+    edt = types.ModuleType("edt")
+    edt.edt = lambda labels, anisotropy=(1, 1, 1), black_border=False, voxel_graph=None, parallel=1: K.edt(labels, anisotropy, bool(black_border))
+    fv = types.ModuleType("fill_voids")
+
+    def fill(labels, in_place=True, return_fill_count=True):
+        filled = scipy.ndimage.binary_fill_holes(labels)
+        n = int(np.count_nonzero(filled)) - int(np.count_nonzero(labels))
+        out = np.asfortranarray(filled.astype(labels.dtype))
+        return (out, n) if return_fill_count else out
+    fv.fill = fill
+    d3 = types.ModuleType("dijkstra3d")
+    d3.euclidean_distance_field = lambda labels, source, anisotropy=(1, 1, 1), free_space_radius=0, voxel_graph=None, return_max_location=False: \
+        K.euclidean_distance_field(labels, source, anisotropy, free_space_radius)
+    class Parents:   # dijkstra3d.parental_field's result, as the oracle represents it (field + its distance field)
+        def __init__(self, field, source):
+            self.field, self.source = np.asfortranarray(field), tuple(int(v) for v in source)
+            self.dist = K.field_distances(field, source)
+
+        def __setitem__(self, key, value):   # trace.py:220 clears the root's parent (a no-op here) whatever the mode
+            assert tuple(int(v) for v in key) == self.source and value == 0
+    d3.parental_field = lambda field, source, voxel_graph=None: Parents(field, source)
+    d3.path_from_parents = lambda parents, target: K.path_to_source(parents.field, parents.dist, parents.source, tuple(int(v) for v in target))
+    d3.railroad = lambda field, source, voxel_graph=None: K.railroad(field, tuple(int(v) for v in source))
+    ost = types.ModuleType("osteoid")
+    ost.Skeleton = Skeleton
+    for name, mod in (("edt", edt), ("fill_voids", fv), ("dijkstra3d", d3), ("osteoid", ost)):
+        sys.modules[name] = mod
+    pkg = types.ModuleType("kimimaro")
+    pkg.__path__ = []
+    pkg.skeletontricks = st
+    sys.modules["kimimaro"] = pkg
+    sys.modules["kimimaro.skeletontricks"] = st
+    spec = importlib.util.spec_from_file_location("kimimaro.trace", os.path.join(REF, "kimimaro", "trace.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_trace_paths(st):
+    import oracle as K
+    from oracle import pipeline as P
+    from shapes import soma_shape, voronoi_labels
+    trace = load_reference_trace_full(st)
+    captured = []
+    real_from_path = sys.modules["osteoid"].Skeleton.from_path
+
+    def spy(path):
+        captured.append(np.asarray(path, dtype=np.int64).reshape(-1, 3).copy())
+        return real_from_path(path)
+    sys.modules["osteoid"].Skeleton.from_path = staticmethod(spy)
+    cases = {}
+    n = 0
+    skipped = 0
+    specs = []
+    for t in range(30):
+        an = [(1, 1, 1), (16, 16, 40), (40, 32, 20)][t % 3]
+        kw = dict(scale=[1.5, 4, 0.5][t % 3], const=[an[0] * 2, an[0] * 0.5, an[0] * 5][(t // 3) % 3], pdrf_scale=100000, pdrf_exponent=4,
+                  fix_branching=(t % 4 != 3))
+        if t % 5 == 4:
+            kw["max_paths"] = 3
+        specs.append(("tube", 700 + t, an, kw))
+    for hole in (False, True):
+        specs.append(("soma", hole, (1, 1, 1), dict(scale=1.5, const=3, pdrf_scale=100000, pdrf_exponent=4, soma_detection_threshold=6,
+                                                     soma_acceptance_threshold=10, soma_invalidation_scale=1.0, soma_invalidation_const=2,
+                                                     fix_branching=True)))
+    for kind, seed, an, kw in specs:
+        if kind == "tube":
+            m = random_walk_tube((40, 36, 30), seed, steps=45, step=3.0, radius=(1.3, 4.5))
+            cc, _ = K.connected_components(m)
+            big = np.argmax(np.bincount(cc.ravel())[1:]) + 1
+            m = np.asfortranarray((cc == big).astype(np.uint8))
+        else:
+            m = np.asfortranarray(soma_shape(hole=seed).astype(np.uint8))
+        dbf = K.edt(m, an, black_border=bool(np.all(m)))
+        idx = np.flatnonzero(m.ravel(order="F"))
+        rng = np.random.default_rng(1000 + n)
+        extra = {}
+        if kind == "tube" and n % 3 == 1:     # manual targets / forced root (intake.py:486-492)
+            pts = K.locs_to_pts(rng.choice(idx, 3, replace=False), m.shape)
+            extra = dict(root=tuple(int(v) for v in pts[0]), manual_targets_before=[tuple(int(v) for v in pts[1])],
+                         manual_targets_after=[tuple(int(v) for v in pts[2])])
+        del captured[:]
+        call = dict(kw)
+        call.update({k: (list(v) if isinstance(v, list) else v) for k, v in extra.items()})
+        skel = trace.trace(m.astype(bool).copy(order="F"), dbf.copy(order="F"), anisotropy=an, **call)
+        ref_paths = [p.copy() for p in captured]
+        # the oracle on the same input: tie orders the reference leaves to numpy's unstable argsort can differ
+        call2 = dict(kw)
+        call2.update({k: (list(v) if isinstance(v, list) else v) for k, v in extra.items()})
+        mine = P.trace(m.astype(bool).copy(order="F"), dbf.copy(order="F"), anisotropy=an, return_paths=True, **call2)
+        same = len(mine) == len(ref_paths) and all(np.array_equal(np.asarray(a), b) for a, b in zip(mine, ref_paths))
+        if not same:
+            skipped += 1
+            k = next((i for i, (a, b) in enumerate(zip(mine, ref_paths)) if not np.array_equal(np.asarray(a), b)), min(len(mine), len(ref_paths)))
+            print("  case %s/%s: oracle differs from the reference run (%d vs %d paths, first difference at path %d: targets %s vs %s) -- not stored"
+                  % (kind, seed, len(mine), len(ref_paths), k, np.asarray(mine[k])[-1].tolist() if k < len(mine) else None, ref_paths[k][-1].tolist() if k < len(ref_paths) else None))
+            continue
+        cases["mask_%d" % n] = np.packbits(m.ravel(order="F"))
+        cases["shape_%d" % n] = np.array(m.shape)
+        cases["an_%d" % n] = np.array(an, np.float32)
+        cases["kw_%d" % n] = np.array(repr(sorted(kw.items())))
+        cases["extra_%d" % n] = np.array(repr(sorted(extra.items())))
+        cases["npaths_%d" % n] = np.array(len(ref_paths))
+        cases["lens_%d" % n] = np.array([len(p) for p in ref_paths], np.int64)
+        cases["verts_%d" % n] = np.concatenate(ref_paths).astype(np.int32) if ref_paths else np.zeros((0, 3), np.int32)
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "trace_paths.npz"), **cases)
+    print("trace_paths:", n, "stored,", skipped, "skipped")
+
+
+
+if __name__ == "__main__" and "trace_paths" in sys.argv[1:]:
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    gen_trace_paths(st)
+elif __name__ == "__main__":
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
     trace = load_reference_trace(st)
@@ -262,3 +391,5 @@ if __name__ == "__main__":
     gen_pdrf(trace)
     gen_border(st)
     gen_edt()
+
+

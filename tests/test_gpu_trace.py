@@ -341,3 +341,51 @@ def test_skeletonize_2d_bool_with_extra_targets(eng):
     assert sorted(got.keys()) == sorted(want.keys()) == [1]
     np.testing.assert_array_equal(got[1].vertices, want[1].vertices)
     np.testing.assert_array_equal(got[1].edges, want[1].edges)
+
+
+def test_trace_matches_reference_trace_goldens(eng):
+    """kimimaro_amd.trace.trace (the HIP path for one object) against the path lists of the reference's OWN trace()
+    (tests/golden/trace_paths.npz, kimimaro/trace.py:36-267 executed in the build container): control flow of
+    compute_paths incl. target stacks, max_paths, both branching modes and the soma branch."""
+    import kimimaro_amd.trace as T
+    import oracle
+    from golden_trace import cases
+    seen = 0
+    for i, mask, an, kw, extra, want in cases():
+        dbf = oracle.edt(mask, an, black_border=bool(np.all(mask)))
+        got = T.trace(mask.astype(bool), dbf, anisotropy=an, return_paths=True, _engine=eng, **kw,
+                      **{k: (list(v) if isinstance(v, list) else v) for k, v in extra.items()})
+        assert len(got) == len(want), i
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(np.asarray(a), b, err_msg="case %d" % i)
+        seen += 1
+    assert seen >= 20
+
+
+@pytest.mark.parametrize("sweep", [True, False])
+def test_invalidate_ball_reference_goldens(sweep):
+    """kh_invalidate_ball (ops.roll_invalidation_ball_inside_component) on the 60 vectors made with the COMPILED
+    REFERENCE (tests/golden/invalidation_ball.npz, incl. the 99-voxel shadow case of SURVEY B-8): counts and masks bit
+    exact, through the order-free sweep (with its heap fall-back) and through the heap emulation alone."""
+    import os
+    from kimimaro_amd import ops
+    from kimimaro_amd.engine import Engine
+    eng2 = Engine()
+    eng2.sweep = sweep
+    ops._engine = eng2
+    try:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "invalidation_ball.npz"))
+        unpack = lambda b, shape: np.unpackbits(b)[: int(np.prod(shape))].reshape(shape, order="F").astype(np.uint8)
+        for i in range(int(z["n"])):
+            shape = tuple(int(v) for v in z["shape_%d" % i])
+            m = np.asfortranarray(unpack(z["mask_%d" % i], shape))
+            path = z["path_%d" % i]
+            dbf = np.zeros(shape, np.float32, order="F")
+            dbf[path[:, 0], path[:, 1], path[:, 2]] = z["dbfpath_%d" % i]
+            scale, const = z["sc_%d" % i]
+            cnt, out = ops.roll_invalidation_ball_inside_component(m, dbf, scale, const, z["an_%d" % i], path)
+            assert out is m
+            assert cnt == int(z["count_%d" % i]), i
+            np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
+    finally:
+        ops._engine = None

@@ -227,3 +227,23 @@ def test_invalidation_cube_singleton_and_anisotropic_ordering():
     assert widths[0] >= widths[1] >= widths[2]
     L = np.ones((1, 1, 1), np.uint8, order="F")
     assert K.roll_invalidation_cube(L, np.zeros((1, 1, 1), np.float32, order="F"), [(0, 0, 0)], 1.0, 1.0)[0] == 1
+
+
+def test_trace_control_flow_matches_reference_trace():
+    """oracle.pipeline.trace against the path lists the reference's OWN trace() / compute_paths() produced
+    (tests/golden/trace_paths.npz): both fix_branching modes, forced root + manual targets before / after, max_paths,
+    the soma branch with and without a void, three anisotropies."""
+    from oracle import pipeline as P
+    from golden_trace import cases
+    seen = 0
+    kinds = set()
+    for i, mask, an, kw, extra, want in cases():
+        dbf = K.edt(mask, an, black_border=bool(np.all(mask)))
+        got = P.trace(mask.astype(bool), dbf, anisotropy=an, return_paths=True, **kw,
+                      **{k: (list(v) if isinstance(v, list) else v) for k, v in extra.items()})
+        assert len(got) == len(want), i
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(np.asarray(a), b, err_msg="case %d" % i)
+        seen += 1
+        kinds.add((kw.get("fix_branching", True), "max_paths" in kw, bool(extra), "soma_detection_threshold" in kw))
+    assert seen >= 20 and len(kinds) >= 5
