@@ -221,6 +221,34 @@ int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* 
                        const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
                        uint64_t* cstate, void* event_arena, int64_t* invalidated, void* stream);
 
+/* ---- a7 / a8 on their own: one search on one object (the path loop has them inside kh_trace_paths).
+ * field: the weight volume (PDRF; +inf outside the object); dist: f32 volume, +inf on entry; qstate / queues as for
+ * kh_edf_batch; task: the object's kh_label_t (q_offset / q_capacity, count).
+ *   mode 0  dijkstra3d.railroad(field, source) (kimimaro/trace.py:240-242): path from `source` to the nearest voxel of
+ *           weight 0, written rail end first; dist is +inf again on exit.
+ *   mode 1  the search of dijkstra3d.parental_field(field, source) (trace.py:155): leaves the distances in `dist`.
+ *   mode 2  dijkstra3d.path_from_parents(parents, target) (trace.py:244) on that `dist`: path source -> target.
+ * *path_length (device u32) = vertices written (0 on failure, see task.status).  Ties between equally short paths are
+ * resolved by the canonical predecessor rule of DESIGN.md 3.3 (dijkstra3d's own tie order is not observable: its
+ * source is absent from the reference tree).                                                                        */
+int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists, const uint32_t* nbrmask,
+                   int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                   const float* field, float* dist, uint8_t* qstate, uint32_t* queues,
+                   uint64_t source, uint64_t target, uint32_t* path, int64_t path_capacity, uint32_t* path_length, void* stream);
+
+/* ---- a3 / a5 / a6 as stand-alone operations (the path loop has them fused: kh_pdrf, kh_trace_paths) ----------------
+ * kh_zero2inf / kh_inf2zero: skeletontricks.zero2inf / inf2zero (skeletontricks.pyx:177-224), in place.
+ * kh_pdrf_field: compute_pdrf (kimimaro/trace.py:315-356) on every element: out = ((1 - dbf*M)^(2^log2_exponent)) * scale
+ *   (+ daf / max_daf, with daf normalised in place, when max_daf != 0); every operation rounded to f32.
+ * kh_target_max: CachedTargetFinder.find_target (skeletontricks.pyx:1008-1045) over a voxel list with its DAF values:
+ *   *out (device u64) = 1<<63 | DAF bits << 32 | voxel of the valid (alive != 0) voxel with the largest DAF, ties ->
+ *   largest index; 0 when no voxel is valid.                                                                       */
+int kh_zero2inf(float* f, int64_t n, void* stream);
+int kh_inf2zero(float* f, int64_t n, void* stream);
+int kh_pdrf_field(const float* dbf, float* daf, int64_t n, float M, int log2_exponent, float scale, float max_daf,
+                  float* out, void* stream);
+int kh_target_max(const uint32_t* list, const float* list_daf, const uint8_t* alive, int64_t n, uint64_t* out, void* stream);
+
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);
 int kh_fill_u8(uint8_t* p, int64_t n, int v, void* stream);

@@ -165,6 +165,52 @@ __global__ __launch_bounds__(256) void init_alive_kernel(const LT* __restrict__ 
   }
 }
 
+// a3 / a5 as plain element-wise kernels (the function-level mirrors; the path loop uses the fused pdrf_kernel)
+__global__ void zero2inf_kernel(float* f, int64_t n) {   // skeletontricks.pyx:203-224
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (f[i] == 0.0f) f[i] = KH_INF;
+}
+__global__ void inf2zero_kernel(float* f, int64_t n) {   // skeletontricks.pyx:177-198
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (f[i] == KH_INF) f[i] = 0.0f;
+}
+// compute_pdrf, kimimaro/trace.py:315-356, on every element (DBF already through zero2inf: background -> +-inf)
+__global__ void pdrf_field_kernel(const float* __restrict__ dbf, float* __restrict__ daf, int64_t n, float M, int nsq, float scale,
+                                  float max_daf, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float p = dbf[i] * M;
+    p = 1.0f - p;
+    for (int s = 0; s < nsq; s++) p = p * p;
+    p = p * scale;
+    if (max_daf != 0.0f) {
+      const float inv = 1.0f / max_daf;
+      const float d = daf[i] * inv;
+      daf[i] = d;
+      p = p + d;
+    }
+    out[i] = p;
+  }
+}
+// CachedTargetFinder.find_target (skeletontricks.pyx:1008-1045): the valid voxel with the largest DAF, ties -> largest index
+__global__ __launch_bounds__(1024) void target_max_kernel(const uint32_t* __restrict__ list, const float* __restrict__ list_daf,
+                                                          const uint8_t* __restrict__ alive, uint32_t n, unsigned long long* out) {
+  __shared__ unsigned long long red[16];
+  unsigned long long best = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t v = list[i];
+    if (!alive[v]) continue;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(list_daf[i]) << 32) | v;
+    if (key >= best) best = key | (1ull << 63);   // bit 63 marks "found" (DAF >= 0: the sign bit is free)
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); if (ob > best) best = ob; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned w = 1; w < (blockDim.x >> 6); w++) if (red[w] > best) best = red[w];
+    *out = best;
+  }
+}
+
 __global__ void fill_f32_kernel(float* p, int64_t n, float v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -282,6 +328,37 @@ extern "C" int kh_fill_u8(uint8_t* p, int64_t n, int v, void* stream) {
 extern "C" int kh_gather_f32(const float* src, const uint32_t* idx, int64_t n, float* out, void* stream) {
   if (int rc = require_device()) return rc;
   hipLaunchKernelGGL(gather_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, n, out);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_zero2inf(float* f, int64_t n, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipLaunchKernelGGL(zero2inf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, f, n);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_inf2zero(float* f, int64_t n, void* stream) {
+  if (int rc = require_device()) return rc;
+  hipLaunchKernelGGL(inf2zero_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, f, n);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_pdrf_field(const float* dbf, float* daf, int64_t n, float M, int log2_exponent, float scale, float max_daf,
+                             float* out, void* stream) {
+  if (int rc = require_device()) return rc;
+  if (log2_exponent < 0 || log2_exponent > 15) { set_error("kh_pdrf_field: exponent must be a power of two < 2^16"); return KH_EINVAL; }
+  hipLaunchKernelGGL(pdrf_field_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dbf, daf, n, M, log2_exponent,
+                     scale, max_daf, out);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_target_max(const uint32_t* list, const float* list_daf, const uint8_t* alive, int64_t n, uint64_t* out,
+                             void* stream) {
+  if (int rc = require_device()) return rc;
+  if (n < 0 || n >= (1ll << 32)) { set_error("kh_target_max: bad list length"); return KH_EINVAL; }
+  hipLaunchKernelGGL(target_max_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, list, list_daf, alive, (uint32_t)n,
+                     (unsigned long long*)out);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -1043,6 +1043,53 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// a7 / a8 on their own (the path loop has them inside trace_paths_kernel): one object, one search.
+//   mode 0  dijkstra3d.railroad(field, source): search from `src` over the field to the nearest zero-weight voxel,
+//           path written rail end first (trace.py:240-242); dist is +inf again on exit.
+//   mode 1  the search of dijkstra3d.parental_field(field, source) (trace.py:155): leaves the distance field in `dist`.
+//   mode 2  dijkstra3d.path_from_parents (trace.py:244) on that distance field: path src(root) -> dst(target).
+__global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int mode, const uint32_t* __restrict__ lists,
+                                                          const uint32_t* __restrict__ nbrmask, Geometry g, const float* pdrf,
+                                                          float* dist, uint8_t* qstate, uint32_t* queues, uint32_t src, uint32_t dst,
+                                                          uint32_t* out, uint32_t cap, uint32_t* out_n) {
+  __shared__ Ctl ctl;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  Queues q;
+  q.cap = task->q_capacity;
+  q.a = queues + (uint64_t)task->q_offset * 4;
+  q.b = q.a + q.cap;
+  q.c = q.b + q.cap;
+  q.touched = q.c + q.cap;
+  if (tid == 0) { ctl.status = 0; ctl.u0 = 0; ctl.g = g; }
+  __syncthreads();
+  if (mode == 1) {
+    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f);
+  } else if (mode == 2) {
+    if (wave == 0) {
+      const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, dst, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status);
+      for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
+      if (lane == 0) ctl.u0 = n;
+    }
+  } else if (pdrf[src] == 0.0f) {
+    if (tid == 0) { out[0] = src; ctl.u0 = 1; }
+  } else {
+    sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f);
+    const unsigned long long br = ctl.best_rail;
+    if (br == NONE64) {
+      if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
+    } else if (wave == 0) {
+      const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status);
+      if (lane == 0) ctl.u0 = n;
+    }
+    __syncthreads();
+    const uint32_t nt = ctl.n_touched < q.cap ? ctl.n_touched : q.cap;
+    for (uint32_t i = tid; i < nt; i += nthr) { const uint32_t v = q.touched[i]; st_f32_l2(&dist[v], KH_INF); qstate[v] = 0; }
+  }
+  __syncthreads();
+  if (tid == 0) { *out_n = ctl.u0; task->status |= ctl.status; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a10: roll_invalidation_cube.  One workgroup per path vertex; bytes are cleared with a 32-bit
 // atomicAnd so each voxel is counted exactly once however many boxes overlap.
 __global__ __launch_bounds__(256) void invalidate_cube_kernel(uint8_t* mask, const float* __restrict__ dbf, int sx, int sy,
@@ -1230,6 +1277,25 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(invalidate_ball_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, task, lists, nbrmask, g, dbf, alive, queues,
                      (hnode_t*)heap_nodes, path, (uint32_t)npath, scale, constant, sg, (long long*)invalidated);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,
+                              int64_t sz, float wx, float wy, float wz, const float* field, float* dist, uint8_t* qstate,
+                              uint32_t* queues, uint64_t source, uint64_t target, uint32_t* path, int64_t path_capacity,
+                              uint32_t* path_length, void* stream) {
+  if (int rc2 = require_device()) return rc2;
+  if (!task || !lists || !nbrmask || !field || !dist || !qstate || !queues || !path_length || mode < 0 || mode > 2 ||
+      (mode != 1 && !path) || sx * sy * sz >= (1ll << 32) || path_capacity < 0 || path_capacity >= (1ll << 32) ||
+      ((uintptr_t)qstate & 3) != 0) {
+    set_error("kh_path_search: bad arguments");
+    return KH_EINVAL;
+  }
+  Geometry g;
+  make_geometry(g, sx, sy, sz, wx, wy, wz);
+  hipLaunchKernelGGL(path_search_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, task, mode, lists, nbrmask, g, field, dist, qstate,
+                     queues, (uint32_t)source, (uint32_t)target, path, (uint32_t)path_capacity, path_length);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -100,3 +100,192 @@ def roll_invalidation_ball_inside_component(labels, DBF, scale, const, anisotrop
     cnt, _ = eng.invalidate_ball(ctx, d_alive, locs, scale, const, anisotropy)
     lab.reshape(-1, order="F")[...] = d_alive.cpu().numpy()
     return cnt, labels
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Function-level mirrors of the modules kimimaro/trace.py imports: same names, argument meaning
+# and return values as at the call sites cited, every computation a HIP kernel reached through the C ABI.  The path
+# loop of skeletonize() does not go through these (it has them fused on the device); they exist so that the reference's
+# own vectors can be fed to the HIP implementation of every step.
+
+def _f3(a, dtype=None):
+    a = np.asarray(a)
+    while a.ndim < 3:
+        a = a[..., np.newaxis]
+    return np.asfortranarray(a if dtype is None else a.astype(dtype, copy=False))
+
+
+def _loc(pt, shape):
+    return int(pt[0]) + shape[0] * (int(pt[1]) + shape[1] * int(pt[2]))
+
+
+def _pts(locs, shape):
+    locs = np.asarray(locs, dtype=np.int64)
+    return np.stack([locs % shape[0], (locs // shape[0]) % shape[1], locs // (shape[0] * shape[1])], axis=1)
+
+
+def zero2inf(field):
+    """kimimaro.skeletontricks.zero2inf (skeletontricks.pyx:203-224): in place, returns the same array."""
+    eng = engine()
+    flat = field.reshape(-1, order="F")
+    d = eng.torch.from_numpy(np.ascontiguousarray(flat)).to(eng.device)
+    _abi.check(eng.lib.kh_zero2inf(eng.ptr(d), flat.size, eng.stream()))
+    flat[...] = d.cpu().numpy()
+    return field
+
+
+def inf2zero(field):
+    """kimimaro.skeletontricks.inf2zero (skeletontricks.pyx:177-198): in place, returns the same array."""
+    eng = engine()
+    flat = field.reshape(-1, order="F")
+    d = eng.torch.from_numpy(np.ascontiguousarray(flat)).to(eng.device)
+    _abi.check(eng.lib.kh_inf2zero(eng.ptr(d), flat.size, eng.stream()))
+    flat[...] = d.cpu().numpy()
+    return field
+
+
+def fill(img, in_place=True, return_fill_count=True):
+    """fill_voids.fill as called at kimimaro/trace.py:109."""
+    eng = engine()
+    m = _f3(img)
+    d_mask = eng.torch.from_numpy(np.ascontiguousarray((m != 0).astype(np.uint8).reshape(-1, order="F"))).to(eng.device)
+    d_out, n = eng.fill_voids(d_mask, m.shape)
+    out = d_out.cpu().numpy().reshape(m.shape, order="F").astype(img.dtype).reshape(img.shape, order="F")
+    if in_place:
+        img[...] = out
+        out = img
+    return (out, n) if return_fill_count else out
+
+
+def compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, max_daf):
+    """kimimaro.trace.compute_pdrf (kimimaro/trace.py:315-356): DBF has been through zero2inf, DAF is normalised in
+    place (like the reference).  Power-of-two exponents (the repeated-squaring branch of :343-345) only."""
+    e = int(pdrf_exponent)
+    if e <= 0 or (e & (e - 1)) != 0 or e >= 2 ** 16:
+        raise NotImplementedError("pdrf_exponent must be a power of two < 2**16 on the HIP path")
+    eng = engine()
+    f = np.float32
+    M = f(1 / (f(dbf_max) ** 1.01))
+    t = eng.torch
+    d_dbf = t.from_numpy(np.ascontiguousarray(np.asarray(DBF, dtype=np.float32).reshape(-1, order="F"))).to(eng.device)
+    daf_flat = DAF.reshape(-1, order="F")
+    d_daf = t.from_numpy(np.ascontiguousarray(daf_flat)).to(eng.device)
+    d_out = eng.empty(d_dbf.numel(), t.float32)
+    _abi.check(eng.lib.kh_pdrf_field(eng.ptr(d_dbf), eng.ptr(d_daf), d_dbf.numel(), M, e.bit_length() - 1, f(pdrf_scale), f(max_daf),
+                                     eng.ptr(d_out), eng.stream()))
+    daf_flat[...] = d_daf.cpu().numpy()
+    return d_out.cpu().numpy().reshape(np.asarray(DBF).shape, order="F")
+
+
+def euclidean_distance_field(labels, source, anisotropy=(1, 1, 1), free_space_radius=0, voxel_graph=None,
+                             return_max_location=False):
+    """dijkstra3d.euclidean_distance_field as called at kimimaro/trace.py:139-145, 302-307: geodesic distance inside
+    the mask from `source`, +inf elsewhere; with return_max_location also the (x, y, z) of the largest finite value."""
+    if voxel_graph is not None:
+        raise NotImplementedError("voxel_graph")
+    eng = engine()
+    lab = _f3(labels)
+    ctx = eng.single_object(lab, anisotropy)
+    shape = ctx["shape"]
+    t = eng.torch
+    task = ctx["task"]
+    task["root"] = _loc(source, shape)
+    task["fsr"] = np.float32(free_space_radius)
+    d_task = t.from_numpy(task.view(np.uint8).reshape(-1).copy()).to(eng.device)
+    d_field = t.full((ctx["nvox"],), float("inf"), dtype=t.float32, device=eng.device)
+    P = eng.ptr
+    _abi.check(eng.lib.kh_edf_batch(P(d_task), 1, 2, P(ctx["d_lists"]), P(ctx["d_nbr"]), shape[0], shape[1], shape[2],
+                                    float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(d_field),
+                                    P(ctx["d_qstate"]), P(ctx["d_queues"]), eng.stream()))
+    out = d_field.cpu().numpy().reshape(shape, order="F").reshape(np.asarray(labels).shape, order="F")
+    if not return_max_location:
+        return out
+    done = d_task.cpu().numpy().view(_abi.LABEL_T)
+    return out, tuple(int(v) for v in _pts([int(done["max_loc"][0])], shape)[0])
+
+
+class _Search:
+    """an object's device context + its weight field for kh_path_search"""
+
+    def __init__(self, field):
+        eng = engine()
+        self.eng = eng
+        self.host_shape = np.asarray(field).shape
+        f = _f3(field, np.float32)
+        self.shape = f.shape
+        self.ctx = eng.single_object(np.isfinite(f), (1, 1, 1))
+        t = eng.torch
+        self.d_field = t.from_numpy(np.ascontiguousarray(f.reshape(-1, order="F"))).to(eng.device)
+        self.d_dist = t.full((f.size,), float("inf"), dtype=t.float32, device=eng.device)
+
+    def run(self, mode, source, target=0):
+        eng, ctx, t, P = self.eng, self.ctx, self.eng.torch, self.eng.ptr
+        cap = 4 * ctx["count"] + 1024
+        d_path = eng.empty(cap, t.int32)
+        d_n = t.zeros(1, dtype=t.int32, device=eng.device)
+        sx, sy, sz = self.shape
+        _abi.check(eng.lib.kh_path_search(P(ctx["d_task"]), mode, P(ctx["d_lists"]), P(ctx["d_nbr"]), sx, sy, sz, 1.0, 1.0, 1.0,
+                                          P(self.d_field), P(self.d_dist), P(ctx["d_qstate"]), P(ctx["d_queues"]), int(source),
+                                          int(target), P(d_path), cap, P(d_n), eng.stream()))
+        status = int(ctx["d_task"].cpu().numpy().view(_abi.LABEL_T)["status"][0])
+        if status:
+            raise _abi.KimiHipError("kh_path_search: %s" % _abi.describe_status(status))
+        n = int(d_n.item())
+        return _pts(d_path[:n].cpu().numpy().view(np.uint32), self.shape)
+
+
+def railroad(field, source, voxel_graph=None):
+    """dijkstra3d.railroad(field, source) as called at kimimaro/trace.py:240-242: the path from `source` to the nearest
+    zero-weight voxel, rail end first, as an (n, 3) array."""
+    if voxel_graph is not None:
+        raise NotImplementedError("voxel_graph")
+    s = _Search(field)
+    return s.run(0, _loc(source, s.shape))
+
+
+class _Parents(_Search):
+    pass
+
+
+def parental_field(field, source, voxel_graph=None):
+    """dijkstra3d.parental_field(field, source) as called at kimimaro/trace.py:155.  The result is opaque to the caller
+    (the reference only hands it to path_from_parents): here the distance field of the search, resident on the device."""
+    if voxel_graph is not None:
+        raise NotImplementedError("voxel_graph")
+    p = _Parents(field)
+    p.source = _loc(source, p.shape)
+    p.run(1, p.source)
+    return p
+
+
+def path_from_parents(parents, target):
+    """dijkstra3d.path_from_parents(parents, target) as called at kimimaro/trace.py:244: source -> target, (n, 3)."""
+    return parents.run(2, parents.source, _loc(target, parents.shape))
+
+
+class CachedTargetFinder:
+    """kimimaro.skeletontricks.CachedTargetFinder (skeletontricks.pyx:995-1045): find_target(labels) returns the
+    still-valid voxel with the largest DAF (ties: the larger index), None when none is left."""
+
+    def __init__(self, labels, daf):
+        eng = engine()
+        self.eng = eng
+        lab = _f3(labels)
+        self.shape = lab.shape
+        self.ctx = eng.single_object(lab, (1, 1, 1))
+        t = eng.torch
+        d_daf = t.from_numpy(np.ascontiguousarray(_f3(daf, np.float32).reshape(-1, order="F"))).to(eng.device)
+        self.d_ldaf = eng.empty(max(self.ctx["count"], 1), t.float32)
+        _abi.check(eng.lib.kh_gather_f32(eng.ptr(d_daf), eng.ptr(self.ctx["d_lists"]), self.ctx["count"], eng.ptr(self.d_ldaf),
+                                         eng.stream()))
+
+    def find_target(self, labels):
+        eng, t = self.eng, self.eng.torch
+        d_alive = t.from_numpy(np.ascontiguousarray(_f3(labels).view(np.uint8).reshape(-1, order="F"))).to(eng.device)
+        d_out = t.zeros(1, dtype=t.int64, device=eng.device)
+        _abi.check(eng.lib.kh_target_max(eng.ptr(self.ctx["d_lists"]), eng.ptr(self.d_ldaf), eng.ptr(d_alive), self.ctx["count"],
+                                         eng.ptr(d_out), eng.stream()))
+        key = int(d_out.cpu().numpy().view(np.uint64)[0])
+        if key == 0:
+            return None
+        return tuple(int(v) for v in _pts([key & 0xFFFFFFFF], self.shape)[0])

@@ -389,3 +389,91 @@ def test_invalidate_ball_reference_goldens(sweep):
             np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
     finally:
         ops._engine = None
+
+
+def _unpack(b, shape):
+    return np.unpackbits(b)[: int(np.prod(shape))].reshape(shape, order="F").astype(np.uint8)
+
+
+def test_pdrf_reference_goldens(eng):
+    """kh_pdrf_field (ops.compute_pdrf) on the vectors of the reference's OWN compute_pdrf (tests/golden/pdrf.npz,
+    kimimaro/trace.py:315-356 loaded in the build container): bit exact incl. the +-inf background and the in-place
+    normalisation of DAF; north_star's 1e-4 tolerance on PDRF floats is met with zero error.  Exponent 3 (np.power
+    branch) is not built on the HIP path."""
+    import os
+    from kimimaro_amd import ops
+    ops._engine = eng
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pdrf.npz"))
+    shape = (9, 7, 5)
+    done = 0
+    for i in range(int(z["n"])):
+        dbf = np.asfortranarray(z["dbf_%d" % i].reshape(shape, order="F"))
+        daf = np.asfortranarray(z["daf_in_%d" % i].reshape(shape, order="F")).copy(order="F")
+        dbf_max, scale, expo, max_daf = z["par_%d" % i]
+        if int(expo) & (int(expo) - 1):
+            with pytest.raises(NotImplementedError):
+                ops.compute_pdrf(np.float32(dbf_max), scale, int(expo), dbf, daf, np.float32(max_daf))
+            continue
+        out = ops.compute_pdrf(np.float32(dbf_max), scale, int(expo), dbf, daf, np.float32(max_daf))
+        np.testing.assert_array_equal(out.ravel(order="F"), z["out_%d" % i], err_msg="case %d" % i)
+        np.testing.assert_array_equal(daf.ravel(order="F"), z["daf_out_%d" % i])
+        done += 1
+    assert done >= 8
+
+
+def test_target_finder_reference_goldens(eng):
+    """kh_target_max (ops.CachedTargetFinder) replays the sequences of the compiled reference's CachedTargetFinder
+    (tests/golden/target_finder.npz, tie-free DAFs)."""
+    import os
+    from kimimaro_amd import ops
+    ops._engine = eng
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "target_finder.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(int(v) for v in z["shape_%d" % i])
+        mask = _unpack(z["mask_%d" % i], shape)
+        daf = np.asfortranarray(z["daf_%d" % i].reshape(shape, order="F"))
+        finder = ops.CachedTargetFinder(mask, daf)
+        m = mask.copy(order="F")
+        seq, kills = z["seq_%d" % i], z["kills_%d" % i]
+        for step in range(seq.shape[0]):
+            assert finder.find_target(m) == tuple(int(v) for v in seq[step]), (i, step)
+            m = _unpack(kills[step], shape)
+        assert finder.find_target(m) is None
+
+
+def test_function_level_mirrors_match_oracle(eng):
+    """the stand-alone entry points behind the names trace.py imports: euclidean_distance_field (field bit exact incl.
+    the max location), railroad, parental_field + path_from_parents, zero2inf / inf2zero, fill -- against the oracle on
+    eight random-walk tubes (three anisotropies)."""
+    import oracle
+    from kimimaro_amd import ops
+    ops._engine = eng
+    for t in range(8):
+        an = [(1, 1, 1), (16, 16, 40), (40, 32, 20)][t % 3]
+        m = random_walk_tube((34, 30, 26), 4400 + t, steps=40, step=3.0, radius=(1.3, 4.0))
+        cc, _ = oracle.connected_components(m)
+        m = np.asfortranarray((cc == np.argmax(np.bincount(cc.ravel())[1:]) + 1).astype(np.uint8))
+        src = oracle.first_label(m)
+        want, wloc = oracle.euclidean_distance_field(m, src, an)
+        got, gloc = ops.euclidean_distance_field(m, src, anisotropy=an, return_max_location=True)
+        np.testing.assert_array_equal(got, want)
+        assert gloc == wloc
+        dbf = oracle.zero2inf(oracle.edt(m, an))
+        daf = oracle.inf2zero(want.copy(order="F"))
+        pdrf = oracle.compute_pdrf(np.max(oracle.edt(m, an)), 100000, 4, dbf, daf, daf[wloc])
+        field = pdrf.copy(order="F")
+        field[src] = 0.0                                         # a rail at the source
+        np.testing.assert_array_equal(ops.railroad(field, wloc), oracle.railroad(field, wloc))
+        par = ops.parental_field(pdrf, src)
+        np.testing.assert_array_equal(ops.path_from_parents(par, wloc),
+                                      oracle.path_to_source(pdrf, oracle.field_distances(pdrf, src), src, wloc))
+        z = oracle.edt(m, an)
+        np.testing.assert_array_equal(ops.zero2inf(z.copy(order="F")), oracle.zero2inf(z.copy(order="F")))
+        np.testing.assert_array_equal(ops.inf2zero(want.copy(order="F")), oracle.inf2zero(want.copy(order="F")))
+    import scipy.ndimage
+    from shapes import soma_shape
+    h = np.asfortranarray(soma_shape(hole=True).astype(np.uint8))
+    filled, n = ops.fill(h.copy(order="F"), in_place=True, return_fill_count=True)
+    want = scipy.ndimage.binary_fill_holes(h)
+    assert n == int(want.sum()) - int(h.sum()) and n > 0
+    np.testing.assert_array_equal(filled.astype(bool), want)
