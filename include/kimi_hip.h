@@ -271,10 +271,11 @@ int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, int64_t sy, 
  * (the numbering of kh_host_ccl26); parent: u32 scratch [nvox]; chunk_counts: u32 scratch [ceil(nvox/1024)];
  * representative: u32 [nvox+1 worst case; N+1 used], representative[id] = smallest linear index of the
  * component (skeletontricks.get_mapping, skeletontricks.pyx:490-525, reads the original label there);
- * *ncomponents (device u32) = N.                                                                      */
+ * *ncomponents (device u32) = N.  out16 (nullable, u16 [nvox]): filled with the same ids when N < 65536
+ * (fastremap.refit, kimimaro/utility.py:79), untouched otherwise.                                     */
 int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent,
              uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents,
-             void* stream);
+             uint16_t* out16, void* stream);
 
 /* ---- f3: binary hole filling, replaces fill_voids.fill(img, in_place=True, return_fill_count=True) as
  * called at kimimaro/trace.py:109 (third-party, source absent): a background voxel (mask == 0) stays

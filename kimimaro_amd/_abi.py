@@ -100,7 +100,7 @@ def lib():
     L.kh_gather_f32.argtypes = [vp, vp, i64, vp, vp]
     L.kh_init_alive.argtypes = [vp, ci, i64, vp, vp, vp]
     L.kh_invalidate_cube.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, vp, i64, f32, f32, vp, vp]
-    L.kh_ccl26.argtypes = [vp, ci, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.kh_ccl26.argtypes = [vp, ci, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.kh_fill_voids.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
     L.kh_host_ccl26.argtypes = [vp, ci, i64, i64, i64, vp]
     L.kh_host_ccl26.restype = i64

@@ -163,14 +163,20 @@ __global__ __launch_bounds__(256) void ccl_number_roots_kernel(const uint32_t* _
   }
 }
 
-__global__ __launch_bounds__(256) void ccl_relabel_kernel(uint32_t* parent, int64_t n, uint32_t* out) {
+__global__ __launch_bounds__(256) void ccl_relabel_kernel(uint32_t* parent, int64_t n, uint32_t* out, uint16_t* out16,
+                                                          const uint32_t* __restrict__ total) {
+  // out16: the ids once more as u16 when there are fewer than 65536 components (fastremap.refit, kimimaro/utility.py:79):
+  // every later sweep over the component volume then reads 2 instead of 4 bytes per voxel
+  const bool narrow = out16 != nullptr && *total < 65536u;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t p = ccl_ld(parent, (uint32_t)i);
-    if (p == CCL_NONE) { out[i] = 0; continue; }
-    if (p == (uint32_t)i) continue;             // roots were written by ccl_number_roots_kernel
+    if (p == CCL_NONE) { out[i] = 0; if (narrow) out16[i] = 0; continue; }
+    if (p == (uint32_t)i) { if (narrow) out16[i] = (uint16_t)out[i]; continue; }   // roots were numbered by ccl_number_roots_kernel
     // parent[i] is an ancestor but not necessarily the root: a path-halving store of another thread's find may have
     // landed after the flatten pass wrote the root (seen on a 10^6-voxel component: a few voxels kept label 0)
-    out[i] = out[ccl_find(parent, (uint32_t)i)];
+    const uint32_t id = out[ccl_find(parent, (uint32_t)i)];
+    out[i] = id;
+    if (narrow) out16[i] = (uint16_t)id;
   }
 }
 
@@ -183,7 +189,7 @@ static inline unsigned ccl_grid(int64_t n, int per_block, int64_t cap = 16384) {
 
 template <typename LT>
 static int ccl_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint32_t* chunk_counts, uint32_t* out,
-                    uint32_t* rep, uint32_t* total, hipStream_t st) {
+                    uint32_t* rep, uint32_t* total, uint16_t* out16, hipStream_t st) {
   const int64_t n = sx * sy * sz;
   const int64_t nchunks = (n + 1023) / 1024;
   hipLaunchKernelGGL((ccl_init_kernel<LT>), dim3(ccl_grid(n, 256)), dim3(256), 0, st, lab, parent, n);
@@ -192,7 +198,7 @@ static int ccl_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, uint32_t*
   hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(ccl_grid(nchunks, 1)), dim3(256), 0, st, parent, n, chunk_counts);
   hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, nchunks, total);
   hipLaunchKernelGGL(ccl_number_roots_kernel, dim3(ccl_grid(nchunks, 1)), dim3(256), 0, st, parent, n, chunk_counts, out, rep);
-  hipLaunchKernelGGL(ccl_relabel_kernel, dim3(ccl_grid(n, 256)), dim3(256), 0, st, parent, n, out);
+  hipLaunchKernelGGL(ccl_relabel_kernel, dim3(ccl_grid(n, 256)), dim3(256), 0, st, parent, n, out, out16, total);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -253,7 +259,8 @@ __global__ __launch_bounds__(256) void fill_apply_kernel(const uint8_t* __restri
 }  // namespace kh
 
 extern "C" int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent,
-                        uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents, void* stream) {
+                        uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents, uint16_t* out16,
+                        void* stream) {
   if (int rc = kh::require_device()) return rc;
   if (!labels || !parent || !chunk_counts || !out || !representative || !ncomponents || sx <= 0 || sy <= 0 || sz <= 0 ||
       sx * sy * sz >= (1ll << 32) - 1) {
@@ -262,10 +269,10 @@ extern "C" int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t
   }
   hipStream_t st = (hipStream_t)stream;
   switch (label_bytes) {
-    case 1: return kh::ccl_impl((const uint8_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
-    case 2: return kh::ccl_impl((const uint16_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
-    case 4: return kh::ccl_impl((const uint32_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
-    case 8: return kh::ccl_impl((const uint64_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, st);
+    case 1: return kh::ccl_impl((const uint8_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, out16, st);
+    case 2: return kh::ccl_impl((const uint16_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, out16, st);
+    case 4: return kh::ccl_impl((const uint32_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, out16, st);
+    case 8: return kh::ccl_impl((const uint64_t*)labels, sx, sy, sz, parent, chunk_counts, out, representative, ncomponents, out16, st);
     default: kh::set_error("kh_ccl26: label_bytes must be 1, 2, 4 or 8"); return KH_EINVAL;
   }
 }

@@ -89,11 +89,22 @@ class Engine:
         d_cc = self.empty(n, t.int32)
         d_rep = self.empty(n + 1, t.int32)
         d_total = self.empty(1, t.int32)
+        d_cc16 = self.empty(n, t.int16)
         _abi.check(self.lib.kh_ccl26(self.ptr(d_lab), itemsize, shape[0], shape[1], shape[2], self.ptr(d_parent),
-                                     self.ptr(d_counts), self.ptr(d_cc), self.ptr(d_rep), self.ptr(d_total), self.stream()))
+                                     self.ptr(d_counts), self.ptr(d_cc), self.ptr(d_rep), self.ptr(d_total), self.ptr(d_cc16),
+                                     self.stream()))
         ncomp = int(d_total.cpu().numpy().view(np.uint32)[0])
+        # fewer than 65536 components: the u16 copy of the ids serves every later sweep (narrow())
+        self._narrow = (d_cc.data_ptr(), d_cc16) if ncomp < 65536 else None
         rep = d_rep[: ncomp + 1].cpu().numpy().view(np.uint32)
         return d_cc, ncomp, rep
+
+    def narrow(self, d_cc):
+        """(device label volume, bytes per label) to sweep over: the u16 copy kh_ccl26 made of `d_cc` when there is one."""
+        nr = getattr(self, "_narrow", None)
+        if nr is not None and nr[0] == d_cc.data_ptr():
+            return nr[1], 2
+        return d_cc, 4
 
     def fill_voids(self, d_mask, shape):
         """kh_fill_voids (fill_voids.fill, kimimaro/trace.py:109) on a u8 mask resident in HBM.

@@ -184,6 +184,7 @@ def fill_all_holes_device(eng, d_cc, shape, nlabels):
     component are filled with kh_fill_voids on the component's bounding box, in ascending label order; a component
     that gets swallowed is not processed itself any more.  Bounding boxes are those before any filling, as in the
     reference (find_objects is called once, intake.py:767).  Returns the number of voxels filled."""
+    eng._narrow = None     # the component volume is edited in place below: its u16 copy no longer matches
     t = eng.torch
     nvox = int(shape[0]) * int(shape[1]) * int(shape[2])
     counts, _, _, xmin, xmax = eng.label_stats(d_cc, 4, t.zeros(nvox, dtype=t.float32, device=eng.device), shape, nlabels)
@@ -246,8 +247,9 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     if d_cc is None:
         d_cc = eng.to_device(cc_labels.host())
         cc_labels.d = d_cc
-    d_dbf = eng.edt(d_cc, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
-    counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, label_bytes, d_dbf, shape, nlabels)
+    d_lab, label_bytes = eng.narrow(d_cc)          # u16 ids when there are < 65536 components (utility.py:79 refit)
+    d_dbf = eng.edt(d_lab, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
+    counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_lab, label_bytes, d_dbf, shape, nlabels)
     yz = eng.last_yz_extent
     bbox = lambda sid: ((int(xmin[sid]), int(yz[sid, 0]), int(yz[sid, 2])),
                         (int(xmax[sid]) + 1, int(yz[sid, 1]) + 1, int(yz[sid, 3]) + 1))  # find_objects, utility.py:85-102
@@ -291,7 +293,7 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
 
     sel = np.asarray(segids, dtype=np.int64)
     asm = Assembler(shape, anisotropy, remapping)
-    eng.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],
+    eng.run_labels(d_lab, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],
                          dbf_max[sel] if len(sel) else [], first_index[sel] if len(sel) else [],
                          xmin[sel] if len(sel) else [], xmax[sel] if len(sel) else [], roots, tb, ta, params,
                          fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings, consume=asm.add)
