@@ -321,18 +321,19 @@ def main():
     names = ["edt_x_kernel<%s>" % lt, "edt_axis_kernel<%s> (y pass)" % lt, "edt_axis_kernel<%s> (z pass)" % lt]
     achieved = pass_bytes[k] / (pass_ms[k] * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs, gfx950 x2 FETCH correction calibrated on the x pass): profiles/r01c_c3_edt_pmc.json.  Only valid for c3.
+    # runs, gfx950 x2 FETCH correction calibrated on the x pass): profiles/r02_c3_edt_pmc.json.  Only valid for c3.
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01c_c3_edt_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_c3_edt_pmc.json")
     if args.workload == "c3" and os.path.exists(pmc):
         kern = json.load(open(pmc))["kernels"]
-        tag = ["edt_x_kernel", "edt_axis_kernel<unsigned int, false", "edt_axis_kernel<unsigned int, true"][k]
+        lts = {2: "unsigned short", 4: "unsigned int"}[L]
+        tag = ["edt_x_kernel", "edt_axis_kernel<%s, false" % lts, "edt_axis_kernel<%s, true" % lts][k]
         hit = [v for name, v in kern.items() if tag in name]
         if hit:
             traffic = hit[0]["hbm_bytes_corrected"]
     roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01c_c3_edt_pmc.json (PMC pass, not live)" if traffic else None,
+                "traffic_source": "profiles/r02_c3_edt_pmc.json (PMC pass, not live)" if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
@@ -342,7 +343,7 @@ def main():
     tk = E.LAST_TASKS
     timings = []
     t_ccl = time.perf_counter()
-    components()
+    d_cc, nlabels, remapping = components()      # (the instrumented pass below sweeps over this call's u16 ids)
     eng.sync()
     t_ccl = time.perf_counter() - t_ccl
     intake.skeletonize_cc(eng, intake.LazyVolume(eng, d_cc, shape, host=cc_labels), nlabels, remapping, params, an, dust,

@@ -1,4 +1,5 @@
-"""Runs only the whole-volume EDT on bench.py's c3 volume (for rocprofv3 --pmc passes)."""
+"""Runs only the whole-volume EDT on bench.py's c3 volume (for rocprofv3 --pmc passes), on the u16 component ids the
+step itself uses when there are fewer than 65536 components."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,10 +9,12 @@ from kimimaro_amd import intake
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 eng = Engine()
 lab, an = bench.make_volume(name)
-cc, n, _ = intake.compute_cc_labels(intake.format_labels(lab, in_place=True))
-d = eng.to_device(cc)
-out = eng.empty(cc.size, torch.float32); ws = eng.empty(2 * cc.size, torch.float32)
+lab = intake.format_labels(lab, in_place=True)
+d_cc, n, _ = eng.ccl_device(eng.to_device(lab), lab.dtype.itemsize, lab.shape)
+d, L = eng.narrow(d_cc)
+nvox = lab.size
+out = eng.empty(nvox, torch.float32); ws = eng.empty(nvox, torch.float32)
 for _ in range(3):
-    eng.edt(d, 4, cc.shape, an, False, out, ws)
+    eng.edt(d, L, lab.shape, an, False, out, ws)
 eng.sync()
-print("done", float(out.max().item()))
+print("done", n, "components, label bytes", L, float(out.max().item()))

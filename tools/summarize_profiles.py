@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 V = 512 ** 3
-L = 4
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 2   # bytes per component id in the EDT launches (u16 since round 2)
 
 shutil.copy(os.path.join(src, "ktrace", "kt_kernel_stats.csv"), os.path.join(dst, pre + "_c3_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, pre + "_c3_bench_under_rocprof.json"))
@@ -53,7 +53,7 @@ fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python tools/edt_only.py c3 ; " + pre,
        "units": "bytes per launch; FETCH_SIZE / WRITE_SIZE are reported in KiB",
        "correction": "FETCH_SIZE on gfx950 counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section): x2.  Calibrated in this "
-                     "access pattern on edt_x_kernel, which reads the 512^3 u32 label volume exactly once (536,870,912 B).  WRITE_SIZE "
+                     "access pattern on edt_x_kernel, which reads the 512^3 label volume exactly once (L * 134,217,728 B).  WRITE_SIZE "
                      "needs no correction (every pass writes 536,870,912 B).",
        "kernels": {}}
 for k in sorted(fetch):
