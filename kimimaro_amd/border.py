@@ -57,14 +57,19 @@ def compute_border_targets(cc_labels, anisotropy, eng=None, edt2d=None, faces=No
     if faces is None:
         faces = (cc_labels[:, :, 0], cc_labels[:, :, -1], cc_labels[:, 0, :], cc_labels[:, -1, :],
                  cc_labels[0, :, :], cc_labels[-1, :, :])
-    planes = (
-        (faces[0], (0, 1), lambda x, y: (x, y, 0)),
-        (faces[1], (0, 1), lambda x, y: (x, y, sz - 1)),
-        (faces[2], (0, 2), lambda x, z: (x, 0, z)),
-        (faces[3], (0, 2), lambda x, z: (x, sy - 1, z)),
-        (faces[4], (1, 2), lambda y, z: (0, y, z)),
-        (faces[5], (1, 2), lambda y, z: (sx - 1, y, z)),
-    )
+    # the six faces in the order of intake.py:551-558 (z = 0, z = max, y = 0, y = max, x = 0, x = max); a face pixel
+    # (p, q) lies on the two axes that span the face, the third coordinate is the face's own
+    extent = (sx, sy, sz)
+    planes = []
+    for fixed_axis, span in ((2, (0, 1)), (1, (0, 2)), (0, (1, 2))):
+        for side in (0, 1):
+            at = 0 if side == 0 else extent[fixed_axis] - 1
+
+            def place(p, q, fixed_axis=fixed_axis, span=span, at=at):
+                pt = [0, 0, 0]
+                pt[span[0]], pt[span[1]], pt[fixed_axis] = p, q, at
+                return tuple(pt)
+            planes.append((faces[len(planes)], span, place))
     target_list = defaultdict(set)
     for plane, dims, rotatefn in planes:
         wx, wy = anisotropy[dims[0]], anisotropy[dims[1]]

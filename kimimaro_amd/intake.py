@@ -44,23 +44,18 @@ class DimensionError(Exception):
 
 
 def format_labels(labels, in_place=False):
-    """kimimaro/intake.py:315-342."""
-    if in_place:
-        labels = np.asfortranarray(labels)
-    else:
-        labels = np.copy(labels, order="F")
-    if labels.dtype == bool:
-        labels = labels.view(np.uint8)
-    original_shape = labels.shape
-    while labels.ndim < 3:
-        labels = labels[..., np.newaxis]
-    while labels.ndim > 3:
-        if labels.shape[-1] == 1:
-            labels = labels[..., 0]
-        else:
-            raise DimensionError(
-                "Input labels may be no more than three non-trivial dimensions. Got: {}".format(original_shape))
-    return labels
+    """The input as a Fortran-ordered array with exactly three axes, as kimimaro/intake.py:315-342 prepares it: bool
+    volumes are reinterpreted as uint8, 1-D / 2-D inputs get trailing axes of extent 1, trailing singleton axes
+    beyond the third are dropped, and a fourth non-trivial axis is a DimensionError (same message).  in_place avoids
+    the copy when the array already is Fortran ordered."""
+    vol = np.asfortranarray(labels) if in_place else np.array(labels, order="F", copy=True)
+    if vol.dtype == np.bool_:
+        vol = vol.view(np.uint8)
+    given = vol.shape
+    if vol.ndim > 3 and any(extent != 1 for extent in given[3:]):
+        raise DimensionError(
+            "Input labels may be no more than three non-trivial dimensions. Got: {}".format(given))
+    return vol.reshape((given + (1, 1, 1))[:3], order="F")
 
 
 def apply_object_mask(all_labels, object_ids):
