@@ -33,6 +33,8 @@ class Engine:
         self.lib = _abi.require_gpu()
         self.torch = _torch()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
+        # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
+        self.torch.cuda.set_device(self.device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
         self._side = None     # second stream: the biggest labels run there while the others are collected
         self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally

@@ -190,6 +190,34 @@ class Skeleton:
                 newid[u], int(self.vertex_types[u]), x, y, z, self.radii[u], p))
         return "\n".join(lines) + "\n"
 
+    def to_precomputed(self):
+        """the Neuroglancer "precomputed" skeleton encoding cloud-volume / osteoid write (row f4): u32 vertex and edge
+        counts, f32 vertices (n, 3), u32 edges (m, 2), then the vertex attributes in the order of
+        `extra_attributes` (radius f32, vertex_types u8), all little endian."""
+        v = np.ascontiguousarray(self.vertices, dtype="<f4")
+        e = np.ascontiguousarray(self.edges, dtype="<u4")
+        parts = [np.array([v.shape[0], e.shape[0]], dtype="<u4").tobytes(), v.tobytes(), e.tobytes()]
+        for attr in self.extra_attributes:
+            data = {"radius": self.radii, "vertex_types": self.vertex_types}[attr["id"]]
+            parts.append(np.ascontiguousarray(data, dtype=np.dtype(attr["data_type"]).newbyteorder("<")).tobytes())
+        return b"".join(parts)
+
+    @classmethod
+    def from_precomputed(cls, blob, segid=None, transform=None, space="physical"):
+        """inverse of to_precomputed (default attribute set: radius f32, vertex_types u8)."""
+        nv, ne = (int(x) for x in np.frombuffer(blob, dtype="<u4", count=2))
+        off = 8
+        verts = np.frombuffer(blob, dtype="<f4", count=3 * nv, offset=off).reshape(nv, 3)
+        off += 12 * nv
+        edges = np.frombuffer(blob, dtype="<u4", count=2 * ne, offset=off).reshape(ne, 2)
+        off += 8 * ne
+        radii = np.frombuffer(blob, dtype="<f4", count=nv, offset=off)
+        off += 4 * nv
+        vtypes = np.frombuffer(blob, dtype="u1", count=nv, offset=off)
+        if off + nv != len(blob):
+            raise ValueError("precomputed skeleton: %d trailing bytes" % (len(blob) - off - nv))
+        return cls(verts.copy(), edges.copy(), radii.copy(), vtypes.copy(), segid=segid, transform=transform, space=space)
+
     def to_osteoid(self):
         try:
             import osteoid

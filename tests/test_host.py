@@ -126,3 +126,18 @@ def test_oracle_pool_equals_serial_oracle():
         np.testing.assert_array_equal(a[k].vertices, b[k].vertices)
         np.testing.assert_array_equal(a[k].edges, b[k].edges)
         np.testing.assert_array_equal(a[k].radii, b[k].radii)
+
+
+def test_precomputed_roundtrip():
+    """Skeleton.to_precomputed / from_precomputed (the wire format of row f4): byte layout and round trip."""
+    from kimimaro_amd.skeleton import Skeleton
+    a = Skeleton([[0, 0, 0], [16, 16, 40], [32, 16, 80]], [[0, 1], [1, 2]], radii=[1.5, 2.5, 3.5], vertex_types=[0, 1, 2], segid=7,
+                 space="physical")
+    blob = a.to_precomputed()
+    assert len(blob) == 8 + 3 * 12 + 2 * 8 + 3 * 4 + 3
+    assert np.frombuffer(blob, "<u4", 2).tolist() == [3, 2]
+    b = Skeleton.from_precomputed(blob, segid=7)
+    assert a == b and b.vertex_types.tolist() == [0, 1, 2]
+    assert Skeleton.from_precomputed(Skeleton().to_precomputed()).empty()
+    with pytest.raises(ValueError):
+        Skeleton.from_precomputed(blob + b"x")
