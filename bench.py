@@ -23,6 +23,13 @@ per-label scratch of all its components).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
+Steps in flight (--inflight F, default 4): the wall clock of ONE volume is the chain of its largest component -- a
+handful of workgroups for seconds while the rest of the GPU idles.  The K timed steps are therefore
+issued from F host threads, each with a HIP stream, an Engine and scratch of its own, so that the tail of one volume
+overlaps the next ones; every step still does all of its work inside the timed region and ms_per_step = wall / K.  The
+latency of a single volume on an otherwise idle GPU is measured in the same run (untimed) and printed as
+single_volume_ms; --inflight 1 times the steps one after the other.
+
 Extra objects on the JSON line:
   roofline      EDT pass kernel (the kernel BASELINE.json's metric names): algorithmic bytes / the
                 pass duration measured with HIP events on the launch stream (kh_edt_timed).
@@ -144,9 +151,14 @@ def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("KIMI_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KIMI_BENCH_INFLIGHT", "4")),
+                    help="volumes in flight per GPU: consecutive steps are issued from that many host threads, each on a HIP "
+                         "stream and with scratch of its own, so the tail of one volume (a handful of workgroups tracing its "
+                         "largest components) overlaps the next volumes.  1 = one step after the other (the latency "
+                         "of a single volume, which is reported either way as single_volume_ms).")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-borders", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("KIMI_BENCH_SCALING", "strong"),
@@ -237,25 +249,86 @@ def main():
         orig = state["flat"][rep[1:].astype(np.int64)]
         return d_cc, n, {i + 1: orig[i].item() for i in range(n)}
 
-    def step():
-        d_cc, nlabels, remapping = components()
-        cc = intake.LazyVolume(eng, d_cc, state["lab"].shape)
-        local = intake.skeletonize_cc(eng, cc, nlabels, remapping, params, an, dust, True, fix_borders,
-                                      empty, empty, black_border=False, rank=state["shard"][0], world=state["shard"][1], d_cc=d_cc)
+    def local_step(e):
+        """the whole step of this rank's share on engine e (current stream of the calling thread); host skeletons."""
+        lab = state["lab"]
+        d_cc, nlabels, rep_ = e.ccl_device(state["d_lab"], lab.dtype.itemsize, lab.shape)
+        orig = state["flat"][rep_[1:].astype(np.int64)]
+        remapping = {i + 1: orig[i].item() for i in range(nlabels)}
+        cc = intake.LazyVolume(e, d_cc, lab.shape)
+        return intake.skeletonize_cc(e, cc, nlabels, remapping, params, an, dust, True, fix_borders,
+                                     empty, empty, black_border=False, rank=state["shard"][0], world=state["shard"][1], d_cc=d_cc)
+
+    def finish(local):
         if world > 1:
             local = gather_skeletons(local, device=eng.device if backend == "nccl" else None)
         result["skels"] = local
         return local
 
+    def step():
+        return finish(local_step(eng))
+
+    # volumes in flight: one host thread + HIP stream + Engine (scratch from that stream's pool) each.  The collective of
+    # a step is issued by the calling thread, in step order, so every rank issues the same sequence.
+    import threading
+    inflight = max(1, args.inflight)
+    lanes = [(Engine(), torch.cuda.Stream(device=eng.device)) for _ in range(inflight)] if inflight > 1 else []
+    for e, _ in lanes:
+        # a lane needs no second stream for its largest components: the other lanes are what overlaps their tail
+        e.split_slots = int(os.environ.get("KIMI_LANE_SPLIT", "0"))
+
+    def run_steps(n, width=None):
+        width = inflight if width is None else width
+        if width <= 1 or n <= 0:
+            for _ in range(n):
+                step()
+            return
+        lock = threading.Lock()
+        nxt = [0]
+        out = [None] * n
+        ready = [threading.Event() for _ in range(n)]
+
+        def worker(e, s):
+            torch.cuda.set_device(e.device)
+            with torch.cuda.stream(s):
+                while True:
+                    with lock:
+                        k = nxt[0]
+                        nxt[0] += 1
+                    if k >= n:
+                        return
+                    try:
+                        out[k] = local_step(e)
+                        s.synchronize()
+                    except BaseException as ex:  # handed to the caller
+                        out[k] = ex
+                    ready[k].set()
+
+        threads = [threading.Thread(target=worker, args=lane, daemon=True) for lane in lanes[:width]]
+        for th in threads:
+            th.start()
+        for k in range(n):
+            ready[k].wait()
+            if isinstance(out[k], BaseException):
+                raise out[k]
+            finish(out[k])
+            out[k] = None
+        for th in threads:
+            th.join()
+
     def measure(warmup, steps):
-        for _ in range(warmup):
-            step()
+        if inflight > 1:
+            run_steps(inflight)            # every lane once: fills the scratch pool of its stream (not a warm-up step)
+        t1 = time.perf_counter()
+        step()                             # one volume alone on the default stream: its latency (also untimed)
+        torch.cuda.synchronize()
+        state["single_ms"] = (time.perf_counter() - t1) * 1e3
+        run_steps(warmup)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run_steps(steps)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -389,6 +462,7 @@ def main():
         "metric": "labels/sec on a dense connectomics-shaped volume (skeletonize hot path, labels resident in HBM)",
         "value": round(value, 3), "unit": "labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
+        "volumes_in_flight": inflight, "single_volume_ms": round(state.get("single_ms", float("nan")), 3),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "
                                "default teasar_params, fix_branching=True, fix_borders=%s, dust_threshold=%d"
@@ -397,7 +471,8 @@ def main():
                    "parallelism": ("one such volume per GPU (mirrored copies, own label ids) on %d GPU(s), no data-path "
                                    "collective, skeleton all-gather-v at the end" % world) if args.scaling == "weak" else
                                   ("components of ONE volume dealt over %d GPU(s) (largest first to the least loaded rank), "
-                                   "skeleton all-gather-v" % world)},
+                                   "skeleton all-gather-v" % world),
+                   "volumes_in_flight": inflight},
         "skeletons": nskel, "labels_per_s_by_label_count": round(nskel * (world if args.scaling == "weak" else 1) / (ms_per_step / 1e3), 3),
         "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,

@@ -11,6 +11,7 @@ its own workgroup (kimimaro/intake.py:434-517 runs them one after the other on c
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
 
 import numpy as np
@@ -41,6 +42,10 @@ class Engine:
         self.split_min_voxels = 16384       # ... if they have at least this many voxels
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
+        # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
+        # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
+        # instead of LDS (2 per CU at 16384) -- +20 % labels/s with several volumes in flight, nothing for a single one.
+        self.sweep_lds_levels = min(int(os.environ.get("KH_SWEEP_LDS_LEVELS", 8192)), _abi.SWEEP_LDS_LEVELS)
         self._level_tables = {}
         self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
 
@@ -249,10 +254,10 @@ class Engine:
             if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
                 shift = 7 if cnt >= 32768 else 6
                 chunks = min(nlev + nlev // 2 + ((14 * cnt) >> shift) + 64, (1 << 22) - 2)
-                wunits = (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256 if nlev > _abi.SWEEP_LDS_LEVELS else 0
+                wunits = (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256 if nlev > self.sweep_lds_levels else 0
                 ev_units = wunits + ((chunks * 8) << shift) // 256
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
-                max_nlev = nlev if nlev <= _abi.SWEEP_LDS_LEVELS else 0
+                max_nlev = nlev if nlev <= self.sweep_lds_levels else 0
             else:
                 d_rank = None
         d_arena = self.empty(max(ev_units, 1) * 32 + 32, t.int64)
@@ -358,7 +363,7 @@ class Engine:
                 # ever used + about 12 events per voxel, with slack
                 shift = np.where(cnt >= 32768, 7, 6).astype(np.int64)
                 chunks = np.minimum(nlev + nlev // 2 + ((14 * cnt) >> shift) + 64, (1 << 22) - 2)
-                wunits = np.where(nlev > _abi.SWEEP_LDS_LEVELS, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
+                wunits = np.where(nlev > self.sweep_lds_levels, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
                 units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
                 ev_total = int(units.sum())
@@ -372,7 +377,7 @@ class Engine:
                 tasks["ev_shift"] = shift
                 if int(nlev.max()) == 0:
                     d_rank = None
-                fits = nlev[nlev <= _abi.SWEEP_LDS_LEVELS]
+                fits = nlev[nlev <= self.sweep_lds_levels]
                 max_nlev = int(fits.max()) if fits.size else 0
         tgt = []
         tgt_off = np.zeros(nl, dtype=np.int64)
