@@ -23,7 +23,7 @@ per-label scratch of all its components).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
-Steps in flight (--inflight F, default 4): the wall clock of ONE volume is the chain of its largest component -- a
+Steps in flight (--inflight F; default 4, and 6 / 8 / 12 for the strong mode on 2 / 4 / 8 GPUs): the wall clock of ONE volume is the chain of its largest component -- a
 handful of workgroups for seconds while the rest of the GPU idles.  The K timed steps are therefore
 issued from F host threads, each with a HIP stream, an Engine and scratch of its own, so that the tail of one volume
 overlaps the next ones; every step still does all of its work inside the timed region and ms_per_step = wall / K.  The
@@ -154,10 +154,12 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("KIMI_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KIMI_BENCH_INFLIGHT", "4")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KIMI_BENCH_INFLIGHT", "0")),
                     help="volumes in flight per GPU: consecutive steps are issued from that many host threads, each on a HIP "
                          "stream and with scratch of its own, so the tail of one volume (a handful of workgroups tracing its "
-                         "largest components) overlaps the next volumes.  1 = one step after the other (the latency "
+                         "largest components) overlaps the next volumes.  0 (default) = 4, and 6 / 8 / 12 for the strong mode on "
+                         "2 / 4 / 8 GPUs (a rank's share of a volume is smaller there, the chain of its largest component "
+                         "is not).  1 = one step after the other (the latency "
                          "of a single volume, which is reported either way as single_volume_ms).")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-borders", action="store_true")
@@ -268,67 +270,47 @@ def main():
     def step():
         return finish(local_step(eng))
 
-    # volumes in flight: one host thread + HIP stream + Engine (scratch from that stream's pool) each.  The collective of
-    # a step is issued by the calling thread, in step order, so every rank issues the same sequence.
-    import threading
-    inflight = max(1, args.inflight)
-    lanes = [(Engine(), torch.cuda.Stream(device=eng.device)) for _ in range(inflight)] if inflight > 1 else []
-    for e, _ in lanes:
-        # a lane needs no second stream for its largest components: the other lanes are what overlaps their tail
-        e.split_slots = int(os.environ.get("KIMI_LANE_SPLIT", "0"))
+    # volumes in flight (kimimaro_amd/lanes.py): one host thread + HIP stream + Engine per lane.  The collective of a step
+    # is issued by this thread, in step order, so every rank issues the same sequence.
+    from kimimaro_amd.lanes import Lanes
+    def width_of(mode):
+        if args.inflight > 0:
+            return args.inflight
+        if mode == "strong" and world > 1:
+            return 6 if world == 2 else 8 if world <= 4 else 12
+        return 4
 
-    def run_steps(n, width=None):
-        width = inflight if width is None else width
-        if width <= 1 or n <= 0:
+    widths = {m: width_of(m) for m in (("weak", "strong") if world > 1 else (args.scaling,))}
+    lanes = Lanes(max(widths.values()), device=eng.device) if max(widths.values()) > 1 else None
+
+    def run_steps(n, width):
+        if lanes is None or width <= 1:
             for _ in range(n):
-                step()
+                finish(local_step(lanes.engines[0] if lanes is not None else eng))
             return
-        lock = threading.Lock()
-        nxt = [0]
-        out = [None] * n
-        ready = [threading.Event() for _ in range(n)]
+        for _, local in lanes.run(lambda e, k: local_step(e), n, width=width):
+            finish(local)
 
-        def worker(e, s):
-            torch.cuda.set_device(e.device)
-            with torch.cuda.stream(s):
-                while True:
-                    with lock:
-                        k = nxt[0]
-                        nxt[0] += 1
-                    if k >= n:
-                        return
-                    try:
-                        out[k] = local_step(e)
-                        s.synchronize()
-                    except BaseException as ex:  # handed to the caller
-                        out[k] = ex
-                    ready[k].set()
-
-        threads = [threading.Thread(target=worker, args=lane, daemon=True) for lane in lanes[:width]]
-        for th in threads:
-            th.start()
-        for k in range(n):
-            ready[k].wait()
-            if isinstance(out[k], BaseException):
-                raise out[k]
-            finish(out[k])
-            out[k] = None
-        for th in threads:
-            th.join()
-
-    def measure(warmup, steps):
-        if inflight > 1:
-            run_steps(inflight)            # every lane once: fills the scratch pool of its stream (not a warm-up step)
-        t1 = time.perf_counter()
-        step()                             # one volume alone on the default stream: its latency (also untimed)
-        torch.cuda.synchronize()
-        state["single_ms"] = (time.perf_counter() - t1) * 1e3
-        run_steps(warmup)
+    def measure(mode, warmup, steps, latency=True):
+        width = widths[mode]
+        torch.cuda.empty_cache()           # scratch of the other mode / of the preparation goes back to the device
+        if width > 1:
+            run_steps(width, width)        # every lane once: fills the scratch pool of its stream (not a warm-up step)
+        if latency:
+            t1 = time.perf_counter()
+            if lanes is not None:          # one volume alone on an otherwise idle GPU: its latency (also untimed)
+                for _, local in lanes.run(lambda e, k: local_step(e), 1, width=1):
+                    finish(local)
+            else:
+                step()
+            torch.cuda.synchronize()
+            state["single_ms"] = (time.perf_counter() - t1) * 1e3
+        run_steps(warmup, width)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(steps)
+        run_steps(steps, width)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -344,11 +326,14 @@ def main():
     if world > 1:
         omode = "weak" if args.scaling == "strong" else "strong"
         prepare(omode)
-        osteps = max(1, min(args.steps, 2))
-        oel = measure(1, osteps)
+        osteps = max(1, min(args.steps, 4))
+        oel = measure(omode, 1, osteps, latency=False)
         other = {"mode": omode, "elapsed": oel, "steps": osteps, "skeletons": len(result["skels"])}
     preamble_s = prepare(args.scaling)
-    elapsed = measure(args.warmup, args.steps)
+    elapsed = measure(args.scaling, args.warmup, args.steps)
+    inflight = widths[args.scaling]
+    lanes = None
+    torch.cuda.empty_cache()
     lab = state["lab"]
     shape = lab.shape
     nskel = len(result["skels"])
@@ -363,7 +348,7 @@ def main():
         oms = other["elapsed"] / other["steps"] * 1e3
         ounits = ncomp * (world if other["mode"] == "weak" else 1)
         other = {"scaling": other["mode"], "value": round(ounits / (oms / 1e3), 3), "unit": "labels/s", "ms_per_step": round(oms, 3),
-                 "steps": other["steps"], "warmup": 1, "skeletons": other["skeletons"],
+                 "steps": other["steps"], "warmup": 1, "skeletons": other["skeletons"], "volumes_in_flight": widths[other["mode"]],
                  "note": ("every GPU its own volume of the workload's size (mirrored copies, own label ids)" if other["mode"] == "weak"
                           else "components of ONE volume dealt over the GPUs")}
 
@@ -463,6 +448,7 @@ def main():
         "value": round(value, 3), "unit": "labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
         "volumes_in_flight": inflight, "single_volume_ms": round(state.get("single_ms", float("nan")), 3),
+        "hbm_reserved_peak_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "
                                "default teasar_params, fix_branching=True, fix_borders=%s, dust_threshold=%d"

@@ -33,7 +33,9 @@ class Engine:
     def __init__(self, device=None):
         self.lib = _abi.require_gpu()
         self.torch = _torch()
-        self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
+        if device is None:
+            device = self.torch.cuda.current_device()
+        self.device = self.torch.device("cuda", device) if isinstance(device, int) else self.torch.device(device)
         # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
         self.torch.cuda.set_device(self.device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)

@@ -1,0 +1,69 @@
+"""Host logic of kimimaro_amd.lanes (several volumes in flight): order of the results, bounded width, error hand-over.
+No GPU: the lanes get stand-in engines."""
+import threading
+import time
+
+import pytest
+
+from kimimaro_amd.lanes import Lanes
+
+
+class _Eng:
+    pass
+
+
+def _lanes(width):
+    return Lanes(width, engine_factory=_Eng, stream_factory=None)
+
+
+def test_results_come_back_in_order_and_lanes_overlap():
+    lanes = _lanes(3)
+    live = [0]
+    peak = [0]
+    lock = threading.Lock()
+    seen_engines = set()
+
+    def job(eng, k):
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+            seen_engines.add(id(eng))
+        time.sleep(0.05 if k % 2 == 0 else 0.01)     # later jobs finish before earlier ones
+        with lock:
+            live[0] -= 1
+        return k * k
+
+    got = list(lanes.run(job, 9))
+    assert got == [(k, k * k) for k in range(9)]
+    assert 2 <= peak[0] <= 3
+    assert len(seen_engines) <= 3
+
+
+def test_width_one_and_empty():
+    lanes = _lanes(2)
+    assert list(lanes.run(lambda e, k: k, 0)) == []
+    order = []
+    assert [v for _, v in lanes.run(lambda e, k: order.append(k) or k, 4, width=1)] == [0, 1, 2, 3]
+    assert order == [0, 1, 2, 3]
+
+
+def test_exception_is_raised_at_its_position():
+    lanes = _lanes(2)
+
+    def job(eng, k):
+        if k == 2:
+            raise ValueError("job 2")
+        return k
+
+    out = []
+    with pytest.raises(ValueError, match="job 2"):
+        for k, v in lanes.run(job, 6):
+            out.append(v)
+    assert out == [0, 1]
+    # the lanes are usable again
+    assert [v for _, v in lanes.run(lambda e, k: k + 1, 3)] == [1, 2, 3]
+
+
+def test_bad_width():
+    with pytest.raises(ValueError):
+        _lanes(0)
