@@ -30,6 +30,8 @@ def build(force=False, verbose=False):
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    extra = os.environ.get("KH_HIPCC_DEFINES", "").split()   # developer probes, e.g. -DKH_SWEEP_PROBE (csrc/sweep.h)
+    cmd[1:1] = extra
     subprocess.check_call(cmd)
     return LIB
 

@@ -52,6 +52,9 @@ struct SweepShared {
   uint32_t na, nb, nnp, bump, nkill, snap, bail;
   int32_t nM;
   uint32_t levels, events, maxnev;
+#ifdef KH_SWEEP_PROBE
+  unsigned long long cyc[8];   // developer probe: cycles per phase of the level loop (thread 0's clock)
+#endif
 };
 
 struct Sweep {
@@ -108,27 +111,37 @@ __device__ __forceinline__ bool sweep_eval(const Sweep& s, const uint4 src, int 
 
 // Event storage.  A level's events live in a chain of fixed-size chunks (slot 0 of a chunk = id of the previous
 // chunk of the level); the level's LDS word holds the newest chunk and its next free slot.
-// sweep_push appends an event to level lv.  Lock-free on the LDS word and free of wait states (a lane never waits
-// for another lane's future action, which lock-step execution could not deliver): next free slot < CH -> take it
-// with a CAS; chunk full (or empty level) -> install a fresh chunk with a CAS, its slot 1 is ours; a lost race
-// just retries, and the chunk it had reserved stays with the thread (`spare`) for its next opening.
+// sweep_push appends an event to level lv.  Free of wait states (a lane never waits for another lane's future action,
+// which lock-step execution could not deliver).  Fast path: one atomic add on the level word takes the next slot -- no
+// retry however many lanes push to the same level at once (a CAS here costs a retry per concurrent pusher, and a busy
+// level has hundreds).  A lane whose add finds the chunk full (or the level empty: the empty word reads as full)
+// installs a fresh chunk with a CAS on the overfull word and takes its slot 1; whoever loses that race just starts over,
+// and the chunk it had reserved stays with the thread (`spare`) for its next opening.  The fill field of a full chunk
+// keeps counting (at most one add per thread before the install: < 1024), readers clamp it to the chunk size.
 __device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint32_t lv, uint32_t vox, uint32_t meta) {
   uint32_t* word = &s.words[lv];
   const uint32_t CH = 1u << s.shift;
   for (;;) {
-    const uint32_t w = sweep_ld(word);
+    const uint32_t w = atomicAdd(word, 1u);
     const uint32_t fill = w & 1023u;
     if (fill < CH) {
-      if (atomicCAS(word, w, w + 1u) != w) continue;
       s.chunks[((size_t)(w >> 10) << s.shift) + fill] = make_uint2(vox, meta);
       return;
     }
     if (spare == SW_NONE) spare = atomicAdd(&s.sh->bump, 1u);
     const uint32_t id = spare;
     if (id >= s.chcap || id >= SW_NOCHUNK) { sweep_bail(s, SW_BAIL_ARENA); return; }   // the call is abandoned
-    if (atomicCAS(word, w, (id << 10) | 2u) != w) continue;
+    bool mine = false;
+    uint32_t cur = w + 1u;
+    for (;;) {
+      if ((cur & 1023u) < CH) break;                       // somebody installed a chunk: take a slot of it
+      const uint32_t old = atomicCAS(word, cur, (id << 10) | 2u);
+      if (old == cur) { mine = true; break; }
+      cur = old;
+    }
+    if (!mine) continue;
     spare = SW_NONE;
-    const uint32_t prev = w >> 10;
+    const uint32_t prev = cur >> 10;
     if (prev == SW_NOCHUNK) atomicOr(&s.lvbits[lv >> 5], 1u << (lv & 31u));
     uint2* c = s.chunks + ((size_t)id << s.shift);
     c[0] = make_uint2(prev, 0u);
@@ -143,10 +156,65 @@ __device__ __forceinline__ void sweep_coords(const Sweep& s, uint32_t v, int& x,
   z = (int)zz; y = (int)yy; x = (int)(r - yy * sx);
 }
 
+// ---- neighbour batches.  An event looks at its 26 neighbours; done one after the other that is a chain of ~50
+// dependent L2 round trips per event (alive byte, then rank word, per neighbour) and the sweep is nothing but such
+// chains.  The helpers below issue the loads of all neighbours before any is consumed (full unrolling, addresses made
+// valid by predication instead of branches), so an event costs a handful of round trips.
+__device__ __forceinline__ uint32_t sweep_alive_nbrs(const Sweep& s, uint32_t v, uint32_t nm) {
+  const int sx = s.g->sx, sxy = s.g->sxy;
+  uint32_t am = 0;
+#pragma unroll
+  for (int k = 0; k < 26; k++) {
+    int dx, dy, dz;
+    dir_delta(k, dx, dy, dz);
+    const uint32_t q = ((nm >> k) & 1u) ? v + (uint32_t)(dx + sx * dy + sxy * dz) : v;
+    am |= (uint32_t)(s.alive[q] != 0) << k;
+  }
+  return am & nm;
+}
+// neighbours K0 .. K0+12 of (x, y, z) that are in `am` and inside the ball of src: coverage mask (bit k) + their ranks
+template <int K0>
+__device__ __forceinline__ uint32_t sweep_eval13(const Sweep& s, const uint4 src, int x, int y, int z, uint32_t am,
+                                                 uint32_t (&rk)[13]) {
+  const float r = __uint_as_float(src.w);
+  const float wx = s.g->wx, wy = s.g->wy, wz = s.g->wz;
+  uint32_t cov = 0;
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    const int k = K0 + j;
+    int dx, dy, dz;
+    dir_delta(k, dx, dy, dz);
+    const int ex = x + dx - (int)src.x, ey = y + dy - (int)src.y, ez = z + dz - (int)src.z;
+    const float a = wx * (float)ex;
+    const float b = wy * (float)ey;
+    const float c = wz * (float)ez;
+    float t = a * a;
+    const float u = b * b;
+    const float w = c * c;
+    t = t + u;
+    t = t + w;
+    const float d = sqrtf(t);
+    const bool in = ((am >> k) & 1u) && d < r;
+    const int ax = ex < 0 ? -ex : ex, ay = ey < 0 ? -ey : ey, az = ez < 0 ? -ez : ez;
+    rk[j] = s.rank[in ? ax + s.ra * (ay + s.rb * az) : 0];
+    cov |= (uint32_t)in << k;
+  }
+  return cov;
+}
+__device__ __forceinline__ uint32_t sweep_pick13(const uint32_t (&a)[13], int j) {
+  uint32_t r = a[0];
+#pragma unroll
+  for (int i = 1; i < 13; i++) r = (j == i) ? a[i] : r;
+  return r;
+}
+
 // a P event (c may own v from this level on)
 __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uint32_t v, uint32_t c, bool has_deadline) {
-  if (!s.alive[v]) return;
+  const uint8_t live = s.alive[v];
   unsigned long long cs = s.cstate[v];
+  const uint32_t nm = s.nbrmask[v];
+  const uint4 src = s.srcs[c];
+  if (!live) return;
   unsigned long long want;
   for (;;) {
     int freeslot = -1;
@@ -168,28 +236,34 @@ __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uin
     if (p < s.ncap) s.np[p] = ((unsigned long long)v << 32) | c; else sweep_bail(s, SW_BAIL_LIST);
   }
   // cascade: neighbours whose key from c is not above this level may be owned by c inside this level
-  const uint32_t nm = s.nbrmask[v];
-  const uint4 src = s.srcs[c];
+  const uint32_t am = sweep_alive_nbrs(s, v, nm);
+  if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
-  for (uint32_t m = nm; m; m &= m - 1u) {
+  uint32_t lm = 0;
+  {
+    uint32_t rk[13];
+    const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk);
+#pragma unroll
+    for (int j = 0; j < 13; j++) lm |= (uint32_t)(((cov >> j) & 1u) && rk[j] <= lvl) << j;
+  }
+  {
+    uint32_t rk[13];
+    const uint32_t cov = sweep_eval13<13>(s, src, x, y, z, am, rk);
+#pragma unroll
+    for (int j = 0; j < 13; j++) lm |= (uint32_t)(((cov >> (13 + j)) & 1u) && rk[j] <= lvl) << (13 + j);
+  }
+  for (uint32_t m = lm; m; m &= m - 1u) {
     const int k = __ffs((int)m) - 1;
     const uint32_t q = v + (uint32_t)s.g->off[k];
-    if (!s.alive[q]) continue;
-    int dx, dy, dz;
-    dir_delta(k, dx, dy, dz);
-    uint32_t rk;
-    if (!sweep_eval(s, src, x + dx, y + dy, z + dz, rk)) continue;
-    if (rk <= lvl) {
-      // (a cheap look keeps most duplicates out of the list; the real test is the CAS of the entry's own turn)
-      const unsigned long long qs = s.cstate[q];
-      bool have = false;
+    // (a cheap look keeps most duplicates out of the list; the real test is the CAS of the entry's own turn)
+    const unsigned long long qs = s.cstate[q];
+    bool have = false;
 #pragma unroll
-      for (int i = 0; i < 4; i++) have = have || ((uint32_t)(qs >> (16 * i)) & 0x7fffu) == c + 1u;
-      if (have) continue;
-      const uint32_t p = atomicAdd(&s.sh->na, 1u);
-      if (p < s.ncap) s.wa[p] = ((unsigned long long)q << 32) | c; else sweep_bail(s, SW_BAIL_LIST);
-    }
+    for (int i = 0; i < 4; i++) have = have || ((uint32_t)(qs >> (16 * i)) & 0x7fffu) == c + 1u;
+    if (have) continue;
+    const uint32_t p = atomicAdd(&s.sh->na, 1u);
+    if (p < s.ncap) s.wa[p] = ((unsigned long long)q << 32) | c; else sweep_bail(s, SW_BAIL_LIST);
   }
 }
 
@@ -197,23 +271,55 @@ __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uin
 __device__ __forceinline__ void sweep_emit_possible(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v, uint32_t c) {
   const uint32_t nm = s.nbrmask[v];
   const uint4 src = s.srcs[c];
+  const uint32_t am = sweep_alive_nbrs(s, v, nm);
+  if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
-  for (uint32_t m = nm; m; m &= m - 1u) {
-    const int k = __ffs((int)m) - 1;
-    const uint32_t q = v + (uint32_t)s.g->off[k];
-    if (!s.alive[q]) continue;
-    int dx, dy, dz;
-    dir_delta(k, dx, dy, dz);
-    uint32_t rk;
-    if (!sweep_eval(s, src, x + dx, y + dy, z + dz, rk)) continue;
-    if (rk > lvl) sweep_push(s, spare, rk, q, c | SW_P);
+  {
+    uint32_t rk[13];
+    const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk);
+    for (uint32_t m = cov & 0x1fffu; m; m &= m - 1u) {
+      const int k = __ffs((int)m) - 1;
+      const uint32_t r = sweep_pick13(rk, k);
+      if (r > lvl) sweep_push(s, spare, r, v + (uint32_t)s.g->off[k], c | SW_P);
+    }
+  }
+  {
+    uint32_t rk[13];
+    const uint32_t cov = sweep_eval13<13>(s, src, x, y, z, am, rk);
+    for (uint32_t m = cov >> 13; m; m &= m - 1u) {
+      const int j = __ffs((int)m) - 1;
+      const uint32_t r = sweep_pick13(rk, j);
+      if (r > lvl) sweep_push(s, spare, r, v + (uint32_t)s.g->off[13 + j], c | SW_P);
+    }
+  }
+}
+
+// the neighbours of a dying voxel with a single candidate source: covered ones die with it (deadline at their own key)
+template <int K0>
+__device__ __forceinline__ void sweep_deadline_one13(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v, uint32_t cid,
+                                                     const uint4 src, int x, int y, int z, uint32_t am) {
+  uint32_t rk[13];
+  const uint32_t cov = sweep_eval13<K0>(s, src, x, y, z, am, rk);
+  for (uint32_t m = (cov >> K0) & 0x1fffu; m; m &= m - 1u) {
+    const int j = __ffs((int)m) - 1;
+    const uint32_t tr = sweep_pick13(rk, j);
+    const uint32_t q = v + (uint32_t)s.g->off[K0 + j];
+    if (tr <= lvl) {
+      if (s.cstate[q] & SW_DYING) continue;
+      const uint32_t p = atomicAdd(&s.sh->nb, 1u);
+      if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
+    } else {
+      sweep_push(s, spare, tr, q, cid | SW_P | SW_D);
+    }
   }
 }
 
 // a D event: v is dead once this level is complete
 __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v) {
-  if (!s.alive[v]) return;
+  const uint8_t live = s.alive[v];
+  const uint32_t nm = s.nbrmask[v];
+  if (!live) return;
   const unsigned long long old = atomicOr(&s.cstate[v], SW_DYING);
   if (old & SW_DYING) return;
   if (old == 0ull) { sweep_bail(s, SW_BAIL_UNTOUCHED); return; }
@@ -226,13 +332,18 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
     const uint32_t sl = (uint32_t)(old >> (16 * i)) & 0x7fffu;
     if (sl) { cid[nc] = sl - 1u; src[nc] = s.srcs[sl - 1u]; nc++; }
   }
-  const uint32_t nm = s.nbrmask[v];
+  const uint32_t am = sweep_alive_nbrs(s, v, nm);
+  if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
-  for (uint32_t m = nm; m; m &= m - 1u) {
+  if (nc == 1) {
+    sweep_deadline_one13<0>(s, spare, lvl, v, cid[0], src[0], x, y, z, am);
+    sweep_deadline_one13<13>(s, spare, lvl, v, cid[0], src[0], x, y, z, am);
+    return;
+  }
+  for (uint32_t m = am; m; m &= m - 1u) {
     const int k = __ffs((int)m) - 1;
     const uint32_t q = v + (uint32_t)s.g->off[k];
-    if (!s.alive[q]) continue;
     int dx, dy, dz;
     dir_delta(k, dx, dy, dz);
     bool all = true;
@@ -249,12 +360,11 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
         const uint32_t p = atomicAdd(&s.sh->nb, 1u);
         if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
       } else {
-        sweep_push(s, spare, tr, q, nc == 1 ? (cid[0] | SW_P | SW_D) : SW_D);
+        sweep_push(s, spare, tr, q, SW_D);
       }
     }
-    if (nc > 1)
-      for (int i = 0; i < nc; i++)
-        if (cov[i] && rk[i] > lvl) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
+    for (int i = 0; i < nc; i++)
+      if (cov[i] && rk[i] > lvl) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
   }
 }
 
@@ -269,7 +379,7 @@ __device__ __forceinline__ uint2 sweep_event(const Sweep& s, uint32_t e, uint32_
 // Whole workgroup.  path / npath: the vertices of the new path; srcs has room for npath records.
 // Returns true when certified (alive updated, *count = voxels invalidated); false when the call has to be redone by
 // the heap emulation (alive and cstate are as they were on entry).
-__device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint32_t* path, uint32_t npath, const float* __restrict__ dbf,
+__device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path, uint32_t npath, const float* __restrict__ dbf,
                                                      float scale, float constant, float rmax, const uint32_t* list, uint32_t nf,
                                                      uint32_t* count) {
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -283,6 +393,9 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
     sh->na = sh->nb = sh->nnp = sh->bump = sh->nkill = sh->snap = sh->bail = 0u;
     sh->nM = 0;
     sh->levels = sh->events = sh->maxnev = 0u;
+#ifdef KH_SWEEP_PROBE
+    for (int i = 0; i < 8; i++) sh->cyc[i] = 0;
+#endif
   }
   __syncthreads();
   uint4* srcs = const_cast<uint4*>(s.srcs);
@@ -298,9 +411,16 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
   __syncthreads();
   if (sh->bail) return false;
   for (uint32_t i = tid; i < npath; i += nthr) if (s.alive[path[i]]) sweep_push(s, spare, 0u, path[i], i | SW_P | SW_D);
+#ifdef KH_SWEEP_PROBE
+  long long tq = clock64();
+#define SW_T(i) if (tid == 0) { const long long n_ = clock64(); sh->cyc[i] += n_ - tq; tq = n_; }
+#else
+#define SW_T(i)
+#endif
   uint32_t next_from = 0, committed = 0;
   for (;;) {
     __syncthreads();
+    SW_T(5)   // pairs of pure P events (end of the previous level)
     // ---- commit the previous level (every push of it is done) and find the next non-empty level
     const uint32_t k1 = sh->nkill;   // stable: no deadline runs in this phase
     for (uint32_t i = committed + tid; i < k1; i += nthr) {
@@ -308,6 +428,7 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
       s.alive[v] = 0;
       s.cstate[v] = 0ull;
     }
+    SW_T(0)   // commit
     if (wave == 0) {
       uint32_t found = SW_NONE;
       const uint32_t w0 = next_from >> 5;
@@ -335,7 +456,7 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
             if (n == SW_CHAIN) { sweep_bail(s, SW_BAIL_LEVEL); found = SW_NONE; sh->lvl = SW_NONE; break; }
             s.chain[n++] = id;
           }
-          const uint32_t newest = (w & 1023u) - 1u;
+          const uint32_t newest = min(w & 1023u, 1u << s.shift) - 1u;   // (the fill of a full chunk keeps counting)
           sh->ord = newest;
           sh->nev = newest + (n - 1u) * ((1u << s.shift) - 1u);
           sh->levels++;
@@ -348,6 +469,7 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
     }
     committed = k1;
     __syncthreads();
+    SW_T(1)   // next level + its chunk chain
     const uint32_t lvl = sh->lvl;
     if (lvl == SW_NONE) break;
     next_from = lvl + 1u;
@@ -358,6 +480,7 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
       if (ev.y & SW_P) sweep_possible(s, lvl, ev.x, ev.y & 0x7fffu, (ev.y & SW_D) != 0u);
     }
     __syncthreads();
+    SW_T(2)   // A
     // cascades (rare).  sh->na is stable whenever it is read here: appends only happen between the two barriers below
     for (uint32_t done = 0;;) {
       const uint32_t avail = sh->na < s.ncap ? sh->na : s.ncap;
@@ -372,12 +495,14 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
       done = end;
       __syncthreads();
     }
+    SW_T(3)   // cascade of A
     // ---- B: deadlines (a voxel's candidates are complete now)
     for (uint32_t e = tid; e < nev; e += nthr) {
       const uint2 ev = sweep_event(s, e, newest);
       if (ev.y & SW_D) sweep_deadline(s, spare, lvl, ev.x);
     }
     __syncthreads();
+    SW_T(6)   // B
     for (uint32_t done = 0;;) {
       const uint32_t avail = sh->nb < s.ncap ? sh->nb : s.ncap;
       if (avail == done) break;
@@ -388,6 +513,7 @@ __device__ __attribute__((noinline)) bool sweep_ball(const Sweep& s, const uint3
       done = end;
       __syncthreads();
     }
+    SW_T(4)   // cascade of B
     // ---- pairs added by pure P events whose voxel survives the level: their possible nodes go out now
     {
       const uint32_t nnp = sh->nnp < s.ncap ? sh->nnp : s.ncap;

@@ -718,6 +718,12 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
       sweep_stats[0]++;
       sweep_stats[2] += sw->sh->levels;
       sweep_stats[3] += sw->sh->events;
+#ifdef KH_SWEEP_PROBE
+      if (blockIdx.x == 0)
+        printf("SWCYC ok=%d lev=%u ev=%u commit=%llu next=%llu A=%llu cascA=%llu B=%llu cascB=%llu pairs=%llu\n", (int)ok,
+               sw->sh->levels, sw->sh->events, sw->sh->cyc[0], sw->sh->cyc[1], sw->sh->cyc[2], sw->sh->cyc[3], sw->sh->cyc[6],
+               sw->sh->cyc[4], sw->sh->cyc[5]);
+#endif
       if (!ok) { sweep_stats[1]++; sweep_stats[4] |= sw->sh->bail; }
       if (sw->sh->maxnev > task->cyc_pop) task->cyc_pop = sw->sh->maxnev;   // diagnostic: busiest level
       if (sw->sh->bump > task->cyc_push) task->cyc_push = sw->sh->bump;      // diagnostic: arena blocks used
@@ -773,7 +779,7 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
 }
 
 template <bool PROF, int TOPL>
-__global__ __launch_bounds__(256) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
+__global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,

@@ -255,7 +255,7 @@ class Engine:
             nlev = int(np.searchsorted(keys, np.float32(rmax), side="left"))
             if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
                 shift = 7 if cnt >= 32768 else 6
-                chunks = min(nlev + nlev // 2 + ((14 * cnt) >> shift) + 64, (1 << 22) - 2)
+                chunks = min(nlev + nlev // 2 + ((14 * cnt) >> shift) + 320, (1 << 22) - 2)
                 wunits = (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256 if nlev > self.sweep_lds_levels else 0
                 ev_units = wunits + ((chunks * 8) << shift) // 256
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
@@ -364,7 +364,7 @@ class Engine:
                 # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
                 # ever used + about 12 events per voxel, with slack
                 shift = np.where(cnt >= 32768, 7, 6).astype(np.int64)
-                chunks = np.minimum(nlev + nlev // 2 + ((14 * cnt) >> shift) + 64, (1 << 22) - 2)
+                chunks = np.minimum(nlev + nlev // 2 + ((14 * cnt) >> shift) + 320, (1 << 22) - 2)
                 wunits = np.where(nlev > self.sweep_lds_levels, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
                 units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
