@@ -242,16 +242,13 @@ __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uin
   sweep_coords(s, v, x, y, z);
   uint32_t lm = 0;
   {
-    uint32_t rk[13];
-    const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk);
+    uint32_t rk0[13], rk1[13];
+    const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
 #pragma unroll
-    for (int j = 0; j < 13; j++) lm |= (uint32_t)(((cov >> j) & 1u) && rk[j] <= lvl) << j;
-  }
-  {
-    uint32_t rk[13];
-    const uint32_t cov = sweep_eval13<13>(s, src, x, y, z, am, rk);
-#pragma unroll
-    for (int j = 0; j < 13; j++) lm |= (uint32_t)(((cov >> (13 + j)) & 1u) && rk[j] <= lvl) << (13 + j);
+    for (int j = 0; j < 13; j++) {
+      lm |= (uint32_t)(((cov >> j) & 1u) && rk0[j] <= lvl) << j;
+      lm |= (uint32_t)(((cov >> (13 + j)) & 1u) && rk1[j] <= lvl) << (13 + j);
+    }
   }
   for (uint32_t m = lm; m; m &= m - 1u) {
     const int k = __ffs((int)m) - 1;
@@ -275,36 +272,24 @@ __device__ __forceinline__ void sweep_emit_possible(const Sweep& s, uint32_t& sp
   if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
-  {
-    uint32_t rk[13];
-    const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk);
-    for (uint32_t m = cov & 0x1fffu; m; m &= m - 1u) {
-      const int k = __ffs((int)m) - 1;
-      const uint32_t r = sweep_pick13(rk, k);
-      if (r > lvl) sweep_push(s, spare, r, v + (uint32_t)s.g->off[k], c | SW_P);
-    }
-  }
-  {
-    uint32_t rk[13];
-    const uint32_t cov = sweep_eval13<13>(s, src, x, y, z, am, rk);
-    for (uint32_t m = cov >> 13; m; m &= m - 1u) {
-      const int j = __ffs((int)m) - 1;
-      const uint32_t r = sweep_pick13(rk, j);
-      if (r > lvl) sweep_push(s, spare, r, v + (uint32_t)s.g->off[13 + j], c | SW_P);
-    }
+  uint32_t rk0[13], rk1[13];
+  const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
+  for (uint32_t m = cov; m; m &= m - 1u) {
+    const int k = __ffs((int)m) - 1;
+    const uint32_t r = k < 13 ? sweep_pick13(rk0, k) : sweep_pick13(rk1, k - 13);
+    if (r > lvl) sweep_push(s, spare, r, v + (uint32_t)s.g->off[k], c | SW_P);
   }
 }
 
 // the neighbours of a dying voxel with a single candidate source: covered ones die with it (deadline at their own key)
-template <int K0>
-__device__ __forceinline__ void sweep_deadline_one13(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v, uint32_t cid,
-                                                     const uint4 src, int x, int y, int z, uint32_t am) {
-  uint32_t rk[13];
-  const uint32_t cov = sweep_eval13<K0>(s, src, x, y, z, am, rk);
-  for (uint32_t m = (cov >> K0) & 0x1fffu; m; m &= m - 1u) {
-    const int j = __ffs((int)m) - 1;
-    const uint32_t tr = sweep_pick13(rk, j);
-    const uint32_t q = v + (uint32_t)s.g->off[K0 + j];
+__device__ __forceinline__ void sweep_deadline_one(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v, uint32_t cid,
+                                                   const uint4 src, int x, int y, int z, uint32_t am) {
+  uint32_t rk0[13], rk1[13];
+  const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
+  for (uint32_t m = cov; m; m &= m - 1u) {
+    const int k = __ffs((int)m) - 1;
+    const uint32_t tr = k < 13 ? sweep_pick13(rk0, k) : sweep_pick13(rk1, k - 13);
+    const uint32_t q = v + (uint32_t)s.g->off[k];
     if (tr <= lvl) {
       if (s.cstate[q] & SW_DYING) continue;
       const uint32_t p = atomicAdd(&s.sh->nb, 1u);
@@ -337,8 +322,7 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
   int x, y, z;
   sweep_coords(s, v, x, y, z);
   if (nc == 1) {
-    sweep_deadline_one13<0>(s, spare, lvl, v, cid[0], src[0], x, y, z, am);
-    sweep_deadline_one13<13>(s, spare, lvl, v, cid[0], src[0], x, y, z, am);
+    sweep_deadline_one(s, spare, lvl, v, cid[0], src[0], x, y, z, am);
     return;
   }
   for (uint32_t m = am; m; m &= m - 1u) {

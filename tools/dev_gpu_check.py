@@ -68,3 +68,11 @@ if tk is not None:
         print("sum over labels without bails: kcyc target/rail/inval", tk["cyc_target"][nb_].astype(np.int64).sum(), tk["cyc_rail"][nb_].astype(np.int64).sum(), tk["cyc_inval"][nb_].astype(np.int64).sum())
     print("labels with bails:", b.size, "their voxels", tk["count"][b].sum(), "of", tk["count"].sum(), "largest such", tk["count"][b].max() if b.size else 0)
     print("pushes total", tk["stat_heap_pushes"].astype(np.int64).sum(), "settled total", tk["stat_settled"].astype(np.int64).sum(), "paths", tk["n_paths"].sum())
+if tk is not None:
+    small = tk["count"] < 32768
+    for nm, sel in (("small (<32768 vox)", small), ("big", ~small)):
+        alloc = tk["ev_chunks"][sel].astype(np.int64) * (8 << tk["ev_shift"][sel].astype(np.int64))
+        used = tk["cyc_push"][sel].astype(np.int64) * (8 << tk["ev_shift"][sel].astype(np.int64))
+        print("arena %s: labels %d, allocated %.2f GB, used (max over calls) %.2f GB, voxels %d, sum nlev %d, max used/alloc %.2f" % (
+            nm, int(sel.sum()), alloc.sum() / 1e9, used.sum() / 1e9, int(tk["count"][sel].sum()), int(tk["nlev"][sel].sum()),
+            float((used / np.maximum(alloc, 1)).max()) if sel.any() else 0))
