@@ -47,6 +47,9 @@ import time
 
 import numpy as np
 
+# one hardware queue per lane stream: with the default of 4, a fifth stream shares a queue and its kernels wait for the
+# seconds-long path kernel queued before them (profiles/r02b_inflight_timeline.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -288,7 +291,10 @@ def main():
             for _ in range(n):
                 finish(local_step(lanes.engines[0] if lanes is not None else eng))
             return
-        for _, local in lanes.run(lambda e, k: local_step(e), n, width=width):
+        # (offsetting the lanes by latency / width -- Lanes.run(stagger=) -- was measured: no gain at 6-8 steps, the ramp
+        # costs what the interleaving wins; KIMI_BENCH_STAGGER=1 turns it on)
+        stagger = state.get("single_ms", 0.0) / 1e3 / width if (n > width and os.environ.get("KIMI_BENCH_STAGGER") == "1") else 0.0
+        for _, local in lanes.run(lambda e, k: local_step(e), n, width=width, stagger=stagger):
             finish(local)
 
     def measure(mode, warmup, steps, latency=True):

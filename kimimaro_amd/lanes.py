@@ -16,6 +16,7 @@ No CPU fallback: a lane is an Engine, and an Engine needs the GPU.
 from __future__ import annotations
 
 import threading
+import time
 
 
 class Lanes:
@@ -37,9 +38,12 @@ class Lanes:
         self.engines = [engine_factory() for _ in range(self.width)]
         self._scopes = [stream_factory(e) if stream_factory is not None else None for e in self.engines]
 
-    def run(self, job, n, width=None):
+    def run(self, job, n, width=None, stagger=0.0):
         """Generator over (k, job(engine, k)) for k = 0..n-1, in order, with at most `width` jobs in flight.  An exception
-        of job k is raised when k is reached (later jobs may have run)."""
+        of job k is raised when k is reached (later jobs may have run).
+        stagger: lane i takes its first job i * stagger seconds after lane 0.  Jobs of equal length started together stay
+        in lock step -- their GPU-filling phases collide and their tails leave the GPU idle together; offset by
+        (duration of one job) / width they interleave."""
         width = self.width if width is None else max(1, min(int(width), self.width))
         if n <= 0:
             return
@@ -49,8 +53,10 @@ class Lanes:
         ready = [threading.Event() for _ in range(n)]
         stop = [False]
 
-        def worker(eng, scope):
+        def worker(eng, scope, delay):
             def loop():
+                if delay > 0:
+                    time.sleep(delay)
                 while True:
                     with lock:
                         k = nxt[0]
@@ -70,7 +76,7 @@ class Lanes:
                 with scope:
                     loop()
 
-        threads = [threading.Thread(target=worker, args=(self.engines[i], self._scopes[i]), daemon=True)
+        threads = [threading.Thread(target=worker, args=(self.engines[i], self._scopes[i], i * float(stagger)), daemon=True)
                    for i in range(min(width, n))]
         for th in threads:
             th.start()
