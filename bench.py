@@ -154,7 +154,7 @@ def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("KIMI_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KIMI_BENCH_INFLIGHT", "0")),
