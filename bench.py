@@ -338,6 +338,25 @@ def main():
     preamble_s = prepare(args.scaling)
     elapsed = measure(args.scaling, args.warmup, args.steps)
     inflight = widths[args.scaling]
+    # ---- instrumented pass (phase times, sweep statistics): one volume alone, on lane 0 while its scratch pool is warm
+    import contextlib
+    import kimimaro_amd.engine as E
+    ieng = lanes.engines[0] if lanes is not None else eng
+    timings = []
+    tk = None
+    if rank == 0:
+        with (lanes._scopes[0] if lanes is not None else contextlib.nullcontext()):
+            torch.cuda.synchronize()
+            t_ccl = time.perf_counter()
+            lab0 = state["lab"]
+            i_cc, i_n, i_rep = ieng.ccl_device(state["d_lab"], lab0.dtype.itemsize, lab0.shape)
+            ieng.sync()
+            t_ccl = time.perf_counter() - t_ccl
+            i_orig = state["flat"][i_rep[1:].astype(np.int64)]
+            intake.skeletonize_cc(ieng, intake.LazyVolume(ieng, i_cc, lab0.shape), i_n, {i + 1: i_orig[i].item() for i in range(i_n)},
+                                  params, an, dust, True, fix_borders, empty, empty, black_border=False, d_cc=i_cc, timings=timings)
+            tk = E.LAST_TASKS
+            del i_cc
     lanes = None
     torch.cuda.empty_cache()
     lab = state["lab"]
@@ -403,22 +422,12 @@ def main():
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
 
     # ---- the path kernel: per-label algorithmic bytes of SURVEY 8d with Vc := Nf (no crops here)
-    import kimimaro_amd.engine as E
-    tk = E.LAST_TASKS
-    timings = []
-    t_ccl = time.perf_counter()
-    d_cc, nlabels, remapping = components()      # (the instrumented pass below sweeps over this call's u16 ids)
-    eng.sync()
-    t_ccl = time.perf_counter() - t_ccl
-    intake.skeletonize_cc(eng, intake.LazyVolume(eng, d_cc, shape, host=cc_labels), nlabels, remapping, params, an, dust,
-                          True, fix_borders, empty, empty, black_border=False, d_cc=d_cc, timings=timings)
     phases = {"ccl": round(t_ccl, 4)}
     prev = None
     for name, ts in timings:
         if prev is not None:
             phases["host_setup" if name == "setup" else name] = round(ts - prev, 4)
         prev = ts
-    tk = E.LAST_TASKS
     nf = tk["count"].astype(np.float64).sum()
     settled = tk["stat_settled"].astype(np.float64).sum()
     trace_bytes = (4 + 9) * nf + 10 * nf + 12 * nf + 12 * nf + 12 * settled + 2 * nf
