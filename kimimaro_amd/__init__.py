@@ -6,6 +6,7 @@ MI355X raises HipUnavailableError (there is deliberately no CPU fallback).
 """
 from ._abi import HipUnavailableError, KimiHipError  # noqa: F401
 from .intake import DEFAULT_TEASAR_PARAMS, DimensionError, skeletonize  # noqa: F401
+from .post import join_close_components, postprocess  # noqa: F401
 from .skeleton import Skeleton  # noqa: F401
 
 __version__ = "0.1.0"

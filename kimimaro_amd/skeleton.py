@@ -118,7 +118,11 @@ class Skeleton:
         skel.space = "physical"
         return skel
 
-    def consolidate(self):
+    def consolidate(self, remove_disconnected_vertices=False):
+        """Duplicate vertices merged (rows sorted lexicographically), edges renumbered, each edge sorted, rows sorted and
+        made unique, self loops dropped; radii / vertex_types from the first occurrence.  remove_disconnected_vertices
+        also drops vertices no edge refers to (what kimimaro/post.py expects of a bare `.consolidate()`); the path
+        assembly of the tracer never produces such vertices and keeps the default."""
         if self.empty():
             return Skeleton(segid=self.id, transform=self.transform, space=self.space)
         eff_nodes, uniq_idx, inverse = np.unique(
@@ -128,33 +132,58 @@ class Skeleton:
         eff_edges = np.sort(eff_edges, axis=1)
         eff_edges = np.unique(eff_edges, axis=0)
         eff_edges = eff_edges[eff_edges[:, 0] != eff_edges[:, 1]]
-        return Skeleton(eff_nodes, eff_edges.astype(np.uint32), self.radii[uniq_idx],
+        skel = Skeleton(eff_nodes, eff_edges.astype(np.uint32), self.radii[uniq_idx],
                         self.vertex_types[uniq_idx], self.id, self.transform, self.space)
+        return skel.remove_disconnected_vertices() if remove_disconnected_vertices else skel
+
+    def remove_disconnected_vertices(self):
+        used = np.unique(self.edges)
+        if used.size == self.vertices.shape[0]:
+            return self
+        renumber = np.full(self.vertices.shape[0], -1, dtype=np.int64)
+        renumber[used] = np.arange(used.size)
+        return Skeleton(self.vertices[used], renumber[self.edges.astype(np.int64)], self.radii[used],
+                        self.vertex_types[used], self.id, self.transform, self.space)
 
     def components(self):
-        """Connected components as a list of Skeletons (used by tests)."""
-        n = self.vertices.shape[0]
-        parent = np.arange(n)
-
-        def find(i):
-            while parent[i] != i:
-                parent[i] = parent[parent[i]]
-                i = parent[i]
-            return i
-
-        for a, b in self.edges:
-            ra, rb = find(int(a)), find(int(b))
-            if ra != rb:
-                parent[max(ra, rb)] = min(ra, rb)
-        roots = np.array([find(i) for i in range(n)])
+        """Connected components of the consolidated skeleton as a list of Skeletons, ordered by their smallest vertex.
+        A skeleton that is one component comes back consolidated; otherwise a component keeps its vertices in order
+        and lists its edges in the order of a depth-first walk from its smallest vertex (children in ascending
+        order, an edge is emitted when its far end is taken off the stack -- so the edge that closes a cycle shows up
+        from both sides).  kimimaro/post.py's loop removal starts its cycle search at a component's first edge."""
+        skel = self.consolidate()
+        if skel.edges.size == 0:
+            return []
+        n = skel.vertices.shape[0]
+        nbrs = [[] for _ in range(n)]
+        for a, b in skel.edges.tolist():      # rows are sorted and unique: both lists come out ascending
+            nbrs[a].append(b)
+            nbrs[b].append(a)
+        seen = np.zeros(n, dtype=bool)
+        forest = []
+        for start in np.unique(skel.edges).tolist():
+            if seen[start]:
+                continue
+            emitted = []
+            todo = [(start, -1)]
+            while todo:
+                node, via = todo.pop()
+                emitted.append((min(node, via), max(node, via)))
+                if seen[node]:
+                    continue
+                seen[node] = True
+                todo.extend((c, node) for c in nbrs[node] if c != via)
+            forest.append(emitted[1:])
+        if len(forest) == 1:
+            return [skel]
         out = []
-        for r in np.unique(roots):
-            sel = np.flatnonzero(roots == r)
-            remap = -np.ones(n, dtype=np.int64)
-            remap[sel] = np.arange(sel.size)
-            emask = roots[self.edges[:, 0]] == r
-            out.append(Skeleton(self.vertices[sel], remap[self.edges[emask]], self.radii[sel],
-                                self.vertex_types[sel], self.id, self.transform, self.space))
+        for emitted in forest:
+            e = np.asarray(emitted, dtype=np.int64)
+            keep = np.unique(e)
+            renumber = np.full(n, -1, dtype=np.int64)
+            renumber[keep] = np.arange(keep.size)
+            out.append(Skeleton(skel.vertices[keep], renumber[e], skel.radii[keep], skel.vertex_types[keep],
+                                skel.id, skel.transform, skel.space))
         return out
 
     def to_swc(self):

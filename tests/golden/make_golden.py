@@ -377,7 +377,126 @@ def gen_trace_paths(st):
 
 
 
-if __name__ == "__main__" and "trace_paths" in sys.argv[1:]:
+
+# ---------------------------------------------------------------------------------------------------------------
+# f4: kimimaro/post.py (postprocess = remove_dust -> remove_loops -> join_close_components -> remove_ticks).
+# The reference's own file is imported with stand-ins for the packages this image lacks: fastremap.unique -> np.unique,
+# osteoid.Skeleton -> tests/golden/osteoid_standin.py, kimimaro.skeletontricks -> the compiled reference (oracle/_ref).
+def load_reference_post(st):
+    import osteoid_standin
+    fr = types.ModuleType("fastremap")
+    fr.unique = lambda a, return_counts=False: np.unique(np.asarray(a), return_counts=return_counts)
+    ost = types.ModuleType("osteoid")
+    ost.Skeleton = osteoid_standin.Skeleton
+    ost.Bbox = osteoid_standin.Bbox
+    sys.modules["fastremap"] = fr
+    sys.modules["osteoid"] = ost
+    pkg = types.ModuleType("kimimaro")
+    pkg.__path__ = []
+    pkg.skeletontricks = st
+    sys.modules["kimimaro"] = pkg
+    sys.modules["kimimaro.skeletontricks"] = st
+    spec = importlib.util.spec_from_file_location("kimimaro.post", os.path.join(REF, "kimimaro", "post.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, osteoid_standin.Skeleton
+
+
+def random_forest(rng, ntrees, nodes, spread, loops=0, tick_every=0):
+    """vertices (float coordinates: no exact ties between branch lengths), edges, radii of a few random trees, with
+    `loops` extra edges closing cycles inside trees and short side branches ("ticks")."""
+    verts, edges, radii = [], [], []
+    for t in range(ntrees):
+        base = len(verts)
+        origin = rng.uniform(0, spread, 3)
+        n = int(nodes[t % len(nodes)])
+        pos = [origin]
+        par = [-1]
+        for i in range(1, n):
+            # mostly extend the latest tip (long neurite-like runs), sometimes branch off an earlier node
+            p = i - 1 if rng.random() < 0.85 else int(rng.integers(0, i))
+            step = rng.normal(0, 1, 3)
+            step = step / np.linalg.norm(step) * rng.uniform(20, 60)
+            if tick_every and i % tick_every == 0:
+                p = int(rng.integers(0, i))
+                step = step / np.linalg.norm(step) * rng.uniform(3, 15)
+            pos.append(pos[p] + step)
+            par.append(p)
+        for i in range(n):
+            verts.append(pos[i])
+            radii.append(rng.uniform(5, 40))
+            if par[i] >= 0:
+                edges.append((base + par[i], base + i))
+        for _ in range(loops):
+            a, b = rng.choice(n, 2, replace=False)
+            edges.append((base + int(a), base + int(b)))
+    return np.array(verts, np.float32), np.array(edges, np.uint32), np.array(radii, np.float32)
+
+
+def gen_post(st):
+    post, Skel = load_reference_post(st)
+    cases = {}
+    n = 0
+
+    def store(fn, args, vin, ein, rin, out):
+        nonlocal n
+        cases["fn_%d" % n] = np.array(fn)
+        cases["args_%d" % n] = np.array(repr(args))
+        cases["vin_%d" % n], cases["ein_%d" % n], cases["rin_%d" % n] = vin, ein, rin
+        cases["vout_%d" % n] = np.asarray(out.vertices, np.float32)
+        cases["eout_%d" % n] = np.asarray(out.edges, np.int64).reshape(-1, 2)
+        cases["rout_%d" % n] = np.asarray(out.radii, np.float32)
+        n += 1
+
+    rng = np.random.default_rng(20240)
+    for t in range(36):
+        kind = t % 6
+        ntrees = [1, 3, 2, 4, 1, 3][kind]
+        loops = [0, 0, 1, 2, 3, 1][kind]
+        ticks = [6, 0, 5, 7, 4, 6][kind]
+        spread = [400, 150, 600, 250, 300, 2000][kind]
+        v, e, r = random_forest(rng, ntrees, [60, 25, 90, 40], spread, loops=loops, tick_every=ticks)
+        mk = lambda: Skel(v.copy(), e.copy(), r.copy(), segid=7)
+        dust = [0, 300, 1500][t % 3]
+        tick = [0, 40, 120][(t // 3) % 3]
+        store("postprocess", (dust, tick), v, e, r, post.postprocess(mk(), dust_threshold=dust, tick_threshold=tick))
+        store("remove_dust", (dust,), v, e, r, post.remove_dust(mk().consolidate(), dust))
+        store("remove_loops", (), v, e, r, post.remove_loops(mk().consolidate()))
+        if loops == 0:
+            store("remove_ticks", (tick,), v, e, r, post.remove_ticks(mk().consolidate(), tick))
+        rad = [None, 80.0, 500.0][t % 3]
+        store("join_close_components", (rad, bool(t % 2)), v, e, r,
+              post.join_close_components(mk(), radius=rad, restrict_by_radius=bool(t % 2)))
+    # skeletons of a chunked volume, merged per label (what post.py is for): the oracle pipeline on four overlapping
+    # quadrants of a small dense volume with fix_borders, then the reference's postprocess
+    from oracle import pipeline as P
+    from shapes import voronoi_labels
+    an = (16, 16, 40)
+    lab = voronoi_labels((96, 96, 40), 10, 77, pts_per_label=5, anisotropy=an)
+    parts = {}
+    for ox in (0, 47):
+        for oy in (0, 47):
+            sub = np.asfortranarray(lab[ox:ox + 49, oy:oy + 49, :])
+            sk = P.skeletonize(sub, anisotropy=an, dust_threshold=50, fix_borders=True, fix_branching=True)
+            for k, s in sk.items():
+                vv = s.vertices + np.array([ox * an[0], oy * an[1], 0], np.float32)
+                parts.setdefault(k, []).append(Skel(vv, s.edges, s.radii, segid=k))
+    for k in sorted(parts):
+        merged = Skel.simple_merge(parts[k])
+        if merged.empty():
+            continue
+        v, e, r = merged.vertices.copy(), merged.edges.copy(), merged.radii.copy()
+        store("postprocess", (500, 900), v, e, r, post.postprocess(Skel(v.copy(), e.copy(), r.copy(), segid=k), 500, 900))
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "post.npz"), **cases)
+    print("post:", n, "cases")
+
+
+if __name__ == "__main__" and "post" in sys.argv[1:]:
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    gen_post(st)
+elif __name__ == "__main__" and "trace_paths" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
     gen_trace_paths(st)
