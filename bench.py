@@ -18,8 +18,8 @@ the axes given by the bits of r, label ids offset) and prints it as the extra ob
 Workload (config.workload): "c3" = 512x512x512, 2124 chains, anisotropy (16,16,40), default
 teasar_params, dust_threshold=1000, fix_borders=True, fix_branching=True  (BASELINE.json configs[2],
 the configuration the metric is quoted on).  "c2" = 512x512x100 / 333 labels (configs[1]).  "c5" = 1024^3, 8192
-chains, anisotropy (8,8,40) (configs[4]; needs the per-rank sharding of N >= 2 ranks: one GPU cannot hold the
-per-label scratch of all its components).
+chains, anisotropy (8,8,40) (configs[4]; one volume at a time, its labels in as many launches of the path loop as
+Engine.scratch_budget asks for).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
@@ -279,6 +279,8 @@ def main():
     def width_of(mode):
         if args.inflight > 0:
             return args.inflight
+        if args.workload == "c5":      # 40 B per voxel of whole-volume fields per lane: one volume at a time
+            return 1
         if mode == "strong" and world > 1:
             return 6 if world == 2 else 8 if world <= 4 else 12
         return 4

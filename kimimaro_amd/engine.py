@@ -50,6 +50,10 @@ class Engine:
         self.sweep_lds_levels = min(int(os.environ.get("KH_SWEEP_LDS_LEVELS", 8192)), _abi.SWEEP_LDS_LEVELS)
         self._level_tables = {}
         self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
+        # Per-label scratch (heap, work lists, event arena, path buffers: ~300 B per voxel of a label) of ONE path-loop
+        # launch.  Labels beyond it go to further launches of the same call, largest labels first (callers that consume
+        # results incrementally only); the whole-volume fields (~40 B per voxel of the volume) are not counted.
+        self.scratch_budget = int(float(os.environ.get("KH_SCRATCH_BUDGET_GB", "120")) * 1e9)
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):
@@ -300,6 +304,7 @@ class Engine:
         kimimaro/trace.py:225-228).  Returns a dict with per-label path arrays -- or, when `consume` is given,
         hands such dicts (one per group of labels, as the groups finish) to `consume` and returns None.
         """
+        global LAST_TASKS
         t = self.torch
         lib = self.lib
         st = self.stream()
@@ -310,6 +315,34 @@ class Engine:
             return {"order": np.zeros(0, np.int64), "tasks": np.zeros(0, _abi.LABEL_T), "paths": []}
         segids = np.asarray(segids, dtype=np.int64)
         counts = np.asarray(counts, dtype=np.int64)
+        if consume is not None and nl > 1:
+            # more per-label scratch than the budget: several launches, each over a group of labels that fits
+            need = counts * 300 + (1 << 20)
+            if int(need.sum()) > self.scratch_budget:
+                by_size = np.argsort(-counts, kind="stable")
+                groups, cur, acc = [], [], 0
+                for i in by_size.tolist():
+                    if cur and acc + int(need[i]) > self.scratch_budget:
+                        groups.append(cur)
+                        cur, acc = [], 0
+                    cur.append(i)
+                    acc += int(need[i])
+                groups.append(cur)
+                if len(groups) > 1:
+                    done = []
+                    pick_list = lambda a, g: [a[i] for i in g] if a is not None else None
+                    for g in groups:
+                        g = np.asarray(g, dtype=np.int64)
+                        sub_soma = None if soma is None else {k: np.asarray(v)[g] for k, v in soma.items()}
+                        self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[g], counts[g],
+                                        np.asarray(dbf_max)[g], np.asarray(first_index)[g], np.asarray(xmin)[g],
+                                        np.asarray(xmax)[g], np.asarray(roots, dtype=np.uint32)[g], pick_list(targets_before, g),
+                                        pick_list(targets_after, g), params, fix_branching=fix_branching, max_paths=max_paths,
+                                        timings=timings if not done else None, soma=sub_soma, consume=consume,
+                                        scratch_scale=scratch_scale)
+                        done.append(LAST_TASKS)
+                    LAST_TASKS = np.concatenate(done)
+                    return None
         order = np.argsort(-counts, kind="stable")  # big labels first: their workgroups start first
         slot_of_label = -np.ones(nlabels + 1, dtype=np.int32)
         slot_of_label[segids[order]] = np.arange(nl, dtype=np.int32)
@@ -501,7 +534,6 @@ class Engine:
                             sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
                             consume=sink, scratch_scale=scratch_scale * 8)
 
-        global LAST_TASKS
         if consume is not None and 0 < n_large < nl:
             # The largest labels are the tail of the run.  They go to a second stream (as large-LDS workgroups); the
             # rest runs on the caller's stream and its results are copied back and handed to `consume` (the Skeleton
