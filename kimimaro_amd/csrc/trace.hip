@@ -1175,10 +1175,13 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (sg.rank && swl > lds) lds = swl;
-  if (lds > 48 * 1024) {
-    // more than 48 KiB of dynamic LDS has to be allowed per kernel (and per device; the attribute is cheap to set)
+  {
+    // More than 48 KiB of dynamic LDS has to be allowed per kernel.  The attribute belongs to the function, not to the
+    // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
+    // launch can ask for -- so that a concurrent caller never lowers it under somebody else's launch.
+    const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
     KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
   const char* thr_env = getenv("KH_TRACE_THREADS");   // developer knob
   const unsigned nthreads = thr_env ? (unsigned)atoi(thr_env) : 256u;
@@ -1278,9 +1281,12 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (level_rank && swl > lds) lds = swl;
-  if (lds > 48 * 1024)
+  {
+    // (constant value: see launch_trace)
+    const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
     KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&invalidate_ball_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
+  }
   hipLaunchKernelGGL(invalidate_ball_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, task, lists, nbrmask, g, dbf, alive, queues,
                      (hnode_t*)heap_nodes, path, (uint32_t)npath, scale, constant, sg, (long long*)invalidated);
   KH_LAUNCH_CHECK();
