@@ -29,6 +29,25 @@ def _torch():
     return torch
 
 
+def plan_launches(counts, budget):
+    """Groups of label positions for successive launches of the path loop: largest labels first, a group is closed when the
+    next label's scratch (about 300 B per voxel + 1 MiB) would take it over `budget` bytes; a label larger than the budget
+    gets a launch of its own.  One group = everything fits."""
+    counts = np.asarray(counts, dtype=np.int64)
+    need = counts * 300 + (1 << 20)
+    if int(need.sum()) <= budget:
+        return [list(range(len(counts)))]
+    groups, cur, acc = [], [], 0
+    for i in np.argsort(-counts, kind="stable").tolist():
+        if cur and acc + int(need[i]) > budget:
+            groups.append(cur)
+            cur, acc = [], 0
+        cur.append(i)
+        acc += int(need[i])
+    groups.append(cur)
+    return groups
+
+
 class Engine:
     def __init__(self, device=None):
         self.lib = _abi.require_gpu()
@@ -317,32 +336,22 @@ class Engine:
         counts = np.asarray(counts, dtype=np.int64)
         if consume is not None and nl > 1:
             # more per-label scratch than the budget: several launches, each over a group of labels that fits
-            need = counts * 300 + (1 << 20)
-            if int(need.sum()) > self.scratch_budget:
-                by_size = np.argsort(-counts, kind="stable")
-                groups, cur, acc = [], [], 0
-                for i in by_size.tolist():
-                    if cur and acc + int(need[i]) > self.scratch_budget:
-                        groups.append(cur)
-                        cur, acc = [], 0
-                    cur.append(i)
-                    acc += int(need[i])
-                groups.append(cur)
-                if len(groups) > 1:
-                    done = []
-                    pick_list = lambda a, g: [a[i] for i in g] if a is not None else None
-                    for g in groups:
-                        g = np.asarray(g, dtype=np.int64)
-                        sub_soma = None if soma is None else {k: np.asarray(v)[g] for k, v in soma.items()}
-                        self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[g], counts[g],
-                                        np.asarray(dbf_max)[g], np.asarray(first_index)[g], np.asarray(xmin)[g],
-                                        np.asarray(xmax)[g], np.asarray(roots, dtype=np.uint32)[g], pick_list(targets_before, g),
-                                        pick_list(targets_after, g), params, fix_branching=fix_branching, max_paths=max_paths,
-                                        timings=timings if not done else None, soma=sub_soma, consume=consume,
-                                        scratch_scale=scratch_scale)
-                        done.append(LAST_TASKS)
-                    LAST_TASKS = np.concatenate(done)
-                    return None
+            groups = plan_launches(counts, self.scratch_budget)
+            if len(groups) > 1:
+                done = []
+                pick_list = lambda a, g: [a[i] for i in g] if a is not None else None
+                for g in groups:
+                    g = np.asarray(g, dtype=np.int64)
+                    sub_soma = None if soma is None else {k: np.asarray(v)[g] for k, v in soma.items()}
+                    self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[g], counts[g],
+                                    np.asarray(dbf_max)[g], np.asarray(first_index)[g], np.asarray(xmin)[g],
+                                    np.asarray(xmax)[g], np.asarray(roots, dtype=np.uint32)[g], pick_list(targets_before, g),
+                                    pick_list(targets_after, g), params, fix_branching=fix_branching, max_paths=max_paths,
+                                    timings=timings if not done else None, soma=sub_soma, consume=consume,
+                                    scratch_scale=scratch_scale)
+                    done.append(LAST_TASKS)
+                LAST_TASKS = np.concatenate(done)
+                return None
         order = np.argsort(-counts, kind="stable")  # big labels first: their workgroups start first
         slot_of_label = -np.ones(nlabels + 1, dtype=np.int32)
         slot_of_label[segids[order]] = np.arange(nl, dtype=np.int32)
