@@ -148,9 +148,9 @@ class Skeleton:
     def components(self):
         """Connected components of the consolidated skeleton as a list of Skeletons, ordered by their smallest vertex.
         A skeleton that is one component comes back consolidated; otherwise a component keeps its vertices in order
-        and lists its edges in the order of a depth-first walk from its smallest vertex (children in ascending
-        order, an edge is emitted when its far end is taken off the stack -- so the edge that closes a cycle shows up
-        from both sides).  kimimaro/post.py's loop removal starts its cycle search at a component's first edge."""
+        and lists its edges as sorted unique rows.  (kimimaro/post.py's loop removal starts its cycle search at a
+        component's first edge and counts a node's edges to find branch points, so neither the order nor duplicates are
+        free: the reference's test_postprocess, automated_test.py:611-632, pins this.)"""
         skel = self.consolidate()
         if skel.edges.size == 0:
             return []
@@ -178,7 +178,7 @@ class Skeleton:
             return [skel]
         out = []
         for emitted in forest:
-            e = np.asarray(emitted, dtype=np.int64)
+            e = np.unique(np.asarray(emitted, dtype=np.int64), axis=0)
             keep = np.unique(e)
             renumber = np.full(n, -1, dtype=np.int64)
             renumber[keep] = np.arange(keep.size)

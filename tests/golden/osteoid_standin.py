@@ -4,11 +4,11 @@ tests/golden/make_golden.py to run the reference's own kimimaro/post.py in the b
 It restates the operations post.py calls (kimimaro/post.py:77-86,115-123,186,218,222-233,256-260,440-444 ...) as
 osteoid / cloud-volume document them: consolidate (np.unique over the vertex rows, edges renumbered, each edge
 sorted, rows sorted and made unique, self loops dropped, optionally vertices without an edge dropped), components
-(depth-first walk from the smallest unvisited vertex of the consolidated skeleton; a component's vertices keep their
-order, its edges come out in the order of the walk), simple_merge, clone, empty, cable_length.  The order in which
-`components()` lists a component's edges is an internal of the real package that the reference's loop removal can see
-(skeletontricks.find_cycle starts at the first edge); the vectors made with this stand-in pin post.py's own logic, not
-that internal ("parity unpinned" for it).  Independent of kimimaro_amd and of oracle/.
+(the components of the consolidated skeleton, ordered by their smallest vertex; a component keeps its vertices in order
+and lists its edges as sorted unique rows), simple_merge, clone, empty, cable_length.  What pins this stand-in to the
+real package: the reference's own known-answer tests that go through it (automated_test.py:384-456 join_close_components
+with exact edge arrays, :611-632 postprocess -- the latter fails if components() lists a cycle's closing edge twice),
+mirrored in tests/test_post.py.  Independent of kimimaro_amd and of oracle/.
 """
 from collections import defaultdict
 
@@ -107,7 +107,7 @@ class Skeleton:
             return [skel]
         out = []
         for edge_list in forest:
-            e = np.array(edge_list, dtype=np.int64)
+            e = np.unique(np.array(edge_list, dtype=np.int64), axis=0)   # (the walk emits the edge that closes a cycle twice)
             vid = np.unique(e)
             remap = -np.ones(len(skel.vertices), np.int64)
             remap[vid] = np.arange(vid.size)

@@ -77,3 +77,67 @@ def test_postprocess_keeps_the_label_and_yields_a_forest():
 def test_join_rejects_bad_radius():
     with pytest.raises(ValueError):
         post.join_close_components(Skeleton(), radius=0)
+
+
+# ---- the reference's own known-answer tests for this row (automated_test.py:335-456, 611-632), on the product
+def test_reference_kat_find_cycle():
+    cyc = post.find_cycle(np.array([[0, 1], [1, 2], [2, 0], [2, 3], [2, 4]], dtype=np.int32))
+    assert cyc == [0, 2, 1, 0]
+    cyc = post.find_cycle(np.array([[0, 1], [1, 2], [2, 3], [3, 4], [4, 10], [10, 11], [11, 12], [12, 2], [4, 5], [5, 6], [6, 7]],
+                                   dtype=np.int32))
+    assert cyc == [2, 12, 11, 10, 4, 3, 2]
+    cyc = post.find_cycle(np.array([[0, 1], [0, 20], [20, 21], [21, 22], [22, 23], [23, 21], [1, 2], [2, 3], [3, 4], [4, 5], [5, 6],
+                                    [6, 7], [7, 10], [10, 11], [11, 6]], dtype=np.int32))
+    assert cyc in ([21, 23, 22, 21], [6, 11, 10, 7, 6])
+    assert post.find_cycle(np.zeros((0, 2), np.int32)) == []
+
+
+def test_reference_kat_join_close_components_simple():
+    skel = Skeleton([(0, 0, 0), (1, 0, 0), (10, 0, 0), (11, 0, 0)], edges=[(0, 1), (2, 3)], radii=[0, 1, 2, 3],
+                    vertex_types=[0, 1, 2, 3], segid=1337)
+    assert len(skel.components()) == 2
+    assert len(post.join_close_components(skel, radius=np.inf).components()) == 1
+    res = post.join_close_components(skel, radius=9)
+    assert len(res.components()) == 1
+    assert np.all(res.edges == [[0, 1], [1, 2], [2, 3]])
+    assert len(post.join_close_components(skel, radius=8.5).components()) == 2
+
+
+def test_reference_kat_join_close_components_complex():
+    skel = Skeleton([(0, 0, 0), (1, 0, 0), (4, 0, 0), (6, 0, 0), (20, 0, 0), (21, 0, 0), (0, 0, 5), (0, 0, 10)],
+                    edges=[(0, 1), (2, 3), (4, 5), (6, 7)])
+    assert len(skel.components()) == 4
+    res = post.join_close_components(skel, radius=np.inf)
+    assert len(res.components()) == 1
+    assert np.all(res.edges == [[0, 1], [0, 3], [1, 2], [3, 4], [4, 5], [5, 6], [6, 7]])
+
+
+def test_reference_kat_join_close_components_by_radius():
+    skel = Skeleton([(0, 0, 0), (1, 0, 0), (5, 0, 0), (11, 0, 0)], edges=[(0, 1), (2, 3)], radii=[100, 100, 100, 100],
+                    vertex_types=[0, 1, 2, 3], segid=1337)
+    for restrict in (False, True):
+        res = post.join_close_components(skel, restrict_by_radius=restrict)
+        assert len(res.components()) == 1
+        assert np.all(res.edges == [[0, 1], [1, 2], [2, 3]])
+    for radii, ncomp, edges in (([1, 1, 1, 1], 2, [[0, 1], [2, 3]]), ([1, 0.9, 3, 1], 2, [[0, 1], [2, 3]]),
+                                ([1, 1, 3, 1], 1, [[0, 1], [1, 2], [2, 3]])):
+        skel.radii = np.array(radii, dtype=np.float32)
+        res = post.join_close_components(skel, restrict_by_radius=True)
+        assert len(res.components()) == ncomp
+        assert np.all(res.edges == edges)
+
+
+def test_reference_kat_postprocess():
+    skel = Skeleton([(0, 0, 0), (1, 0, 0), (4, 0, 0), (6, 0, 0), (20, 0, 0), (21, 0, 0), (0, 0, 5), (0, 0, 10)],
+                    edges=[(0, 1), (2, 3), (4, 5), (6, 7), (0, 7), (1, 6)])
+    res = post.postprocess(skel, dust_threshold=0, tick_threshold=0)
+    v, r, e = canonical(res.vertices, res.edges, res.radii)
+    wv, wr, we = canonical([(4, 0, 0), (6, 0, 0), (20, 0, 0), (21, 0, 0)], [(0, 1), (2, 3)], [-1] * 4)
+    assert np.array_equal(v, wv) and np.array_equal(e, we)
+
+
+def test_reference_kat_remove_row():
+    """automated_test.py:566-586 (post.remove_row): every row equal to a doomed row goes, in either orientation."""
+    arr = np.array([[0, 1], [1, 2], [2, 1], [2, 2], [2, 3], [3, 4]])
+    assert np.array_equal(post._drop_edges(arr, np.array([[1, 2]])), [[0, 1], [2, 2], [2, 3], [3, 4]])
+    assert post._drop_edges(np.zeros((0, 2), np.int64), np.array([[1, 2]])).size == 0
