@@ -23,7 +23,7 @@ Engine.scratch_budget asks for).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
-Steps in flight (--inflight F; default 4, and 6 / 8 / 12 for the strong mode on 2 / 4 / 8 GPUs): the wall clock of ONE volume is the chain of its largest component -- a
+Steps in flight (--inflight F; default 4, and 7 / 10 / 12 for the strong mode on 2 / 4 / 8 GPUs): the wall clock of ONE volume is the chain of its largest component -- a
 handful of workgroups for seconds while the rest of the GPU idles.  The K timed steps are therefore
 issued from F host threads, each with a HIP stream, an Engine and scratch of its own, so that the tail of one volume
 overlaps the next ones; every step still does all of its work inside the timed region and ms_per_step = wall / K.  The
@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KIMI_BENCH_INFLIGHT", "0")),
                     help="volumes in flight per GPU: consecutive steps are issued from that many host threads, each on a HIP "
                          "stream and with scratch of its own, so the tail of one volume (a handful of workgroups tracing its "
-                         "largest components) overlaps the next volumes.  0 (default) = 4, and 6 / 8 / 12 for the strong mode on "
+                         "largest components) overlaps the next volumes.  0 (default) = 4, and 7 / 10 / 12 for the strong mode on "
                          "2 / 4 / 8 GPUs (a rank's share of a volume is smaller there, the chain of its largest component "
                          "is not).  1 = one step after the other (the latency "
                          "of a single volume, which is reported either way as single_volume_ms).")
@@ -282,7 +282,7 @@ def main():
         if args.workload == "c5":      # 40 B per voxel of whole-volume fields per lane: one volume at a time
             return 1
         if mode == "strong" and world > 1:
-            return 6 if world == 2 else 8 if world <= 4 else 12
+            return 7 if world == 2 else 10 if world <= 4 else 12
         return 4
 
     widths = {m: width_of(m) for m in (("weak", "strong") if world > 1 else (args.scaling,))}
