@@ -130,9 +130,12 @@ def cpu_baseline(cc_labels, remapping, an, params, dust_threshold, budget_s=15.0
                       "seeded shuffle" % (done, len(segids), vox, dt)}
 
 
-def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate, budget_s=10.0, timeout_s=120.0):
-    """the same per-label work as cpu_baseline on every host core: oracle/cpu_pool_baseline.py in a child process
-    (forked worker pool over a read-only map of the component volume), under a hard timeout."""
+def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate, volumes_in_flight=1, budget_s=25.0,
+                           timeout_s=300.0):
+    """the same per-label work as cpu_baseline on every usable host core: oracle/cpu_pool_baseline.py in a child process
+    (forked worker pool over a read-only map of the component volume, components largest first), under a hard timeout.
+    Two legs: ONE volume through the pool (latency) and `volumes_in_flight` volumes' components through the same pool at
+    once (throughput) -- the like-for-like partners of single_volume_ms and of the pipelined `value`."""
     import subprocess
     import tempfile
     if (os.cpu_count() or 1) < 2:
@@ -142,7 +145,7 @@ def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate,
     try:
         np.save(path, cc_labels)
         args = {"anisotropy": [float(a) for a in an], "params": params, "dust_threshold": int(dust_threshold),
-                "one_core_rate": float(one_core_rate), "budget_s": float(budget_s)}
+                "one_core_rate": float(one_core_rate), "budget_s": float(budget_s), "volumes_in_flight": int(volumes_in_flight)}
         out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_pool_baseline.py"), path, json.dumps(args)],
                              capture_output=True, text=True, timeout=timeout_s, check=True)
         return json.loads(out.stdout.strip().splitlines()[-1])
@@ -266,7 +269,9 @@ def main():
 
     def finish(local):
         if world > 1:
+            tg = time.perf_counter()
             local = gather_skeletons(local, device=eng.device if backend == "nccl" else None)
+            state["gather_s"] = state.get("gather_s", 0.0) + (time.perf_counter() - tg)
         result["skels"] = local
         return local
 
@@ -282,7 +287,14 @@ def main():
         if args.workload == "c5":      # 40 B per voxel of whole-volume fields per lane: one volume at a time
             return 1
         if mode == "strong" and world > 1:
-            return 7 if world == 2 else 10 if world <= 4 else 12
+            # a rank's share of a volume shrinks with N, the chain of its largest component does not: more volumes in
+            # flight.  Sized from the HBM that is free now and what a lane reserves (measured at c3 on one GPU: ~7 GB of
+            # whole-volume fields + ~37 GB of per-label scratch for ALL components, of which a rank holds 1 / N), 75 % of
+            # the free memory at most, 4 .. 12 lanes.
+            nvox_rel = float(np.prod(WORKLOADS[args.workload][0])) / 512.0 ** 3
+            per_lane = (7.0 + 37.0 / world) * nvox_rel * 1e9
+            free_b = torch.cuda.mem_get_info()[0]
+            return int(max(4, min(12, (0.75 * free_b) // per_lane)))
         return 4
 
     widths = {m: width_of(m) for m in (("weak", "strong") if world > 1 else (args.scaling,))}
@@ -320,16 +332,24 @@ def main():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
+        state["gather_s"] = 0.0
         t0 = time.perf_counter()
         run_steps(steps, width)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0      # this rank's own steps (before it waits for the slowest rank)
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
+            dev = eng.device if backend == "nccl" else "cpu"
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+            mine = torch.tensor([own, state["gather_s"]], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            state["rank_times"] = {"own_s_per_step": [round(float(e[0]) / max(steps, 1), 4) for e in every],
+                                   "gather_s_per_step": [round(float(e[1]) / max(steps, 1), 4) for e in every]}
         return elapsed
 
     # the other scaling mode first (short), the selected one last so that everything below describes the selected one
@@ -430,8 +450,9 @@ def main():
     phases = {"ccl": round(t_ccl, 4)}
     prev = None
     for name, ts in timings:
-        if prev is not None:
-            phases["host_setup" if name == "setup" else name] = round(ts - prev, 4)
+        if prev is not None:   # (a name repeats when the labels ran in several launches: accumulated)
+            key = "host_setup" if name == "setup" else name
+            phases[key] = round(phases.get(key, 0.0) + ts - prev, 4)
         prev = ts
     nf = tk["count"].astype(np.float64).sum()
     settled = tk["stat_settled"].astype(np.float64).sum()
@@ -457,11 +478,19 @@ def main():
         try:
             cpu = cpu_baseline(cc_labels, remapping, an, params, dust)
             try:
-                cpu_all = cpu_baseline_all_cores(cc_labels, an, params, dust, cpu["value"])
+                cpu_all = cpu_baseline_all_cores(cc_labels, an, params, dust, cpu["value"], volumes_in_flight=inflight)
             except Exception as e:
                 cpu_all = {"value": None, "unit": "labels/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         except Exception as e:  # the baseline must never take the bench line down
             cpu = {"value": None, "unit": "labels/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    # like-for-like ratios: one volume vs one volume, pipelined vs pipelined (never mixed)
+    speedup_latency = speedup_throughput = None
+    single_ms = state.get("single_ms", float("nan"))
+    if cpu_all and cpu_all.get("latency") and cpu_all["latency"].get("value") and single_ms == single_ms:
+        speedup_latency = round((ncomp / (single_ms / 1e3)) / cpu_all["latency"]["value"], 2)
+    if cpu_all and cpu_all.get("throughput") and cpu_all["throughput"].get("value") and world == 1:
+        speedup_throughput = round(value / cpu_all["throughput"]["value"], 2)
 
     line = {
         "metric": "labels/sec on a dense connectomics-shaped volume (skeletonize hot path, labels resident in HBM)",
@@ -483,7 +512,12 @@ def main():
         "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
+        "speedup_latency": speedup_latency, "speedup_throughput": speedup_throughput,
+        "speedup_note": "latency: components / single_volume_ms vs ONE volume on the all-cores pool; throughput: value (volumes "
+                        "in flight) vs the same number of volumes' components through the same pool at once",
     }
+    if state.get("rank_times"):
+        line["rank_times"] = state["rank_times"]
     if other is not None:
         line["weak_scaling" if other["scaling"] == "weak" else "strong_scaling"] = other
     print(json.dumps(line))

@@ -164,6 +164,14 @@ int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint32_t* lists,
  * For every voxel of a selected label: daf *= 1/max_daf (max_daf = task.max_val, skipped
  * when 0), pdrf = ((1 - dbf*M)^(2^log2_exponent)) * scale + daf, each op rounded to f32.
  * Voxels of unselected labels / background get pdrf = +inf.                           */
+/* Exponents that are not a power of two take the reference's np.power branch (kimimaro/trace.py:346-347), whose rounding
+ * is that of the host's numpy (libm / SVML powf -- machine dependent, so no device powf can promise the same bits).
+ * The call is then made twice around the host's own np.power on the pdrf buffer:
+ *   log2_exponent = KH_PDRF_BASE    pdrf = 1 - dbf*M for the selected voxels (+inf elsewhere), daf untouched;
+ *   (host: np.power(pdrf, exponent, out=pdrf) in float32)
+ *   log2_exponent = KH_PDRF_FINISH  pdrf = pdrf*scale + daf/max_daf, daf normalised in place -- the tail of the normal call. */
+#define KH_PDRF_BASE (-1)
+#define KH_PDRF_FINISH (-2)
 int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
             const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale,
             float* pdrf, void* stream);
@@ -239,7 +247,8 @@ int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists, const uint
 /* ---- a3 / a5 / a6 as stand-alone operations (the path loop has them fused: kh_pdrf, kh_trace_paths) ----------------
  * kh_zero2inf / kh_inf2zero: skeletontricks.zero2inf / inf2zero (skeletontricks.pyx:177-224), in place.
  * kh_pdrf_field: compute_pdrf (kimimaro/trace.py:315-356) on every element: out = ((1 - dbf*M)^(2^log2_exponent)) * scale
- *   (+ daf / max_daf, with daf normalised in place, when max_daf != 0); every operation rounded to f32.
+ *   (+ daf / max_daf, with daf normalised in place, when max_daf != 0); every operation rounded to f32.  KH_PDRF_BASE /
+ *   KH_PDRF_FINISH as for kh_pdrf (the two halves around the host's np.power for other exponents).
  * kh_target_max: CachedTargetFinder.find_target (skeletontricks.pyx:1008-1045) over a voxel list with its DAF values:
  *   *out (device u64) = 1<<63 | DAF bits << 32 | voxel of the valid (alive != 0) voxel with the largest DAF, ties ->
  *   largest index; 0 when no voxel is valid.                                                                       */
@@ -248,6 +257,14 @@ int kh_inf2zero(float* f, int64_t n, void* stream);
 int kh_pdrf_field(const float* dbf, float* daf, int64_t n, float M, int log2_exponent, float scale, float max_daf,
                   float* out, void* stream);
 int kh_target_max(const uint32_t* list, const float* list_daf, const uint8_t* alive, int64_t n, uint64_t* out, void* stream);
+/* kh_find_target: the legacy skeletontricks.find_target(labels, PDRF) (skeletontricks.pyx:331-367): the first voxel in the
+ *   reference's scan (x outermost, z innermost) whose field value is the maximum over the mask (strict >, from -inf).
+ *   labels u8 / field f32 [sx,sy,sz] Fortran ordered; *out (device u64) = 0 when the mask is empty (the reference returns
+ *   (-1,-1,-1)), else orderable value bits << 32 | (0xFFFFFFFF - (x*sy + y)*sz - z).
+ * kh_first_label: skeletontricks.first_label (skeletontricks.pyx:307-326): *out (device u64) = smallest linear index of a
+ *   non-zero voxel, ~0 when there is none (the reference returns None).                                              */
+int kh_find_target(const uint8_t* labels, const float* field, int64_t sx, int64_t sy, int64_t sz, uint64_t* out, void* stream);
+int kh_first_label(const uint8_t* labels, int64_t n, uint64_t* out, void* stream);
 
 /* small helpers used by the host mirror */
 int kh_fill_f32(float* p, int64_t n, float v, void* stream);

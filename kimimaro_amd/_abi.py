@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
 SYMBOLS = [
     "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_nd", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
     "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
-    "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_invalidate_ball", "kh_path_search", "kh_zero2inf", "kh_inf2zero", "kh_pdrf_field", "kh_target_max", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
+    "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_invalidate_ball", "kh_path_search", "kh_zero2inf", "kh_inf2zero", "kh_pdrf_field", "kh_target_max", "kh_find_target", "kh_first_label", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
 
 
@@ -47,6 +47,16 @@ LABEL_T = np.dtype([
 assert LABEL_T.itemsize == 184
 SWEEP_LDS_LEVELS = 16384  # KH_SWEEP_LDS_LEVELS
 SWEEP_MAX_LEVELS = 1 << 22  # labels with more levels than this use the heap emulation only
+PDRF_BASE, PDRF_FINISH = -1, -2  # KH_PDRF_BASE / KH_PDRF_FINISH
+
+
+def is_pow2_exponent(e):
+    """kimimaro/trace.py:343: is_power_of_two(pdrf_exponent) and pdrf_exponent < 2**16 (the repeated-squaring branch)"""
+    try:
+        i = int(e)
+    except (TypeError, ValueError):
+        return False
+    return i == e and i > 0 and (i & (i - 1)) == 0 and i < 2 ** 16
 
 ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
            8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",
@@ -94,6 +104,8 @@ def lib():
     L.kh_inf2zero.argtypes = [vp, i64, vp]
     L.kh_pdrf_field.argtypes = [vp, vp, i64, f32, ci, f32, f32, vp, vp]
     L.kh_target_max.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.kh_find_target.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.kh_first_label.argtypes = [vp, i64, vp, vp]
     L.kh_level_keys.argtypes = [i64, i64, i64, f32, f32, f32, vp, vp]
     L.kh_fill_f32.argtypes = [vp, i64, f32, vp]
     L.kh_fill_u8.argtypes = [vp, i64, ci, vp]

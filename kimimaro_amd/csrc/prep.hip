@@ -139,8 +139,13 @@ __global__ __launch_bounds__(256) void pdrf_kernel(const LT* __restrict__ lab, i
     if (slot >= 0) {
       const float M = tasks[slot].M;
       const float max_daf = tasks[slot].max_val;
-      p = dbf[i] * M;        // np.multiply(DBF, M)            trace.py:341
-      p = 1.0f - p;          // np.subtract(f(1), PDRF)        trace.py:342
+      if (nsq != KH_PDRF_FINISH) {
+        p = dbf[i] * M;        // np.multiply(DBF, M)            trace.py:341
+        p = 1.0f - p;          // np.subtract(f(1), PDRF)        trace.py:342
+      } else {
+        p = pdrf[i];           // the base raised to the exponent by np.power on the host  trace.py:346-347
+      }
+      if (nsq == KH_PDRF_BASE) { pdrf[i] = p; continue; }
       for (int s = 0; s < nsq; s++) p = p * p;  //             trace.py:343-345
       p = p * scale;         // PDRF *= f(pdrf_scale)          trace.py:349
       float d = daf[i];
@@ -178,8 +183,14 @@ __global__ void inf2zero_kernel(float* f, int64_t n) {   // skeletontricks.pyx:1
 __global__ void pdrf_field_kernel(const float* __restrict__ dbf, float* __restrict__ daf, int64_t n, float M, int nsq, float scale,
                                   float max_daf, float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float p = dbf[i] * M;
-    p = 1.0f - p;
+    float p;
+    if (nsq != KH_PDRF_FINISH) {
+      p = dbf[i] * M;
+      p = 1.0f - p;
+    } else {
+      p = out[i];
+    }
+    if (nsq == KH_PDRF_BASE) { out[i] = p; continue; }
     for (int s = 0; s < nsq; s++) p = p * p;
     p = p * scale;
     if (max_daf != 0.0f) {
@@ -199,8 +210,10 @@ __global__ __launch_bounds__(1024) void target_max_kernel(const uint32_t* __rest
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t v = list[i];
     if (!alive[v]) continue;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(list_daf[i]) << 32) | v;
-    if (key >= best) best = key | (1ull << 63);   // bit 63 marks "found" (DAF >= 0: the sign bit is free)
+    // bit 63 marks "found" (DAF >= 0: the sign bit is free).  It is part of the compared key: `best` carries it from the
+    // first valid voxel on, so a bare key would never beat it again (lists longer than the block, round-2 advisor finding).
+    const unsigned long long key = ((unsigned long long)__float_as_uint(list_daf[i]) << 32) | v | (1ull << 63);
+    if (key > best) best = key;                    // equal keys cannot occur: the voxel index is in the key
   }
   for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); if (ob > best) best = ob; }
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
@@ -209,6 +222,37 @@ __global__ __launch_bounds__(1024) void target_max_kernel(const uint32_t* __rest
     for (unsigned w = 1; w < (blockDim.x >> 6); w++) if (red[w] > best) best = red[w];
     *out = best;
   }
+}
+
+// legacy skeletontricks.find_target (skeletontricks.pyx:331-367): the first voxel, scanning x outermost / z innermost,
+// whose value is the maximum over the mask (strict >, starting from -inf: a -inf or NaN voxel is never chosen).
+// key = orderable float bits << 32 | (~scan position): one atomicMax per wave.
+__global__ __launch_bounds__(256) void find_target_kernel(const uint8_t* __restrict__ labels, const float* __restrict__ field,
+                                                          int64_t sx, int64_t sy, int64_t sz, unsigned long long* out) {
+  const int64_t n = sx * sy * sz;
+  unsigned long long best = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (!labels[i]) continue;
+    const float f = field[i];
+    if (!(f > -KH_INF)) continue;                      // PDRF[x,y,z] > maxpdrf fails for -inf and for NaN
+    const uint32_t b = __float_as_uint(f);
+    const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // monotone map of the floats onto unsigned
+    const int64_t z = i / (sx * sy), r = i - z * sx * sy, y = r / sx, x = r - y * sx;
+    const uint32_t scan = (uint32_t)((x * sy + y) * sz + z);
+    const unsigned long long key = ((unsigned long long)ord << 32) | (0xFFFFFFFFu - scan);
+    if (key > best) best = key;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); if (ob > best) best = ob; }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+// skeletontricks.first_label (skeletontricks.pyx:307-326): the first non-zero voxel of the z / y / x raster = the smallest
+// Fortran linear index
+__global__ __launch_bounds__(256) void first_label_kernel(const uint8_t* __restrict__ labels, int64_t n, unsigned long long* out) {
+  unsigned long long best = ~0ull;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (labels[i] && (unsigned long long)i < best) best = (unsigned long long)i;
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); if (ob < best) best = ob; }
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(out, best);
 }
 
 __global__ void fill_f32_kernel(float* p, int64_t n, float v) {
@@ -294,7 +338,10 @@ extern "C" int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const 
                        const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale, float* pdrf,
                        void* stream) {
   if (int rc = require_device()) return rc;
-  if (log2_exponent < 0 || log2_exponent > 15) { set_error("kh_pdrf: exponent must be a power of two < 2^16"); return KH_EINVAL; }
+  if ((log2_exponent < 0 && log2_exponent != KH_PDRF_BASE && log2_exponent != KH_PDRF_FINISH) || log2_exponent > 15) {
+    set_error("kh_pdrf: log2_exponent must be 0..15, KH_PDRF_BASE or KH_PDRF_FINISH");
+    return KH_EINVAL;
+  }
   hipStream_t st = (hipStream_t)stream;
   KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((pdrf_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
                                                  (const LT*)labels, nvox, slot_of_label, tasks, dbf, daf, log2_exponent, scale,
@@ -347,10 +394,38 @@ extern "C" int kh_inf2zero(float* f, int64_t n, void* stream) {
 extern "C" int kh_pdrf_field(const float* dbf, float* daf, int64_t n, float M, int log2_exponent, float scale, float max_daf,
                              float* out, void* stream) {
   if (int rc = require_device()) return rc;
-  if (log2_exponent < 0 || log2_exponent > 15) { set_error("kh_pdrf_field: exponent must be a power of two < 2^16"); return KH_EINVAL; }
+  if ((log2_exponent < 0 && log2_exponent != KH_PDRF_BASE && log2_exponent != KH_PDRF_FINISH) || log2_exponent > 15) {
+    set_error("kh_pdrf_field: log2_exponent must be 0..15, KH_PDRF_BASE or KH_PDRF_FINISH");
+    return KH_EINVAL;
+  }
   hipLaunchKernelGGL(pdrf_field_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dbf, daf, n, M, log2_exponent,
                      scale, max_daf, out);
   KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_find_target(const uint8_t* labels, const float* field, int64_t sx, int64_t sy, int64_t sz, uint64_t* out,
+                              void* stream) {
+  if (int rc = require_device()) return rc;
+  if (!labels || !field || !out || sx <= 0 || sy <= 0 || sz <= 0 || sx * sy * sz >= (1ll << 32)) {
+    set_error("kh_find_target: bad arguments");
+    return KH_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  KH_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(uint64_t), st));
+  hipLaunchKernelGGL(find_target_kernel, dim3(grid_for(sx * sy * sz, 256)), dim3(256), 0, st, labels, field, sx, sy, sz,
+                     (unsigned long long*)out);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+extern "C" int kh_first_label(const uint8_t* labels, int64_t n, uint64_t* out, void* stream) {
+  if (int rc = require_device()) return rc;
+  if (!labels || !out || n < 0) { set_error("kh_first_label: bad arguments"); return KH_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  KH_HIP_CHECK(hipMemsetAsync(out, 0xFF, sizeof(uint64_t), st));
+  if (n > 0) {
+    hipLaunchKernelGGL(first_label_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, labels, n, (unsigned long long*)out);
+    KH_LAUNCH_CHECK();
+  }
   return KH_OK;
 }
 extern "C" int kh_target_max(const uint32_t* list, const float* list_daf, const uint8_t* alive, int64_t n, uint64_t* out,

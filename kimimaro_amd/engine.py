@@ -127,14 +127,16 @@ class Engine:
                                      self.stream()))
         ncomp = int(d_total.cpu().numpy().view(np.uint32)[0])
         # fewer than 65536 components: the u16 copy of the ids serves every later sweep (narrow())
-        self._narrow = (d_cc.data_ptr(), d_cc16) if ncomp < 65536 else None
+        # (keyed by the tensor OBJECT, which the record keeps alive: the caching allocator hands a freed volume's address
+        # to the next volume of the same size, so an address is no identity)
+        self._narrow = (d_cc, d_cc16) if ncomp < 65536 else None
         rep = d_rep[: ncomp + 1].cpu().numpy().view(np.uint32)
         return d_cc, ncomp, rep
 
     def narrow(self, d_cc):
         """(device label volume, bytes per label) to sweep over: the u16 copy kh_ccl26 made of `d_cc` when there is one."""
         nr = getattr(self, "_narrow", None)
-        if nr is not None and nr[0] == d_cc.data_ptr():
+        if nr is not None and nr[0] is d_cc:
             return nr[1], 2
         return d_cc, 4
 
@@ -347,7 +349,7 @@ class Engine:
                                     np.asarray(dbf_max)[g], np.asarray(first_index)[g], np.asarray(xmin)[g],
                                     np.asarray(xmax)[g], np.asarray(roots, dtype=np.uint32)[g], pick_list(targets_before, g),
                                     pick_list(targets_after, g), params, fix_branching=fix_branching, max_paths=max_paths,
-                                    timings=timings if not done else None, soma=sub_soma, consume=consume,
+                                    timings=timings, soma=sub_soma, consume=consume,
                                     scratch_scale=scratch_scale)
                     done.append(LAST_TASKS)
                 LAST_TASKS = np.concatenate(done)
@@ -467,12 +469,21 @@ class Engine:
         d_ldaf = self.empty(max(total, 1), t.float32)
         _abi.check(lib.kh_gather_f32(P(d_field), P(d_lists), total, P(d_ldaf), st))
         # PDRF (trace.py:148)
-        expo = int(params["pdrf_exponent"])
-        if expo <= 0 or (expo & (expo - 1)) != 0 or expo >= 2 ** 16:
-            raise NotImplementedError("pdrf_exponent must be a power of two < 2**16 on the HIP path")
+        expo = params["pdrf_exponent"]
         d_pdrf = self.empty(nvox, t.float32)
-        _abi.check(lib.kh_pdrf(P(d_cc), label_bytes, nvox, P(d_slot), P(d_tasks), P(d_dbf), P(d_field),
-                               expo.bit_length() - 1, np.float32(params["pdrf_scale"]), P(d_pdrf), st))
+        pdrf_call = lambda stage: _abi.check(lib.kh_pdrf(P(d_cc), label_bytes, nvox, P(d_slot), P(d_tasks), P(d_dbf), P(d_field),
+                                                         stage, np.float32(params["pdrf_scale"]), P(d_pdrf), st))
+        if _abi.is_pow2_exponent(expo):
+            pdrf_call(int(expo).bit_length() - 1)          # repeated squaring, trace.py:343-345
+        else:
+            # trace.py:346-347: np.power.  Its rounding is the host numpy's (libm / SVML powf), which no device powf can
+            # promise, so exactly that function is applied -- by numpy itself -- between the two device halves.
+            pdrf_call(_abi.PDRF_BASE)
+            base = d_pdrf.cpu().numpy()
+            with np.errstate(all="ignore"):
+                np.power(base, expo, out=base)
+            d_pdrf.copy_(t.from_numpy(base))
+            pdrf_call(_abi.PDRF_FINISH)
         mark("pdrf")
         d_dist = self.empty(nvox, t.float32)
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
@@ -532,16 +543,18 @@ class Engine:
         retry = []   # positions (caller order) of the labels whose scratch overflowed
 
         def run_retry(sink):
+            """re-trace the overflowed labels with 8x the scratch.  sink = None: returns the nested call's own (already
+            spliced) result, whose `order` indexes `retry`; else the groups go to `sink` like every other result."""
             if not retry:
-                return
+                return None
             pick = np.asarray(retry, dtype=np.int64)
             sub = lambda a: [a[i] for i in pick] if a is not None else None
             subsoma = None if soma is None else {k: np.asarray(v)[pick] for k, v in soma.items()}
-            self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[pick], counts[pick],
-                            np.asarray(dbf_max)[pick], np.asarray(first_index)[pick], np.asarray(xmin)[pick],
-                            np.asarray(xmax)[pick], np.asarray(roots, dtype=np.uint32)[pick], sub(targets_before),
-                            sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
-                            consume=sink, scratch_scale=scratch_scale * 8)
+            return self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[pick], counts[pick],
+                                   np.asarray(dbf_max)[pick], np.asarray(first_index)[pick], np.asarray(xmin)[pick],
+                                   np.asarray(xmax)[pick], np.asarray(roots, dtype=np.uint32)[pick], sub(targets_before),
+                                   sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
+                                   consume=sink, scratch_scale=scratch_scale * 8)
 
         if consume is not None and 0 < n_large < nl:
             # The largest labels are the tail of the run.  They go to a second stream (as large-LDS workgroups); the
@@ -579,8 +592,8 @@ class Engine:
             return None
         if retry:
             # splice the re-traced labels into the result (callers without a sink: single labels, tests)
-            redo = []
-            run_retry(redo.append)
+            # (the nested call splices its own further retries before it returns: one dict, `order` indexing `retry`)
+            redo = [run_retry(None)]
             pos_of = {int(o): s for s, o in enumerate(res["order"])}
             per_v = [res["verts"][res["voff"][s]:res["voff"][s + 1]] for s in range(nl)]
             per_r = [res["radii"][res["voff"][s]:res["voff"][s + 1]] for s in range(nl)]

@@ -297,6 +297,7 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     if soma_jobs:
         _trace_soma_labels(eng, soma_jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out)
         _mark("soma_labels")
+    eng._narrow = None      # the u16 copy of this volume's ids is not kept alive past the call
     return out
 
 
@@ -363,7 +364,8 @@ def consolidate_paths(locs, lens, radii, shape):
     """Skeleton.from_path per path + simple_merge + consolidate (kimimaro/trace.py:182-184) for one label, on
     linear voxel indices: returns (vertices (n,3) f32 sorted lexicographically by (x,y,z) like
     np.unique(axis=0), edges (m,2) u32 sorted/unique without self loops, radii of the first occurrences).
-    Same result as kimimaro_amd.skeleton.Skeleton.consolidate, ~10x cheaper (1-D unique on a key)."""
+    Same result as kimimaro_amd.skeleton.Skeleton.consolidate (vertices no edge refers to dropped), ~10x cheaper
+    (1-D unique on a key)."""
     sx, sy, sz = shape
     x, y, z = locs % sx, (locs // sx) % sy, locs // (sx * sy)
     key = (x * sy + y) * sz + z                      # row-lexicographic order of (x, y, z)
@@ -379,9 +381,13 @@ def consolidate_paths(locs, lens, radii, shape):
     lo, hi = np.minimum(a, b), np.maximum(a, b)
     ok = lo != hi
     ekey = np.unique(lo[ok] * np.int64(ukey.size) + hi[ok])
-    edges = np.stack([ekey // ukey.size, ekey % ukey.size], axis=1).astype(np.uint32)
+    edges = np.stack([ekey // ukey.size, ekey % ukey.size], axis=1)
+    used = np.zeros(ukey.size, dtype=bool)
+    used[edges.ravel()] = True
+    if not used.all():      # a one-vertex path off every other path: no edge refers to it (consolidate drops it)
+        first, edges = first[used], (np.cumsum(used) - 1)[edges]
     verts = np.stack([x[first], y[first], z[first]], axis=1).astype(np.float32)
-    return verts, edges, radii[first]
+    return verts, edges.astype(np.uint32), radii[first]
 
 
 class Assembler:

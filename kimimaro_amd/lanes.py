@@ -15,8 +15,35 @@ No CPU fallback: a lane is an Engine, and an Engine needs the GPU.
 """
 from __future__ import annotations
 
+import os
 import threading
 import time
+
+
+def ensure_hw_queues(width):
+    """Every lane stream needs a hardware queue of its own: with fewer queues than streams a lane's kernels wait behind
+    another lane's seconds-long path kernel (profiles/r02b_inflight_timeline.txt).  The HIP runtime reads
+    GPU_MAX_HW_QUEUES once, when it initialises (default 4): set it here while that is still possible, otherwise verify it
+    and fail loudly rather than run with the silently serialised lanes that were measured as broken."""
+    want = max(8, 2 * int(width))
+    have = os.environ.get("GPU_MAX_HW_QUEUES")
+    try:
+        import torch
+        started = torch.cuda.is_initialized()
+    except ImportError:      # host-logic tests without torch
+        started = False
+    if not started:
+        if have is None or int(have) < width + 1:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+        return
+    if (have is None and width > 3) or (have is not None and int(have) < width + 1):
+        if os.environ.get("KIMI_LANES_ALLOW_SHARED_QUEUES") == "1":
+            return
+        raise RuntimeError(
+            "kimimaro_amd.Lanes(%d): the HIP runtime is already initialised with GPU_MAX_HW_QUEUES=%s; %d lanes need at "
+            "least %d hardware queues.  Export GPU_MAX_HW_QUEUES=%d before the first GPU call (importing kimimaro_amd "
+            "before touching the GPU does it), or set KIMI_LANES_ALLOW_SHARED_QUEUES=1 to accept lanes that wait for "
+            "each other." % (width, have or "unset (4)", width, width + 1, want))
 
 
 class Lanes:
@@ -27,6 +54,7 @@ class Lanes:
             raise ValueError("Lanes: width must be >= 1")
         self.width = int(width)
         if engine_factory is None:
+            ensure_hw_queues(self.width)
             from .engine import Engine
             import torch
 
@@ -43,7 +71,9 @@ class Lanes:
         of job k is raised when k is reached (later jobs may have run).
         stagger: lane i takes its first job i * stagger seconds after lane 0.  Jobs of equal length started together stay
         in lock step -- their GPU-filling phases collide and their tails leave the GPU idle together; offset by
-        (duration of one job) / width they interleave."""
+        (duration of one job) / width they interleave.
+        When the consumer stops early (an exception of job k, or the generator is closed) no NEW job is started, but the
+        jobs already in flight are waited for before this returns."""
         width = self.width if width is None else max(1, min(int(width), self.width))
         if n <= 0:
             return
@@ -52,6 +82,8 @@ class Lanes:
         out = [None] * n
         ready = [threading.Event() for _ in range(n)]
         stop = [False]
+
+        alive = [0]
 
         def worker(eng, scope, delay):
             def loop():
@@ -70,14 +102,31 @@ class Lanes:
                     except BaseException as ex:  # handed to the caller at position k
                         out[k] = (False, ex)
                     ready[k].set()
-            if scope is None:
-                loop()
-            else:
-                with scope:
+            try:
+                if scope is None:
                     loop()
+                else:
+                    with scope:
+                        loop()
+            except BaseException as ex:
+                # the lane itself failed (its stream scope, not a job).  The other lanes take over its jobs; when it was
+                # the last one, nobody would ever set the remaining events: hand the failure to every job not yet taken
+                # so that the consumer raises instead of waiting forever.
+                with lock:
+                    last = alive[0] == 1
+                    if last:
+                        first, nxt[0] = nxt[0], n
+                if last:
+                    for k in range(first, n):
+                        out[k] = (False, RuntimeError("kimimaro_amd.Lanes: every lane failed outside its job: %r" % (ex,)))
+                        ready[k].set()
+            finally:
+                with lock:
+                    alive[0] -= 1
 
         threads = [threading.Thread(target=worker, args=(self.engines[i], self._scopes[i], i * float(stagger)), daemon=True)
                    for i in range(min(width, n))]
+        alive[0] = len(threads)
         for th in threads:
             th.start()
         try:

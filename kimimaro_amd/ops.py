@@ -159,10 +159,9 @@ def fill(img, in_place=True, return_fill_count=True):
 
 def compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, max_daf):
     """kimimaro.trace.compute_pdrf (kimimaro/trace.py:315-356): DBF has been through zero2inf, DAF is normalised in
-    place (like the reference).  Power-of-two exponents (the repeated-squaring branch of :343-345) only."""
-    e = int(pdrf_exponent)
-    if e <= 0 or (e & (e - 1)) != 0 or e >= 2 ** 16:
-        raise NotImplementedError("pdrf_exponent must be a power of two < 2**16 on the HIP path")
+    place (like the reference).  Power-of-two exponents take the repeated-squaring branch (:343-345); any other
+    exponent the np.power branch (:346-347): the device computes the base and the tail, numpy itself the power (its
+    rounding is the host libm's -- the only function that reproduces the reference's bits on a given machine)."""
     eng = engine()
     f = np.float32
     M = f(1 / (f(dbf_max) ** 1.01))
@@ -171,8 +170,17 @@ def compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, max_daf):
     daf_flat = DAF.reshape(-1, order="F")
     d_daf = t.from_numpy(np.ascontiguousarray(daf_flat)).to(eng.device)
     d_out = eng.empty(d_dbf.numel(), t.float32)
-    _abi.check(eng.lib.kh_pdrf_field(eng.ptr(d_dbf), eng.ptr(d_daf), d_dbf.numel(), M, e.bit_length() - 1, f(pdrf_scale), f(max_daf),
-                                     eng.ptr(d_out), eng.stream()))
+    call = lambda stage: _abi.check(eng.lib.kh_pdrf_field(eng.ptr(d_dbf), eng.ptr(d_daf), d_dbf.numel(), M, stage, f(pdrf_scale),
+                                                          f(max_daf), eng.ptr(d_out), eng.stream()))
+    if _abi.is_pow2_exponent(pdrf_exponent):
+        call(int(pdrf_exponent).bit_length() - 1)
+    else:
+        call(_abi.PDRF_BASE)
+        base = d_out.cpu().numpy()
+        with np.errstate(all="ignore"):
+            np.power(base, pdrf_exponent, out=base)
+        d_out.copy_(t.from_numpy(base))
+        call(_abi.PDRF_FINISH)
     daf_flat[...] = d_daf.cpu().numpy()
     return d_out.cpu().numpy().reshape(np.asarray(DBF).shape, order="F")
 
@@ -261,6 +269,50 @@ def parental_field(field, source, voxel_graph=None):
 def path_from_parents(parents, target):
     """dijkstra3d.path_from_parents(parents, target) as called at kimimaro/trace.py:244: source -> target, (n, 3)."""
     return parents.run(2, parents.source, _loc(target, parents.shape))
+
+
+def dijkstra(field, source, target, voxel_graph=None):
+    """dijkstra3d.dijkstra(field, source, target) as called at kimimaro/trace.py:385 (point_to_point): the cheapest path
+    from `source` to `target` where entering a voxel costs its field value, as an (n, 3) array source first.  The same
+    search as parental_field + path_from_parents (one weighted Dijkstra from the source, predecessor walk from the
+    target); ties between equally cheap paths follow the canonical predecessor rule of DESIGN.md 3.3."""
+    if voxel_graph is not None:
+        raise NotImplementedError("voxel_graph")
+    return path_from_parents(parental_field(field, source), target)
+
+
+def first_label(labels):
+    """kimimaro.skeletontricks.first_label (skeletontricks.pyx:307-326): (x, y, z) of the first non-zero voxel in the
+    z / y / x raster, None when there is none."""
+    eng = engine()
+    lab = _f3(labels)
+    t = eng.torch
+    d = t.from_numpy(np.ascontiguousarray((lab != 0).astype(np.uint8).reshape(-1, order="F"))).to(eng.device)
+    d_out = t.zeros(1, dtype=t.int64, device=eng.device)
+    _abi.check(eng.lib.kh_first_label(eng.ptr(d), lab.size, eng.ptr(d_out), eng.stream()))
+    loc = int(d_out.cpu().numpy().view(np.uint64)[0])
+    if loc == 0xFFFFFFFFFFFFFFFF:
+        return None
+    return tuple(int(v) for v in _pts([loc], lab.shape)[0])
+
+
+def find_target(labels, PDRF):
+    """the legacy kimimaro.skeletontricks.find_target(labels, PDRF) (skeletontricks.pyx:331-367): the first voxel in the
+    reference's scan order (x outermost, z innermost) holding the maximum of PDRF over the mask; (-1, -1, -1) when the
+    mask is empty (or holds only -inf / NaN)."""
+    eng = engine()
+    lab = _f3(labels)
+    t = eng.torch
+    d_lab = t.from_numpy(np.ascontiguousarray((lab != 0).astype(np.uint8).reshape(-1, order="F"))).to(eng.device)
+    d_f = t.from_numpy(np.ascontiguousarray(_f3(PDRF, np.float32).reshape(-1, order="F"))).to(eng.device)
+    d_out = t.zeros(1, dtype=t.int64, device=eng.device)
+    sx, sy, sz = lab.shape
+    _abi.check(eng.lib.kh_find_target(eng.ptr(d_lab), eng.ptr(d_f), sx, sy, sz, eng.ptr(d_out), eng.stream()))
+    key = int(d_out.cpu().numpy().view(np.uint64)[0])
+    if key == 0:
+        return (-1, -1, -1)
+    scan = 0xFFFFFFFF - (key & 0xFFFFFFFF)
+    return (int(scan // (sy * sz)), int((scan // sz) % sy), int(scan % sz))
 
 
 class CachedTargetFinder:

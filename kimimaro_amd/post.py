@@ -189,7 +189,8 @@ def remove_loops(skeleton):
     """skeletons are trees: every cycle is removed, by the rule its number of outside connections selects (post.py:436-563)."""
     if skeleton.empty():
         return skeleton
-    return Skeleton.simple_merge([_remove_loops_component(c) for c in skeleton.components()]).consolidate()
+    return Skeleton.simple_merge([_remove_loops_component(c) for c in skeleton.components()]).consolidate(
+        remove_disconnected_vertices=False)   # post.py:260
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -301,4 +302,5 @@ def remove_ticks(skeleton, threshold):
     re-evaluated after each removal (post.py:235-362)."""
     if skeleton.empty() or threshold == 0:
         return skeleton
-    return Skeleton.simple_merge([_remove_ticks_component(c, threshold) for c in skeleton.components()]).consolidate()
+    return Skeleton.simple_merge([_remove_ticks_component(c, threshold) for c in skeleton.components()]).consolidate(
+        remove_disconnected_vertices=False)   # post.py:444

@@ -118,11 +118,11 @@ class Skeleton:
         skel.space = "physical"
         return skel
 
-    def consolidate(self, remove_disconnected_vertices=False):
+    def consolidate(self, remove_disconnected_vertices=True):
         """Duplicate vertices merged (rows sorted lexicographically), edges renumbered, each edge sorted, rows sorted and
         made unique, self loops dropped; radii / vertex_types from the first occurrence.  remove_disconnected_vertices
-        also drops vertices no edge refers to (what kimimaro/post.py expects of a bare `.consolidate()`); the path
-        assembly of the tracer never produces such vertices and keeps the default."""
+        (default True, as in osteoid / cloud-volume, so that code ported from kimimaro that calls a bare `.consolidate()`
+        behaves the same) also drops vertices no edge refers to -- e.g. a one-vertex path (trace.py:182-184 calls it bare)."""
         if self.empty():
             return Skeleton(segid=self.id, transform=self.transform, space=self.space)
         eff_nodes, uniq_idx, inverse = np.unique(

@@ -78,3 +78,23 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     skel.transform = np.array([[anisotropy[0], 0, 0, 0], [0, anisotropy[1], 0, 0], [0, 0, anisotropy[2], 0]],
                               dtype=np.float32)
     return skel
+
+
+def point_to_point(binary_img, start, end, anisotropy=(1, 1, 1), pdrf_scale=100000, pdrf_exponent=4):
+    """kimimaro.trace.point_to_point (kimimaro/trace.py:358-390): one centerline from `start` to `end` through a binary
+    image -- EDT with black_border, DAF from `start`, PDRF, then the cheapest path end -> start over the PDRF
+    (dijkstra3d.dijkstra); radii are the (zero2inf'ed) DBF at the vertices, as in the reference.  Every step is the HIP
+    kernel behind the function-level mirror of the module the reference calls (kimimaro_amd.ops)."""
+    from . import ops
+    img = np.asfortranarray(binary_img)
+    DBF = ops.edt(img, anisotropy=anisotropy, black_border=True)
+    dbf_max = np.max(DBF)
+    DBF = ops.zero2inf(np.asfortranarray(DBF))
+    DAF, target = ops.euclidean_distance_field(img, start, anisotropy=anisotropy, return_max_location=True)
+    DAF = ops.inf2zero(np.asfortranarray(DAF))
+    PDRF = ops.compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, DAF[target])
+    path = ops.dijkstra(PDRF, end, start)
+    skel = Skeleton.from_path(path)
+    verts = skel.vertices.flatten().astype(np.uint32)
+    skel.radii = DBF[verts[::3], verts[1::3], verts[2::3]]
+    return skel

@@ -41,7 +41,8 @@ class Skeleton:
 
     def consolidate(self):
         """identical vertices merged (rows sorted lexicographically), edges renumbered, sorted, made unique,
-        self loops dropped; per-vertex attributes come from the first occurrence."""
+        self loops dropped; per-vertex attributes come from the first occurrence; vertices no edge refers to are
+        dropped (osteoid's default remove_disconnected_vertices=True: kimimaro/trace.py:182-184 calls it bare)."""
         if self.empty():
             return Skeleton(segid=self.id, transform=self.transform, space=self.space)
         order = np.lexsort((self.vertices[:, 2], self.vertices[:, 1], self.vertices[:, 0]))   # stable: first occurrence leads
@@ -55,6 +56,11 @@ class Skeleton:
         e = e[e[:, 0] != e[:, 1]]
         e = np.unique(e, axis=0) if len(e) else e.reshape(0, 2)
         keep = order[new]
+        used = np.zeros(len(keep), bool)
+        used[e.ravel()] = True
+        if not used.all():
+            renum = np.cumsum(used) - 1
+            keep, e = keep[used], renum[e]
         return Skeleton(self.vertices[keep], e, self.radii[keep], self.id, self.transform, self.space)
 
     def cable_length(self):

@@ -160,6 +160,46 @@ def gen_finder(st):
     print("target_finder: 8")
 
 
+def gen_legacy(st):
+    """the legacy skeletontricks.find_target(labels, PDRF) (skeletontricks.pyx:331-367) and first_label (:307-326) of the
+    compiled reference: fields with many ties (the FIRST maximum of the x-outermost scan wins), negative values, -inf
+    inside the mask, an empty mask."""
+    rng = np.random.default_rng(331)
+    cases = {}
+    n = 0
+    for t in range(14):
+        shape = (int(rng.integers(5, 40)), int(rng.integers(5, 34)), int(rng.integers(3, 30)))
+        dens = [0.6, 0.05, 1.0, 0.3][t % 4]
+        mask = np.asfortranarray((rng.random(shape) < dens).astype(np.uint8))
+        kind = t % 5
+        if kind == 0:
+            f = rng.random(shape) * 100                                  # tie free
+        elif kind == 1:
+            f = np.floor(rng.random(shape) * 6)                          # heavy ties
+        elif kind == 2:
+            f = -np.floor(rng.random(shape) * 5) - 1                     # all negative, ties
+        elif kind == 3:
+            f = np.floor(rng.random(shape) * 4)
+            f[rng.random(shape) < 0.5] = -np.inf                         # -inf inside the mask
+        else:
+            f = np.full(shape, 7.0)                                      # one plateau
+        f = np.asfortranarray(f.astype(np.float32))
+        if t == 9:
+            mask[...] = 0                                                # empty mask -> (-1, -1, -1)
+        if t == 11:
+            f[...] = -np.inf                                             # nothing above -inf -> (-1, -1, -1)
+        cases["shape_%d" % n] = np.array(shape)
+        cases["mask_%d" % n] = np.packbits(mask.ravel(order="F"))
+        cases["field_%d" % n] = f.ravel(order="F")
+        cases["target_%d" % n] = np.array(st.find_target(mask, f), np.int64)
+        fl = st.first_label(mask)
+        cases["first_%d" % n] = np.array(fl if fl is not None else (-1, -1, -1), np.int64)
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "legacy_targets.npz"), **cases)
+    print("legacy_targets:", n)
+
+
 def gen_pdrf(trace):
     rng = np.random.default_rng(11)
     cases = {}
@@ -496,6 +536,10 @@ if __name__ == "__main__" and "post" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
     gen_post(st)
+elif __name__ == "__main__" and "legacy" in sys.argv[1:]:
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    gen_legacy(st)
 elif __name__ == "__main__" and "trace_paths" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
@@ -507,6 +551,7 @@ elif __name__ == "__main__":
     gen_ball(st)
     gen_cube(st)
     gen_finder(st)
+    gen_legacy(st)
     gen_pdrf(trace)
     gen_border(st)
     gen_edt()

@@ -1,0 +1,148 @@
+"""BASELINE.json configs that round 2 left without a parity test on the HIP path:
+
+  configs[1]  c2 (512x512x100, 333 chains, anisotropy (16,16,40)) at FULL size, every skeleton against the pooled oracle
+              (round 2 checked size-independent properties only);
+  configs[3]  the rank / world shard of ONE volume on the HIP path: skeletonize_cc(rank=r, world=2) for r = 0, 1 on one
+              GPU, merged with distributed.merge_rank_results (what the all-gather-v hands every rank), equal to the
+              oracle -- labels whose components land on different ranks included (small Voronoi volume and c2);
+  configs[4]  c5 (1024^3, 8192 chains, anisotropy (8,8,40), fix_branching) through kimimaro_amd.skeletonize on ONE GPU
+              (several launches of the path loop under Engine.scratch_budget), a seeded sample -- the 32 largest
+              components + random ones -- compared bit exact with oracle.pool.skeletonize_pool(only=...).
+
+Bars: vertices / edges bit exact, radii within 1e-4 relative (north_star).  /root/reference is not touched.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from kimimaro_amd.engine import Engine
+    return Engine()
+
+
+def _same(got, want, k):
+    np.testing.assert_array_equal(got.vertices, want.vertices, err_msg="label %d" % k)
+    np.testing.assert_array_equal(got.edges, want.edges, err_msg="label %d" % k)
+    np.testing.assert_allclose(got.radii, want.radii, rtol=1e-4, err_msg="label %d" % k)
+
+
+def _sharded(eng, lab, an, params, dust, world):
+    """what `world` ranks produce for ONE volume, run one after the other on this GPU, and the merge every rank ends up with"""
+    from collections import defaultdict
+    from kimimaro_amd import intake
+    from kimimaro_amd.distributed import merge_rank_results, pack_skeletons, unpack_skeletons
+    lab = intake.format_labels(lab, in_place=False)
+    empty = defaultdict(list)
+    per_rank, sizes = [], []
+    for r in range(world):
+        d_cc, n, remap = intake.compute_cc_labels_device(eng, lab)
+        cc = intake.LazyVolume(eng, d_cc, lab.shape)
+        local = intake.skeletonize_cc(eng, cc, n, remap, params, np.asarray(an, dtype=np.float32), dust, True, True,
+                                      empty, empty, black_border=False, rank=r, world=world, d_cc=d_cc)
+        sizes.append(len(local))
+        per_rank.append(unpack_skeletons(pack_skeletons(local)))     # through the wire format of the all-gather-v
+    return merge_rank_results(per_rank), sizes
+
+
+def test_shard_small_volume_two_and_three_ranks(eng):
+    import kimimaro_amd
+    from oracle import pipeline as P
+    from shapes import voronoi_labels
+    an = (16, 16, 40)
+    lab = voronoi_labels((128, 128, 128), 60, seed=33, pts_per_label=6, step=14.0, anisotropy=an)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=500, fix_borders=True, fix_branching=True)
+    assert len(want) > 20
+    for world in (2, 3):
+        got, sizes = _sharded(eng, lab, an, params, 500, world)
+        assert all(s > 0 for s in sizes) and sum(sizes) >= len(want)      # every rank traced something
+        assert sorted(got) == sorted(want)
+        for k in want:
+            _same(got[k], want[k], k)
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import bench
+    import kimimaro_amd
+    from oracle import pool
+    lab, an = bench.make_volume("c2")
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    want, cc, counts = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True, fix_borders=True)
+    return lab, an, params, want, cc, counts
+
+
+def test_c2_full_size_every_skeleton(eng, c2):
+    import kimimaro_amd
+    lab, an, params, want, _, _ = c2
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=1000, fix_borders=True, fix_branching=True,
+                                   progress=False, _engine=eng)
+    assert sorted(got) == sorted(want) and len(want) >= 300
+    for k in want:
+        _same(got[k], want[k], k)
+
+
+def test_c2_sharded_over_two_ranks(eng, c2):
+    from kimimaro_amd.intake import shard_components
+    lab, an, params, want, cc, counts = c2
+    got, sizes = _sharded(eng, lab, an, params, 1000, 2)
+    assert all(s > 0 for s in sizes)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        _same(got[k], want[k], k)
+    # the case the merge exists for: a label whose components were traced by different ranks
+    segids = [i for i in range(1, counts.size) if counts[i] > 1000]
+    owner = {}
+    for r in range(2):
+        for s in shard_components(segids, counts, r, 2):
+            owner[s] = r
+    flat_cc, flat_lab = cc.ravel(order="K"), np.asfortranarray(lab).ravel(order="K")
+    ids, where = np.unique(flat_cc, return_index=True)
+    first = {int(i): int(flat_lab[w]) for i, w in zip(ids, where)}
+    ranks_of_label = {}
+    for s in segids:
+        ranks_of_label.setdefault(first[s], set()).add(owner[s])
+    split = [l for l, rs in ranks_of_label.items() if len(rs) > 1 and l in want]
+    assert len(split) > 0, "no label of c2 was split over the two ranks: the merge path was not exercised"
+
+
+def test_c5_sample_matches_oracle(eng):
+    """1024^3 / (8,8,40): the sweep's certificate at the third anisotropy, the multi-launch path at full size."""
+    if os.environ.get("KIMI_SKIP_C5") == "1":
+        pytest.skip("KIMI_SKIP_C5=1")
+    import bench
+    import kimimaro_amd
+    import kimimaro_amd.engine as E
+    from oracle import pool
+    lab, an = bench.make_volume("c5")
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=1000, fix_borders=True, fix_branching=True,
+                                   progress=False, _engine=eng)
+    tk = E.LAST_TASKS
+    assert len(tk) > 8000 and int(tk["stat_sweep_calls"].sum()) > 20000
+    # the sample, from the device's own component ids and sizes (kh_ccl26 numbers the components like the oracle's CCL:
+    # by first appearance in the F-order raster, tests/test_gpu_ccl.py)
+    segs, cnts = tk["segid"].astype(np.int64), tk["count"].astype(np.int64)
+    big = segs[np.argsort(-cnts, kind="stable")[:32]]
+    rng = np.random.default_rng(5)
+    nrand = 480 if (os.cpu_count() or 1) >= 64 else 96
+    only = set(big.tolist()) | set(rng.choice(np.sort(segs), size=min(nrand, segs.size), replace=False).tolist())
+    want, _, _ = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True, fix_borders=True,
+                                       only=only)
+    checked = 0
+    for k, w in want.items():
+        g = got[k]
+        if g.vertices.shape != w.vertices.shape:
+            continue   # a label with several components of which only some were sampled
+        _same(g, w, k)
+        checked += 1
+    assert checked >= 0.8 * len(want) and checked >= 64

@@ -179,31 +179,4 @@ def test_joinability(eng, axis):  # :281-333: two chunks with a 1-voxel overlap 
                 and np.array_equal(fb.edges, plain.edges))
 
 
-def test_full_size_c2_properties(eng):
-    """BASELINE config 2 (512x512x100, 333 chains, anisotropy (16,16,40)) at full size: size independent
-    properties of the whole product path (the oracle would need minutes here)."""
-    import sys, os
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    import kimimaro_amd
-    from kimimaro_amd import intake
-    lab, an = bench.make_volume("c2")
-    skels = kimimaro_amd.skeletonize(lab, anisotropy=an, dust_threshold=1000, fix_borders=True, progress=False, _engine=eng)
-    ids, counts = np.unique(lab, return_counts=True)
-    assert set(skels.keys()) <= set(ids.tolist())
-    assert len(skels) >= 0.95 * np.count_nonzero(counts > 1000)
-    d_cc, n, _ = eng.ccl(np.asfortranarray(lab))
-    dbf = eng.edt(d_cc, 4, lab.shape, an, False).cpu().numpy().reshape(lab.shape, order="F")
-    anf = np.asarray(an, dtype=np.float32)
-    total = 0
-    for k, s in skels.items():
-        v = np.rint(s.vertices / anf).astype(np.int64)
-        assert s.space == "physical" and s.id == k
-        np.testing.assert_array_equal(np.multiply(v.astype(np.float32), anf, dtype=np.float32), s.vertices)  # lattice points
-        assert (lab[v[:, 0], v[:, 1], v[:, 2]] == k).all()                   # every vertex lies inside its label
-        np.testing.assert_array_equal(s.radii, dbf[v[:, 0], v[:, 1], v[:, 2]])  # radii are the DBF there
-        e = s.edges.astype(np.int64)
-        assert (np.abs(v[e[:, 0]] - v[e[:, 1]]).max(axis=1) == 1).all()      # edges join 26-neighbours
-        assert len(np.unique(e, axis=0)) == len(e) and (e[:, 0] < e[:, 1]).all()
-        total += len(v)
-    assert total > 10000
+# (BASELINE config 2 at full size: tests/test_gpu_configs.py compares every c2 skeleton with the pooled oracle)

@@ -143,6 +143,33 @@ def test_precomputed_roundtrip():
         Skeleton.from_precomputed(blob + b"x")
 
 
+def test_precomputed_bytes_from_the_format_specification():
+    """to_precomputed against a byte string assembled by hand from the Neuroglancer precomputed skeleton specification
+    (neuroglancer/src/datasource/precomputed/skeletons.md, "Encoded skeleton file format"): num_vertices u32le,
+    num_edges u32le, vertex_positions float32le [num_vertices][3] (C order), edges uint32le [num_edges][2], then every
+    vertex attribute of the info file in order -- here radius float32le [num_vertices], vertex_types uint8 [num_vertices]
+    (the attribute set kimimaro / cloud-volume declare).  Independent of from_precomputed."""
+    import struct
+    from kimimaro_amd.skeleton import Skeleton
+    verts = [(0.0, 0.0, 0.0), (16.0, 32.0, 40.0), (-1.5, 2.25, 1e6)]
+    edges = [(0, 1), (1, 2)]
+    radii = [1.5, 2.5, 0.0]
+    vtypes = [0, 3, 255]
+    want = struct.pack("<II", 3, 2)
+    want += b"".join(struct.pack("<fff", *v) for v in verts)
+    want += b"".join(struct.pack("<II", *e) for e in edges)
+    want += struct.pack("<fff", *radii)
+    want += bytes(vtypes)
+    # spot values of the spec's byte order: 1.5f = 00 00 C0 3F little endian, vertex 1's x = 16.0f = 00 00 80 41
+    assert want[8 + 12:8 + 16] == bytes([0x00, 0x00, 0x80, 0x41]) and want[8 + 36 + 16:8 + 36 + 20] == bytes([0x00, 0x00, 0xC0, 0x3F])
+    s = Skeleton(verts, edges, radii=radii, vertex_types=vtypes, segid=1, space="physical")
+    assert s.to_precomputed() == want
+    assert [a["id"] for a in s.extra_attributes] == ["radius", "vertex_types"]
+    assert [(a["data_type"], a["num_components"]) for a in s.extra_attributes] == [("float32", 1), ("uint8", 1)]
+    back = Skeleton.from_precomputed(want, segid=1)
+    assert back == s and back.vertex_types.tolist() == vtypes
+
+
 def test_plan_launches_groups_labels_under_the_scratch_budget():
     """Engine.scratch_budget: labels sorted by size, groups closed at the budget, an oversized label alone."""
     from kimimaro_amd.engine import plan_launches

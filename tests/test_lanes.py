@@ -67,3 +67,51 @@ def test_exception_is_raised_at_its_position():
 def test_bad_width():
     with pytest.raises(ValueError):
         _lanes(0)
+
+
+def test_every_lane_failing_outside_its_job_raises_instead_of_hanging():
+    """a lane whose stream scope cannot be entered never takes a job; when that happens to ALL lanes nobody would set the
+    jobs' events -- the consumer must get an error, not wait forever (round-2 advisor finding)."""
+    class BadScope:
+        def __enter__(self):
+            raise OSError("no stream")
+
+        def __exit__(self, *a):
+            return False
+
+    lanes = Lanes(2, engine_factory=_Eng, stream_factory=lambda e: BadScope())
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="every lane failed"):
+        list(lanes.run(lambda e, k: k, 5))
+    assert time.perf_counter() - t0 < 5.0
+
+
+def test_one_failing_lane_is_covered_by_the_others():
+    class Scope:
+        def __init__(self, bad):
+            self.bad = bad
+
+        def __enter__(self):
+            if self.bad:
+                raise OSError("no stream")
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    made = []
+
+    def factory(e):
+        made.append(e)
+        return Scope(bad=len(made) == 1)
+
+    lanes = Lanes(3, engine_factory=_Eng, stream_factory=factory)
+    assert [v for _, v in lanes.run(lambda e, k: k * 2, 7)] == [0, 2, 4, 6, 8, 10, 12]
+
+
+def test_hw_queue_guard(monkeypatch):
+    from kimimaro_amd import lanes as L
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    L.ensure_hw_queues(6)          # HIP not started in the CPU suite: the variable is set for the runtime to read
+    import os
+    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 7

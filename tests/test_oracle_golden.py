@@ -247,3 +247,18 @@ def test_trace_control_flow_matches_reference_trace():
         seen += 1
         kinds.add((kw.get("fix_branching", True), "max_paths" in kw, bool(extra), "soma_detection_threshold" in kw))
     assert seen >= 20 and len(kinds) >= 5
+
+
+def test_legacy_find_target_golden():
+    """the definition kh_find_target implements (first maximum of the x-outermost / z-innermost scan, strict > from -inf),
+    restated in numpy, against the compiled reference's vectors (tests/golden/legacy_targets.npz) -- and first_label."""
+    z = np.load(os.path.join(G, "legacy_targets.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(int(v) for v in z["shape_%d" % i])
+        mask = np.unpackbits(z["mask_%d" % i])[: int(np.prod(shape))].reshape(shape, order="F").astype(bool)
+        field = z["field_%d" % i].reshape(shape, order="F")
+        c = np.where(mask & (field > -np.inf), field, -np.inf)      # C order of (x, y, z) = the reference's scan
+        got = tuple(int(v) for v in np.unravel_index(int(np.argmax(c)), shape)) if np.max(c, initial=-np.inf) > -np.inf else (-1, -1, -1)
+        assert got == tuple(int(v) for v in z["target_%d" % i]), i
+        fl = K.first_label(np.asfortranarray(mask.astype(np.uint8)))
+        assert (tuple(int(v) for v in fl) if fl is not None else (-1, -1, -1)) == tuple(int(v) for v in z["first_%d" % i]), i
