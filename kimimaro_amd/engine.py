@@ -272,7 +272,7 @@ class Engine:
         _abi.check(lib.kh_scatter_lists(P(d_cc), 4, nvox, P(d_slot), 1, P(d_off), P(d_cur), P(d_lists), st))
         _abi.check(lib.kh_neighbor_mask(P(d_cc), 4, shape[0], shape[1], shape[2], P(d_nbr), st))
         ctx.update(d_slot=d_slot, d_lists=d_lists, d_nbr=d_nbr, d_queues=self.empty(4 * (cnt + 64), t.int32),
-                   d_heap=self.empty(2 * hcap, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
+                   d_heap=self.empty(2 * hcap + 128, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
         d_rank, rdims, max_nlev, ev_units = None, (0, 0, 0), 0, 0
         rmax = float(np.float32(rmax))
         if self.sweep and cnt > 0 and np.isfinite(rmax) and rmax > 0:
@@ -365,7 +365,8 @@ class Engine:
         q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
         # heap / path scratch are sized for the common case; a label that overflows them is traced again on its own
         # with `scratch_scale` times as much (below) -- the reference has no such limits
-        hcap = np.maximum((3 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256)  # (the sweep's lists live here too)
+        # (the sweep's lists live here too; the first 2047 slots of a heap are in LDS, slot 2047 must exist: csrc/trace.hip Heap)
+        hcap = np.maximum(np.maximum((3 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256), 2304)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
         pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
@@ -489,7 +490,7 @@ class Engine:
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
-        d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
+        d_heap = self.empty(2 * int(hcap.sum()) + 128, t.int64)  # 16-byte nodes (+ slack: a pop reads one node past its array)
         d_cstate = t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device)
         d_arena = self.empty(max(ev_total, 1) * 32 + 32, t.int64)   # units of 256 bytes, 256-byte aligned start
         arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
