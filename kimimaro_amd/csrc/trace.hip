@@ -436,7 +436,10 @@ __device__ __forceinline__ bool pipe_on_chain_range(uint32_t pos, int lane, uint
 
 // One tick.  `A` = ballot of the occupied lanes (non-zero).  Returns true when lane 0's pop moved on (the root of the heap
 // was rewritten: *root receives its new content).
-template <class H>
+// DEEP = false: every slot the tick touches is in LDS (no HBM instruction is issued at all: a small flood never pays an L2
+// round trip per tick).  DEEP = true: the HBM loads are issued for every lane, the ones that do not need them read the dummy
+// slot TOP -- no data-dependent branch between the loads, so all of them (LDS and HBM) are in flight before the first wait.
+template <bool DEEP, class H>
 __device__ __forceinline__ bool heap_pipe_tick(H& h, HeapPipe& p, int lane, unsigned long long A, bool fresh0,
                                                uint32_t& ep_cur, uint32_t& ep_prev, uint32_t& ep_count, hnode_t& root) {
   const bool act = p.pos != PIPE_NONE;
@@ -451,23 +454,21 @@ __device__ __forceinline__ bool heap_pipe_tick(H& h, HeapPipe& p, int lane, unsi
   }
   const bool mine = (fetch >> lane) & 1ull;
   const bool cand = mine || (fresh0 && lane == 0);      // the fresh pop reads its slot either way: value or floor candidate
-  // ---- read phase
+  // ---- read phase: every load of the tick is issued before the first one is waited for (one round trip per tick: a
+  // first version that initialised the HBM results with the LDS ones waited four times, 2.5 k cycles per tick)
   const uint32_t c0 = 2u * p.pos + 1u;
   const bool hasL = act && c0 < p.plen, hasR = act && c0 + 1u < p.plen;
-  const bool lo = c0 < H::TOP;                          // siblings c0 (odd), c0 + 1 share the memory space
+  const bool lo = !DEEP || c0 < H::TOP;                 // siblings c0 (odd), c0 + 1 share the memory space
+  const bool vlo = !DEEP || p.plen < H::TOP;
   const uint32_t il = hasL && lo ? c0 : 0u;
-  const hnode_t Ll = h.top[il], Rl = h.top[il + 1u];
-  hnode_t Lg = Ll, Rg = Rl, Vg = Ll;
-  const bool deep = hasL && !lo;
-  if (ballot64(deep)) {
-    const uint32_t ig = deep ? c0 : H::TOP;
-    Lg = h.node[ig];
-    Rg = h.node[ig + 1u];
+  const uint32_t iv = cand && vlo ? p.plen : 0u;
+  const hnode_t Ll = h.top[il], Rl = h.top[il + 1u], Vl = h.top[iv];
+  hnode_t L = Ll, R = Rl, V = Vl;
+  if constexpr (DEEP) {
+    const uint32_t ig = hasL && !lo ? c0 : H::TOP;
+    const hnode_t Lg = h.node[ig], Rg = h.node[ig + 1u], Vg = h.node[cand && !vlo ? p.plen : H::TOP];
+    L = lo ? Ll : Lg; R = lo ? Rl : Rg; V = vlo ? Vl : Vg;
   }
-  const bool vlo = p.plen < H::TOP;
-  const hnode_t Vl = h.top[cand && vlo ? p.plen : 0u];
-  if (ballot64(cand && !vlo)) Vg = h.node[cand && !vlo ? p.plen : H::TOP];
-  const hnode_t L = lo ? Ll : Lg, R = lo ? Rl : Rg, V = vlo ? Vl : Vg;
   // ---- values and floors
   if (fresh0) {                                          // wave uniform
     const uint32_t ck = rdlane_u32(V.x, 0);              // what the fresh pop's slot holds now
@@ -490,7 +491,7 @@ __device__ __forceinline__ bool heap_pipe_tick(H& h, HeapPipe& p, int lane, unsi
   const hnode_t W = stop ? val : P;
   // ---- write phase
   if (go) {
-    if (p.pos < H::TOP) h.top[p.pos] = W;
+    if (!DEEP || p.pos < H::TOP) h.top[p.pos] = W;
     else h.node[p.pos] = W;
   }
   const bool moved0 = (A & 1ull) && frz < 0;
@@ -694,8 +695,11 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
     }
     if (!A) continue;
     if (PROF) n_ticks++;
-    if (heap_pipe_tick(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root))
-      root_live = __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // does this tick touch a slot outside LDS?  (children of the holes, the slots of the values still to be fetched)
+    const bool deep = ballot64(p.pos != PIPE_NONE && (2u * p.pos + 2u >= H::TOP || (!p.hv && p.plen >= H::TOP))) != 0ull;
+    const bool moved = deep ? heap_pipe_tick<true>(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root)
+                            : heap_pipe_tick<false>(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root);
+    if (moved) root_live = __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane == 0) {
     if (ovf) atomicOr(status, KH_ST_HEAP_OVERFLOW);
@@ -811,18 +815,51 @@ struct SweepGlobal {
   unsigned long long* cstate;   // one word per voxel, all zero on entry and on exit
   unsigned char* arena;         // event arenas (per label: kh_label_t.ev_offset, in units of 256 bytes)
   uint32_t lds_levels;          // labels with more levels keep their level words in the arena instead of LDS
+  uint32_t* park;               // nullptr: a call the sweep cannot certify runs on the heap in place; else see ParkCtl
+  const uint32_t* index;        // nullptr: workgroup b traces tasks[b]; else tasks[index[b]] (a resume launch)
 };
 
+// ---- parking ------------------------------------------------------------------------------------------------------
+// A call the sweep cannot certify is redone on the exact heap: ONE wave working for up to seconds.  Inside the path
+// kernel that wave sits in a 256-thread, 152-VGPR, 39-KiB-LDS workgroup slot whose other three waves wait at a barrier --
+// 55 % of the GPU's slot time at c3 (round 2).  With a park record the path kernel instead PARKS the label: its loop state
+// goes to its task record, its index into the queue below, and the workgroup ends.  A second kernel of 64-thread
+// workgroups (heap_server_kernel, launched beside the path kernel on another stream) takes parked labels from the queue
+// as they arrive and runs their heap call; the host then launches the path kernel again over the parked labels, which
+// resume behind the invalidation.  Nobody ever waits for the server: the path kernel only appends and exits, the server
+// polls until the path kernel's workgroups are all gone (t_done == t_total) and the queue is drained.  The queue has one
+// entry per task of the launch plus one per server workgroup (a ticket may lie that far beyond the last entry); the host
+// fills it with ~0 = "not written yet".
+struct ParkCtl {
+  uint32_t q_count;     // labels appended (path kernel)
+  uint32_t q_taken;     // tickets handed out (server)
+  uint32_t t_done;      // path workgroups that have ended
+  uint32_t t_total;     // ... of this launch (host)
+  uint32_t error;       // server: 1 = gave up waiting (a path kernel that never ends: cannot happen, but never hang the GPU)
+  uint32_t served;      // server: calls done (diagnostic)
+  uint32_t pad[10];
+  // uint32_t queue[] follows (64 bytes in)
+};
+static constexpr uint32_t KH_PARKED = 0xFFFFFFFFu;
+// kh_label_t.park_phase
+static constexpr uint32_t PARK_NONE = 0, PARK_SOMA = 1, PARK_LOOP = 2, PARK_DONE = 2;   // + PARK_DONE once the server has run the call
+
 // One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
-// certifies the call, the heap emulation (wave 0) otherwise.  Returns the number of voxels invalidated.
-template <bool PROF, class H>
+// certifies the call, the heap emulation otherwise -- by wave 0 in place, or, with can_park, by the heap server: then
+// KH_PARKED is returned (alive is as it was before the call) and the caller parks the label.  A call the sweep cannot
+// even try (no table for the label, path too long) always runs in place: such a label would park at every path.
+// Returns the number of voxels invalidated.  INPLACE = false (the path kernel that is launched with a park record) has no
+// heap code at all -- its registers are the sweep's -- and parks every call the sweep does not certify.
+template <bool PROF, bool INPLACE, class H>
 __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                                const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                                float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
-                                               uint32_t* sweep_stats) {
+                                               uint32_t* sweep_stats, bool can_park) {
   const int tid = threadIdx.x;
   bool ok = false;
+  bool tried = false;
   if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
+    tried = true;
     uint32_t cnt = 0;
     ok = sweep_ball(*sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt);
     if (tid == 0) {
@@ -843,10 +880,15 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   }
   if (!ok) {
     __syncthreads();
-    if (tid < 64) {
-      const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                                  &ctl->status, &ctl->u3, ctl->cyc3);
-      if (tid == 0) ctl->u1 = c;
+    if constexpr (!INPLACE) {
+      return KH_PARKED;
+    } else {
+      if (tried && can_park) return KH_PARKED;
+      if (tid < 64) {
+        const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+                                                    &ctl->status, &ctl->u3, ctl->cyc3);
+        if (tid == 0) ctl->u1 = c;
+      }
     }
   }
   __syncthreads();
@@ -889,7 +931,7 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.sh = swsh;
 }
 
-template <bool PROF, int TOPL>
+template <bool PROF, bool INPLACE>
 __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
@@ -903,9 +945,13 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
   __shared__ uint32_t sweep_stats[5];
-  // (Heap<TOPL>::TOP + 3) nodes for the heap emulation; the sweep's level words and lists use the same bytes
+  // (Heap<1>::TOP + 3) nodes for the heap emulation; the sweep's level words and lists use the same bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
-  kh_label_t* task = &tasks[blockIdx.x];
+  constexpr int TOPL = 1;
+  const uint32_t task_index = sg.index ? sg.index[blockIdx.x] : blockIdx.x;
+  kh_label_t* task = &tasks[task_index];
+  ParkCtl* park = reinterpret_cast<ParkCtl*>(sg.park);
+  const bool can_park = !INPLACE || park != nullptr;
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
@@ -931,38 +977,63 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   const uint32_t* after = before + task->n_before;
   const bool soma = task->soma_mode != 0;
   const bool implicit = task->n_before == 0 && !soma;   // trace.py:160-172
+  // a resumed label (park_phase: the heap server has run the call the label parked at) picks its loop state up again
+  const uint32_t resume = task->park_phase;             // PARK_NONE, PARK_SOMA + PARK_DONE or PARK_LOOP + PARK_DONE
   uint32_t nb = implicit ? 1u : task->n_before;
   uint32_t na = task->n_after;
   uint32_t valid = nf;
-  uint32_t npaths = 0, nverts = 0;
+  uint32_t npaths = 0, nverts = 0, max_paths = 0;
+  if (resume != PARK_NONE) {
+    valid = task->park_valid; npaths = task->park_npaths; nverts = task->park_nverts; nb = task->park_nb; na = task->park_na;
+    max_paths = task->park_max_paths;
+  }
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
   if (tid == 0) {
-    ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
+    // (a resumed label whose parked call failed on the server -- heap scratch too small -- stops right behind it)
+    ctl.status = resume != PARK_NONE ? task->status : 0u;
+    ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
     sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top);
   }
   __syncthreads();
-  if (soma) {
-    // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
-    if (tid == 0) pverts[0] = root;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  uint32_t parked = PARK_NONE, park_plen = 0;
+  bool finished = false;                                // trace.py:217-218: nothing to trace
+  if (resume != PARK_LOOP + PARK_DONE) {
+    if (soma) {
+      // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
+      uint32_t c;
+      if (resume == PARK_SOMA + PARK_DONE) {
+        c = task->park_count;
+      } else {
+        if (tid == 0) pverts[0] = root;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        c = invalidate<PROF, INPLACE, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+                                         heap, list, nf, sweep_stats, can_park);
+      }
+      if (c == KH_PARKED) { parked = PARK_SOMA; park_plen = 1; }
+      else valid -= c;                                    // trace.py:211 counts what is left
+    }
+    if (!parked) {
+      max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
+      if (nb + na >= max_paths) {                           // trace.py:217-218
+        finished = true;
+      } else if (fix_branching) {
+        if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
+      } else {
+        // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
+        sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
+      }
+    }
     __syncthreads();
-    valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                          heap, list, nf, sweep_stats);   // trace.py:211 counts what is left
   }
-  const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
-  if (nb + na >= max_paths) {                           // trace.py:217-218
-    if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; task->status |= ctl.status; }
-    return;
-  }
-  if (fix_branching) {
-    if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
-  } else {
-    // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
-    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
-  }
-  __syncthreads();
-  while ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths) {
+  bool redo = resume == PARK_LOOP + PARK_DONE;          // the first turn of the loop resumes behind its invalidation
+  while (!parked && !finished && (redo || ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths))) {
+    uint32_t plen = 0;
+    uint32_t* out = pverts + nverts;
+    if (redo) {
+      plen = task->park_plen;
+    } else {
     // ---- target selection, trace.py:225-230
     t0 = clock64();
     uint32_t target;
@@ -991,13 +1062,11 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     }
     // ---- railroad, trace.py:240-242
     t_target += clock64() - t0; t0 = clock64();
-    uint32_t plen = 0;
     if (nverts >= pcap || npaths >= pcap) {
       if (tid == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW);
       __syncthreads();
       break;
     }
-    uint32_t* out = pverts + nverts;
     if (!fix_branching) {
       // dijkstra3d.path_from_parents (trace.py:244): walk target -> root, return root -> target
       if (tid == 0) ctl.u0 = 0;
@@ -1079,11 +1148,19 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
       __syncthreads();
       if (plen == 0) break;
     }
+    t_rail += clock64() - t0;
+    }
     // ---- invalidation, trace.py:253-259
-    t_rail += clock64() - t0; t0 = clock64();
-    if (valid > 0)
-      valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list, nf,
-                                            sweep_stats);
+    t0 = clock64();
+    if (redo) {
+      valid -= task->park_count;                          // the call the label parked at, done by the heap server
+      redo = false;
+    } else if (valid > 0) {
+      const uint32_t c = invalidate<PROF, INPLACE, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list,
+                                                      nf, sweep_stats, can_park);
+      if (c == KH_PARKED) { parked = PARK_LOOP; park_plen = plen; break; }
+      valid -= c;
+    }
     // ---- rails, trace.py:261-263
     t_inval += clock64() - t0;
     if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
@@ -1094,26 +1171,118 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     if (ctl.status) break;
   }
   __syncthreads();
-  if (!fix_branching) {  // leave dist = +inf behind
+  if (!parked && !fix_branching && !finished) {  // leave dist = +inf behind
     for (uint32_t i = tid; i < nf; i += nthr) st_f32_l2(&dist[list[i]], KH_INF);
   }
   if (tid == 0) {
-    task->n_paths = npaths;
-    task->n_vertices = nverts;
+    if (parked) {
+      task->park_phase = parked;
+      task->park_valid = valid; task->park_npaths = npaths; task->park_nverts = nverts; task->park_nb = nb; task->park_na = na;
+      task->park_max_paths = max_paths; task->park_plen = park_plen;
+    } else {
+      task->park_phase = PARK_NONE;
+      task->n_paths = finished ? 0u : npaths;
+      task->n_vertices = finished ? 0u : nverts;
+    }
+    // (counters accumulate over the launches of a label that parked; the host zeroes them)
     task->status |= ctl.status;
-    task->stat_settled = ctl.u2;
-    task->stat_heap_pushes = ctl.u3;
-    task->cyc_target = (uint32_t)(t_target >> 10);
-    task->cyc_rail = (uint32_t)(t_rail >> 10);
-    task->cyc_inval = (uint32_t)(t_inval >> 10);
-    if (PROF) task->cyc_pop = (uint32_t)(ctl.cyc3[0] >> 10);
-    if (PROF) task->cyc_push = (uint32_t)(ctl.cyc3[1] >> 10);
-    task->cyc_fire = (uint32_t)(ctl.cyc3[2] >> 10);
-    task->stat_sweep_calls = sweep_stats[0];
-    task->stat_sweep_bails = sweep_stats[1];
-    task->stat_sweep_levels = sweep_stats[2];
-    task->stat_sweep_events = sweep_stats[3];
-    task->stat_sweep_why = sweep_stats[4];
+    task->stat_settled += ctl.u2;
+    task->stat_heap_pushes += ctl.u3;
+    task->cyc_target += (uint32_t)(t_target >> 10);
+    task->cyc_rail += (uint32_t)(t_rail >> 10);
+    task->cyc_inval += (uint32_t)(t_inval >> 10);
+    if (PROF) task->cyc_pop += (uint32_t)(ctl.cyc3[0] >> 10);
+    if (PROF) task->cyc_push += (uint32_t)(ctl.cyc3[1] >> 10);
+    if (PROF) task->cyc_fire += (uint32_t)(ctl.cyc3[2] >> 10);
+    task->stat_sweep_calls += sweep_stats[0];
+    task->stat_sweep_bails += sweep_stats[1];
+    task->stat_sweep_levels += sweep_stats[2];
+    task->stat_sweep_events += sweep_stats[3];
+    task->stat_sweep_why |= sweep_stats[4];
+  }
+  if (park != nullptr && tid == 0) {
+    // the task record (and, through the barrier above, the workgroup's alive / pdrf / path writes) must be visible to the
+    // server before the label shows up in the queue, and the queue entry before this workgroup counts as done
+    __threadfence();
+    if (parked) {
+      uint32_t* queue = sg.park + 16;
+      const uint32_t slot = atomicAdd(&park->q_count, 1u);
+      __hip_atomic_store(&queue[slot], task_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (entries start as ~0)
+      __threadfence();
+    }
+    atomicAdd(&park->t_done, 1u);
+  }
+}
+
+// The heap server: 64-thread workgroups that take parked labels (tickets in queue order) and run the invalidation call they
+// parked at on the exact heap (invalidate_ball: the pop pipeline).  A workgroup with a ticket beyond the queue's end waits
+// for the entry to appear -- or for the path kernel to be over (t_done == t_total; q_count is final then, because a path
+// workgroup publishes its entry before it counts itself done).  The wait is bounded (wall clock): never hang the GPU.
+template <int TOPL>
+__global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, const uint32_t* __restrict__ nbrmask, Geometry g,
+                                                         const float* __restrict__ dbf, uint8_t* alive, float scale,
+                                                         float constant, hnode_t* heap_nodes, uint32_t* path_vertices,
+                                                         uint32_t* park_words, unsigned long long patience) {
+  __shared__ Geometry geo;
+  __shared__ uint32_t sh_status, sh_pushes, sh_ticket, sh_go;
+  __shared__ unsigned long long cyc3[3];
+  extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
+  ParkCtl* park = reinterpret_cast<ParkCtl*>(park_words);
+  const uint32_t* queue = park_words + 16;
+  const int lane = threadIdx.x;
+  if (lane == 0) geo = g;
+  __syncthreads();
+  const unsigned long long t_start = wall_clock64();
+  for (;;) {
+    if (lane == 0) {
+      const uint32_t ticket = atomicAdd(&park->q_taken, 1u);
+      uint32_t go = 2;                                    // 1: entry readable, 0: nothing will come, 2: keep waiting
+      while (go == 2) {
+        if (__hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu) { go = 1; break; }
+        if (__hip_atomic_load(&park->t_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >=
+            __hip_atomic_load(&park->t_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          // the path kernel is over: every entry it will ever write is written
+          go = __hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu ? 1u : 0u;
+          break;
+        }
+        if (wall_clock64() - t_start > patience) { atomicOr(&park->error, 1u); go = 0; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+      sh_ticket = ticket;
+      sh_go = go;
+    }
+    __syncthreads();
+    if (sh_go == 0u) return;
+    // what the path kernel wrote for this label (task record, path vertices, restored alive bytes) is read with ordinary
+    // loads below: drop whatever this CU's vector cache still holds from an earlier call
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    kh_label_t* task = &tasks[__hip_atomic_load(&queue[sh_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    const uint32_t phase = task->park_phase;
+    Heap<TOPL> heap;
+    heap.node = heap_nodes + task->heap_offset;
+    heap.top = (lds_hnode_t*)heap_top;
+    heap.cap = task->heap_capacity;
+    heap.n = 0;
+    if (lane == 0) { sh_status = 0; sh_pushes = 0; cyc3[0] = cyc3[1] = cyc3[2] = 0; }
+    __syncthreads();
+    uint32_t* pverts = path_vertices + task->path_offset;
+    const bool soma_call = phase == PARK_SOMA;
+    const uint32_t* path = soma_call ? pverts : pverts + task->park_nverts;
+    const long long t_call = clock64();
+    const uint32_t c = invalidate_ball<false, Heap<TOPL>>(geo, task, nbrmask, dbf, alive, path, task->park_plen,
+                                                          soma_call ? task->soma_scale : scale,
+                                                          soma_call ? task->soma_const : constant, heap, &sh_status, &sh_pushes, cyc3);
+    __syncthreads();
+    if (lane == 0) {
+      task->park_count = c;
+      task->cyc_fire += (uint32_t)((unsigned long long)(clock64() - t_call) >> 10);   // kilo-cycles on the heap server
+      task->status |= sh_status;
+      task->stat_heap_pushes += sh_pushes;
+      task->park_phase = phase + PARK_DONE;
+      atomicAdd(&park->served, 1u);
+    }
+    __threadfence();
+    __syncthreads();
   }
 }
 
@@ -1143,8 +1312,8 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
     sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top);
   }
   __syncthreads();
-  const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                               lists + task->list_offset, nf, sweep_stats);
+  const uint32_t c = invalidate<false, true, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+                                               lists + task->list_offset, nf, sweep_stats, false);
   if (tid == 0) {
     *invalidated = (long long)c;
     task->status |= ctl.status;
@@ -1274,6 +1443,13 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
 }
 
 namespace kh {
+static size_t trace_lds_bytes(const SweepGlobal& sg, uint32_t max_nlev) {
+  // (the variant launched with a park record runs no heap: its LDS is the sweep's alone)
+  size_t lds = sg.park ? (size_t)SW_CHAIN * 4 : (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
+  if (sg.rank && swl > lds) lds = swl;
+  return lds;
+}
 template <bool PROF>
 static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
@@ -1281,22 +1457,27 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                         int fix_branching, const SweepGlobal& sg, uint32_t max_nlev) {
   if (count <= 0) return KH_OK;
-  size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
-  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
-  if (sg.rank && swl > lds) lds = swl;
+  const size_t lds = trace_lds_bytes(sg, max_nlev);
   {
     // More than 48 KiB of dynamic LDS has to be allowed per kernel.  The attribute belongs to the function, not to the
     // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
     // launch can ask for -- so that a concurrent caller never lowers it under somebody else's launch.
     const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
-    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
   const char* thr_env = getenv("KH_TRACE_THREADS");   // developer knob
   const unsigned nthreads = thr_env ? (unsigned)atoi(thr_env) : 256u;
-  hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
-                     g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                     path_lengths, fix_branching, sg);
+  if (sg.park)   // every uncertified call goes to the heap server: the variant without any heap code
+    hipLaunchKernelGGL((trace_paths_kernel<PROF, false>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
+                       g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
+                       path_lengths, fix_branching, sg);
+  else
+    hipLaunchKernelGGL((trace_paths_kernel<PROF, true>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
+                       g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
+                       path_lengths, fix_branching, sg);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -1333,10 +1514,12 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
                               void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                               const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                              uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream) {
+                              uint64_t* cstate, void* event_arena, int flags, int fix_branching,
+                              uint32_t* park, const uint32_t* task_index, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
+  if (park && ((uintptr_t)park & 63) != 0) { set_error("kh_trace_paths: the park record must be 64-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
@@ -1353,6 +1536,8 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
+  sg.park = park;
+  sg.index = task_index;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
@@ -1361,6 +1546,27 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
               : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                     scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
                                     (uint32_t)max_nlev);
+}
+
+extern "C" int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                              float wz, const float* dbf, uint8_t* alive, float scale, float constant, void* heap_nodes,
+                              uint32_t* path_vertices, uint32_t* park, int64_t nblocks, double patience_seconds, void* stream) {
+  if (int rc2 = require_device()) return rc2;
+  if (!tasks || !nbrmask || !dbf || !alive || !heap_nodes || !path_vertices || !park || nblocks <= 0 || nblocks > 65536 ||
+      sx * sy * sz >= (1ll << 32) || ((uintptr_t)heap_nodes & 15) != 0 || ((uintptr_t)park & 63) != 0 || !(patience_seconds > 0)) {
+    set_error("kh_heap_server: bad arguments");
+    return KH_EINVAL;
+  }
+  Geometry g;
+  make_geometry(g, sx, sy, sz, wx, wy, wz);
+  const size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&heap_server_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+  const unsigned long long patience = (unsigned long long)(patience_seconds * 1e8);   // wall_clock64 ticks at 100 MHz
+  hipLaunchKernelGGL((heap_server_kernel<1>), dim3((unsigned)nblocks), dim3(64), lds, (hipStream_t)stream, tasks, nbrmask, g, dbf,
+                     alive, scale, constant, (hnode_t*)heap_nodes, path_vertices, park, patience);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
 }
 
 extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,
@@ -1387,6 +1593,8 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
+  sg.park = nullptr;
+  sg.index = nullptr;
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (level_rank && swl > lds) lds = swl;

@@ -58,9 +58,14 @@ class Engine:
         # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
         self.torch.cuda.set_device(self.device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
-        self._side = None     # second stream: the biggest labels run there while the others are collected
-        self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
-        self.split_min_voxels = 16384       # ... if they have at least this many voxels
+        self._side = None     # second stream: the heap server runs there beside the path kernel
+        self.split_slots = 0  # (rounds 1-2: the biggest labels on a second stream; superseded by the heap server)
+        # Calls the sweep cannot certify go to the heap server (csrc/trace.hip "parking"): 64-thread workgroups beside the
+        # path kernel instead of one busy wave inside a 256-thread path workgroup.  False: the heap runs in place.
+        self.park = os.environ.get("KH_PARK", "1") != "0"
+        self.park_servers = int(os.environ.get("KH_PARK_SERVERS", "256"))   # server workgroups per launch (one wave each)
+        self.park_patience = 60.0          # seconds a server waits for a path kernel that never ends before giving up
+        self.last_rounds = 0                # launches of the path kernel the last run_labels call needed
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
@@ -496,19 +501,60 @@ class Engine:
         arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
-        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
-        # are consumed incrementally they go to a second stream and the others are collected while they still run
-        n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
         prof = 1 if self.profile else 0
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
+        use_park = bool(self.park) and d_rank is not None
+        n_srv = int(max(1, min(self.park_servers, nl))) if use_park else 0
+        d_park = t.zeros(16 + nl + n_srv + 16, dtype=t.int32, device=self.device) if use_park else None
+        isz = _abi.LABEL_T.itemsize
 
         def launch(first, count, stream):
-            tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
-            _abi.check(lib.kh_trace_paths(tasks_ptr, count, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
-                                          P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
-                                          np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
-                                          P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
-                                          P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), stream))
+            """the path loop of tasks [first, first + count), to completion: with the heap server, as many launches of the
+            path kernel as the labels need (a label parks at a call the sweep cannot certify, the server runs that call,
+            the next launch resumes the parked labels)."""
+            tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * isz)
+
+            def paths(ntasks, park_ptr, index_ptr):
+                _abi.check(lib.kh_trace_paths(tasks_ptr, ntasks, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
+                                              P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
+                                              np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
+                                              P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
+                                              P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), park_ptr, index_ptr, stream))
+
+            self.last_rounds = 1
+            if not use_park:
+                paths(count, C.c_void_p(0), C.c_void_p(0))
+                return
+            cur = t.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = t.cuda.Stream(device=self.device)
+            side = self._side
+            hdr = np.zeros(16, dtype=np.int32)
+            d_index, ntasks = None, count
+            while True:
+                hdr[3] = ntasks
+                d_park[:16].copy_(t.from_numpy(hdr), non_blocking=False)
+                d_park[16:].fill_(-1)
+                side.wait_stream(cur)      # (the server starts behind the reset above, not behind the path kernel)
+                # path kernel first: should the two launches ever be serialised (fewer hardware queues than streams), the
+                # server then runs behind it and drains the queue instead of waiting for a kernel that cannot start
+                paths(ntasks, P(d_park), P(d_index) if d_index is not None else C.c_void_p(0))
+                _abi.check(lib.kh_heap_server(tasks_ptr, P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_alive),
+                                              np.float32(params["scale"]), np.float32(params["const"]), P(d_heap), P(d_pverts),
+                                              P(d_park), min(n_srv, ntasks), float(self.park_patience),
+                                              C.c_void_p(side.cuda_stream)))
+                cur.wait_stream(side)
+                head = d_park[:16].cpu().numpy().view(np.uint32)      # (synchronises: the launch and its server are over)
+                if int(head[4]):
+                    raise _abi.KimiHipError("kh_heap_server gave up waiting for the path kernel")
+                nparked = int(head[0])
+                if nparked == 0:
+                    return
+                if int(head[5]) != nparked:
+                    raise _abi.KimiHipError("kh_heap_server served %d of %d parked calls" % (int(head[5]), nparked))
+                d_index = d_park[16:16 + nparked].clone()
+                ntasks = nparked
+                self.last_rounds += 1
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
@@ -557,31 +603,6 @@ class Engine:
                                    sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
                                    consume=sink, scratch_scale=scratch_scale * 8)
 
-        if consume is not None and 0 < n_large < nl:
-            # The largest labels are the tail of the run.  They go to a second stream (as large-LDS workgroups); the
-            # rest runs on the caller's stream and its results are copied back and handed to `consume` (the Skeleton
-            # assembly on the host) while the big labels are still being traced.
-            cur = t.cuda.current_stream(self.device)
-            if self._side is None:
-                self._side = t.cuda.Stream(device=self.device)
-            self._side.wait_stream(cur)
-            launch(0, n_large, C.c_void_p(self._side.cuda_stream))
-            try:
-                launch(n_large, nl - n_large, st)
-                small = collect(n_large, nl)
-                consume(small)                  # overlaps the big labels' kernel: no device-wide sync in here
-            finally:
-                cur.wait_stream(self._side)     # the scratch of this call must outlive the side stream's kernel
-                if sys.exc_info()[0] is not None:
-                    self._side.synchronize()
-            big = collect(0, n_large)
-            mark("paths")
-            consume(big)
-            mark("d2h")
-            tasks_done = np.concatenate([big["tasks"], small["tasks"]])
-            run_retry(consume)
-            LAST_TASKS = tasks_done
-            return None
         launch(0, nl, st)
         mark("paths")
         res = collect(0, nl)

@@ -136,6 +136,21 @@ def compute_pdrf(dbf_max, pdrf_scale, pdrf_exponent, DBF, DAF, max_daf):
     f = np.float32
     M = f(1 / (f(dbf_max) ** 1.01))  # numpy scalar arithmetic, as trace.py:336
     assert DBF.flags.f_contiguous and DAF.flags.f_contiguous
+    e = pdrf_exponent
+    if not (int(e) == e and int(e) > 0 and (int(e) & (int(e) - 1)) == 0 and e < 2 ** 16):
+        # trace.py:346-347, the np.power branch.  numpy's float32 power is the host's (glibc powf or a SIMD kernel,
+        # by CPU features) and differs from C's powf in the last bit on ~10 % of the elements, so the restatement is
+        # numpy's own call, statement for statement (ko_pdrf's powf line is kept for reference only).
+        with np.errstate(all="ignore"):
+            out = np.empty(DBF.shape, dtype=np.float32, order="F")
+            np.multiply(DBF, M, out=out)
+            np.subtract(f(1), out, out=out)
+            np.power(out, e, out=out)
+            out *= f(pdrf_scale)
+            if max_daf != 0:
+                DAF *= (1 / f(max_daf))
+                out += DAF
+        return np.asfortranarray(out)
     out = np.empty(DBF.shape, dtype=np.float32, order="F")
     _check(lib().ko_pdrf(_p(DBF), _p(DAF), DBF.size, M, int(pdrf_exponent),
                          f(pdrf_scale), f(max_daf), _p(out)))

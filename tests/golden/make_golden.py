@@ -204,7 +204,7 @@ def gen_pdrf(trace):
     rng = np.random.default_rng(11)
     cases = {}
     n = 0
-    for expo in (1, 2, 4, 16):
+    for expo in (1, 2, 4, 16, 3, 5):        # 3, 5: the np.power branch (trace.py:346-347); appended, so the first 16 cases stay as they were
         for scale in (5000, 100000):
             for zero_daf in (False, True):
                 shape = (9, 7, 5)
@@ -536,6 +536,10 @@ if __name__ == "__main__" and "post" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
     gen_post(st)
+elif __name__ == "__main__" and "pdrf" in sys.argv[1:]:
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    gen_pdrf(load_reference_trace(st))
 elif __name__ == "__main__" and "legacy" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"

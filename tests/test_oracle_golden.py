@@ -98,7 +98,14 @@ def test_pdrf_golden():
         daf = np.asfortranarray(z["daf_in_%d" % i].reshape(shape, order="F")).copy(order="F")
         dbf_max, scale, expo, max_daf = z["par_%d" % i]
         out = K.compute_pdrf(np.float32(dbf_max), scale, int(expo), dbf, daf, np.float32(max_daf))
-        np.testing.assert_array_equal(out.ravel(order="F"), z["out_%d" % i], err_msg="case %d" % i)
+        if int(expo) & (int(expo) - 1):
+            # np.power branch: numpy's float32 power depends on the CPU's SIMD level -- bit exact where the vectors were
+            # made, 1e-6 relative elsewhere
+            fin = np.isfinite(z["out_%d" % i])
+            np.testing.assert_array_equal(np.isfinite(out.ravel(order="F")), fin)
+            np.testing.assert_allclose(out.ravel(order="F")[fin], z["out_%d" % i][fin], rtol=1e-6, err_msg="case %d" % i)
+        else:
+            np.testing.assert_array_equal(out.ravel(order="F"), z["out_%d" % i], err_msg="case %d" % i)
         np.testing.assert_array_equal(daf.ravel(order="F"), z["daf_out_%d" % i])  # DAF is mutated
 
 

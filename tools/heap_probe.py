@@ -34,5 +34,9 @@ for sweep in ((False, True) if "--both" in sys.argv else (False,)):
     if pops[i]:
         print("  worst label: %.2f ticks / pop, %.0f cycles / pop+push pair, %.0f cycles / tick (upper bound: all of inval)" % (
             ticks[i] / pops[i], tot[i] * 1024 / max(pushes[i], 1), tot[i] * 1024 / max(ticks[i], 1)))
+    srv = tk["cyc_fire"].astype(np.int64) * 1024
+    j = int(np.argmax(srv))
+    print("  rounds %d; heap-server cycles: total %.1f G, worst label %.3f G (%d voxels, %d pushes -> %.0f cycles / pair)" % (
+        eng.last_rounds, srv.sum() / 1e9, srv[j] / 1e9, tk["count"][j], pushes[j], srv[j] / max(pushes[j], 1)))
     print("  all labels: pushes %d, ticks %d, pops %d, inval %.1f Gcyc, heap calls via sweep bails %d" % (
         pushes.sum(), ticks.sum(), pops.sum(), tot.sum() * 1024 / 1e9, int(tk["stat_sweep_bails"].sum())))
