@@ -231,8 +231,10 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
  * they arrive and run the invalidation call they parked at as the exact emulation of std::priority_queue
  * (dijkstra_invalidation.hpp:239-332), one wave per call; a label's park_phase goes from 1 / 2 to 3 / 4 and park_count
  * receives the number of voxels invalidated.  Launch it on ANOTHER stream than the kh_trace_paths call it serves, before or
- * after it: it ends when that call's workgroups have all ended and the queue is drained, or -- never hang the GPU -- after
- * patience_seconds of waiting (word 4 of the record is set then).  Arguments as for kh_trace_paths.          */
+ * after it: a server workgroup ends when that call's workgroups have all ended and the queue is drained, or when it has
+ * been idle for patience_seconds (word 4 of the record counts those; idle servers must never starve the path kernel they
+ * wait for).  A label left parked (park_phase 1 / 2) is served by calling kh_heap_server on a record whose queue lists it
+ * and whose word 3 (path workgroups of the launch) is 0.  Arguments as for kh_trace_paths.                       */
 int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz,
                    float wx, float wy, float wz, const float* dbf, uint8_t* alive, float scale, float constant,
                    void* heap_nodes, uint32_t* path_vertices, uint32_t* park, int64_t nblocks,

@@ -324,12 +324,14 @@ typedef uint32_t hnode_t __attribute__((ext_vector_type(4)));
 // LDS pointers keep their address space in the type, so LDS and HBM accesses can never be merged into flat_* ones
 typedef __attribute__((address_space(3))) hnode_t lds_hnode_t;
 
-// Heap slots 0..TOP-1 (levels 0..10) live in LDS and nowhere else -- the bytes the sweep's level words use while it
-// runs; slots >= TOP live in the label's slice of HBM scratch (L2 resident in practice).
+// Heap slots 0..TOP-1 live in LDS and nowhere else, slots >= TOP in the label's slice of HBM scratch (L2 resident in
+// practice).  TOPL = 1: levels 0..10 (32 KiB: the bytes the sweep's level words use while it runs) for the heap that runs
+// inside a path workgroup; TOPL = 0: levels 0..8 (8 KiB) for the heap server, whose workgroups sit beside the path
+// kernel's on the same CUs -- a thousand idle servers with 32 KiB each would leave the path kernel no LDS to start in.
 template <int TOPL_>
 struct Heap {
   static constexpr int TOPL = TOPL_;
-  static constexpr uint32_t TOP = 2047u;
+  static constexpr uint32_t TOP = TOPL_ ? 2047u : 511u;
   hnode_t* node;   // HBM scratch of this label; slots < TOP unused (slot TOP is read as a dummy: capacity > TOP + 1)
   lds_hnode_t* top;  // LDS, TOP + 3 entries
   uint32_t cap, n;
@@ -528,7 +530,8 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
                                     float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3) {
   const int lane = threadIdx.x & 63;
-  unsigned long long n_ticks = 0, n_pops = 0, n_stall = 0;
+  unsigned long long n_ticks = 0, n_pops = 0, n_stall = 0, n_deep = 0, c_tick = 0, c_push = 0, c_all = 0, tt = 0;
+  const unsigned long long t_begin = PROF ? clock64() : 0ull;
   h.n = 0;
   uint32_t npush = 0;
   bool ovf = false;
@@ -643,6 +646,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
         const bool busy = h.n < 64u ? A != 0ull
                                     : ballot64(act && (!p.hv || pipe_on_chain_range(p.pos, lane, h.n, h.n + cnt - 1u))) != 0ull;
         if (!busy) {
+          if (PROF) tt = clock64();
           // The pushes of one fired voxel go to consecutive leaves, in direction order.  About three quarters of them do
           // not climb (measured: 76 % on the largest label of the bench volume): such a push writes its own leaf and
           // nothing else, and whether it climbs depends on its parent only.  So every pending lane looks at the parent
@@ -690,21 +694,29 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
           // the root may be one of the new nodes now
           root = h.top[0];
           root_live = __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (PROF) c_push += clock64() - tt;
         } else if (PROF) n_stall++;
       }
     }
     if (!A) continue;
-    if (PROF) n_ticks++;
+    if (PROF) { n_ticks++; tt = clock64(); }
     // does this tick touch a slot outside LDS?  (children of the holes, the slots of the values still to be fetched)
     const bool deep = ballot64(p.pos != PIPE_NONE && (2u * p.pos + 2u >= H::TOP || (!p.hv && p.plen >= H::TOP))) != 0ull;
     const bool moved = deep ? heap_pipe_tick<true>(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root)
                             : heap_pipe_tick<false>(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root);
     if (moved) root_live = __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PROF) { c_tick += clock64() - tt; n_deep += deep ? 1u : 0u; }
   }
   if (lane == 0) {
     if (ovf) atomicOr(status, KH_ST_HEAP_OVERFLOW);
     *pushes += npush;
-    if (PROF) { cyc3[0] += n_ticks; cyc3[1] += n_pops; cyc3[2] += n_stall; }
+    if (PROF) {
+      cyc3[0] += n_ticks; cyc3[1] += n_pops; cyc3[2] += n_stall;
+      c_all = clock64() - t_begin;
+      if (blockIdx.x == 0 && npush > 100000u)   // developer probe: the flood of the launch's first (= largest) label
+        printf("HEAPPROF pushes=%u pops=%llu ticks=%llu deep=%llu stall_iters=%llu cycles: all=%llu tick=%llu push=%llu\n", npush, n_pops,
+               n_ticks, n_deep, n_stall, c_all, c_tick, c_push);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   return count;
@@ -835,7 +847,7 @@ struct ParkCtl {
   uint32_t q_taken;     // tickets handed out (server)
   uint32_t t_done;      // path workgroups that have ended
   uint32_t t_total;     // ... of this launch (host)
-  uint32_t error;       // server: 1 = gave up waiting (a path kernel that never ends: cannot happen, but never hang the GPU)
+  uint32_t error;       // server: workgroups that left because they were idle for too long
   uint32_t served;      // server: calls done (diagnostic)
   uint32_t pad[10];
   // uint32_t queue[] follows (64 bytes in)
@@ -1216,8 +1228,10 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
 
 // The heap server: 64-thread workgroups that take parked labels (tickets in queue order) and run the invalidation call they
 // parked at on the exact heap (invalidate_ball: the pop pipeline).  A workgroup with a ticket beyond the queue's end waits
-// for the entry to appear -- or for the path kernel to be over (t_done == t_total; q_count is final then, because a path
-// workgroup publishes its entry before it counts itself done).  The wait is bounded (wall clock): never hang the GPU.
+// for the entry to appear -- or for the path kernel to be over (t_done == t_total; the queue is final then, because a path
+// workgroup publishes its entry before it counts itself done) -- or until it has been idle for `patience` (wall clock): it
+// then leaves, so that idle servers can never starve the path kernel they are waiting for (word 4 counts such exits; the
+// host serves what they left behind with a launch that has no path kernel beside it: t_total = 0).
 template <int TOPL>
 __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, const uint32_t* __restrict__ nbrmask, Geometry g,
                                                          const float* __restrict__ dbf, uint8_t* alive, float scale,
@@ -1232,11 +1246,11 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
   const int lane = threadIdx.x;
   if (lane == 0) geo = g;
   __syncthreads();
-  const unsigned long long t_start = wall_clock64();
   for (;;) {
     if (lane == 0) {
       const uint32_t ticket = atomicAdd(&park->q_taken, 1u);
-      uint32_t go = 2;                                    // 1: entry readable, 0: nothing will come, 2: keep waiting
+      const unsigned long long t_start = wall_clock64();
+      uint32_t go = 2;                                    // 1: entry readable, 0: leave, 2: keep waiting
       while (go == 2) {
         if (__hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu) { go = 1; break; }
         if (__hip_atomic_load(&park->t_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >=
@@ -1245,7 +1259,9 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
           go = __hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu ? 1u : 0u;
           break;
         }
-        if (wall_clock64() - t_start > patience) { atomicOr(&park->error, 1u); go = 0; break; }
+        // idle for too long: leave (the slot, the registers and the LDS go back to the path kernel).  A label that parks
+        // at this ticket later is found unserved by the host and served by a launch of its own.
+        if (wall_clock64() - t_start > patience) { atomicAdd(&park->error, 1u); go = 0; break; }
         __builtin_amdgcn_s_sleep(32);
       }
       sh_ticket = ticket;
@@ -1559,11 +1575,11 @@ extern "C" int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_
   }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
-  const size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
-  KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&heap_server_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  const size_t lds = (size_t)(Heap<0>::TOP + 3) * sizeof(hnode_t);
+  KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&heap_server_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
   const unsigned long long patience = (unsigned long long)(patience_seconds * 1e8);   // wall_clock64 ticks at 100 MHz
-  hipLaunchKernelGGL((heap_server_kernel<1>), dim3((unsigned)nblocks), dim3(64), lds, (hipStream_t)stream, tasks, nbrmask, g, dbf,
+  hipLaunchKernelGGL((heap_server_kernel<0>), dim3((unsigned)nblocks), dim3(64), lds, (hipStream_t)stream, tasks, nbrmask, g, dbf,
                      alive, scale, constant, (hnode_t*)heap_nodes, path_vertices, park, patience);
   KH_LAUNCH_CHECK();
   return KH_OK;

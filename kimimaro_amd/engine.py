@@ -64,8 +64,9 @@ class Engine:
         # path kernel instead of one busy wave inside a 256-thread path workgroup.  False: the heap runs in place.
         self.park = os.environ.get("KH_PARK", "1") != "0"
         self.park_servers = int(os.environ.get("KH_PARK_SERVERS", "256"))   # server workgroups per launch (one wave each)
-        self.park_patience = 60.0          # seconds a server waits for a path kernel that never ends before giving up
+        self.park_patience = 3.0           # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
         self.last_rounds = 0                # launches of the path kernel the last run_labels call needed
+        self.sweep_force_bail = False       # tests: every call of the sweep bails at once (radius limit 0) -> every call parks
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
@@ -423,7 +424,7 @@ class Engine:
                 if ev_total >= 2 ** 32:
                     raise ValueError("kimimaro_amd: event arena offsets exceed 32 bits; shard the labels")
                 tasks["nlev"] = nlev
-                tasks["sweep_rmax"] = np.where(ok, rmax_t, 0).astype(np.float32)
+                tasks["sweep_rmax"] = np.where(ok, rmax_t if not self.sweep_force_bail else 0.0, 0).astype(np.float32)
                 tasks["ev_offset"] = ev_off
                 tasks["ev_chunks"] = np.where(nlev > 0, chunks, 0)
                 tasks["ev_shift"] = shift
@@ -545,14 +546,24 @@ class Engine:
                                               C.c_void_p(side.cuda_stream)))
                 cur.wait_stream(side)
                 head = d_park[:16].cpu().numpy().view(np.uint32)      # (synchronises: the launch and its server are over)
-                if int(head[4]):
-                    raise _abi.KimiHipError("kh_heap_server gave up waiting for the path kernel")
                 nparked = int(head[0])
                 if nparked == 0:
                     return
-                if int(head[5]) != nparked:
-                    raise _abi.KimiHipError("kh_heap_server served %d of %d parked calls" % (int(head[5]), nparked))
                 d_index = d_park[16:16 + nparked].clone()
+                if int(head[5]) != nparked:
+                    # servers that had been idle for too long left before these labels parked: serve them now (t_total = 0)
+                    phase_at = (d_index.to(t.int64) * (isz // 4) + _abi.LABEL_T.fields["park_phase"][1] // 4)
+                    phases = d_tasks[first * isz:].view(t.int32)[phase_at].cpu().numpy()
+                    left = d_index[t.from_numpy(np.flatnonzero(phases <= 2)).to(self.device)]
+                    hdr[3] = 0
+                    hdr[0] = int(left.numel())
+                    d_park[:16].copy_(t.from_numpy(hdr))
+                    d_park[16:].fill_(-1)
+                    d_park[16:16 + left.numel()] = left
+                    _abi.check(lib.kh_heap_server(tasks_ptr, P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_alive),
+                                                  np.float32(params["scale"]), np.float32(params["const"]), P(d_heap), P(d_pverts),
+                                                  P(d_park), min(max(n_srv, 64), int(left.numel())), float(self.park_patience), stream))
+                    hdr[0] = 0
                 ntasks = nparked
                 self.last_rounds += 1
 

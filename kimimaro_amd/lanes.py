@@ -64,6 +64,11 @@ class Lanes:
             def stream_factory(eng):
                 return _StreamScope(torch, eng)
         self.engines = [engine_factory() for _ in range(self.width)]
+        for e in self.engines:
+            # heap-server workgroups per launch (csrc/trace.hip "parking"): about a thousand on the GPU over all lanes -- each
+            # holds 8 KiB of LDS on a CU that path workgroups (38 KiB each) share
+            if hasattr(e, "park_servers"):
+                e.park_servers = max(32, min(e.park_servers, 1024 // self.width))
         self._scopes = [stream_factory(e) if stream_factory is not None else None for e in self.engines]
 
     def run(self, job, n, width=None, stagger=0.0):
