@@ -311,33 +311,60 @@ __global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int 
 //           a ballot gives the climb length and the lanes shift the chain down in one step.
 //   pop   = __pop_heap/__adjust_heap: libstdc++ walks the hole to a leaf along the smaller child
 //           (ties: left) and then pushes the last element up again.  Because keys never decrease
-//           from parent to child this lands exactly where the early-exit sift-down lands ("move the
-//           smaller child up while its key < last.key"; tests/experiments/systolic_heap_sim.c runs the
-//           literal libstdc++ form, the early-exit form and the pipeline below side by side).
+//           from parent to child this lands exactly where the text-book early-exit sift-down lands
+//           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
+//           per memory round trip: 126 speculative child nodes are fetched by the 64 lanes, the path
+//           is resolved from registers, and the nodes on it are moved up in one parallel step.
 // Nodes are 16-byte records {key bits, voxel, source voxel, max_dist bits} -- the reference's HeapDistanceNode
-// (dijkstra_invalidation.hpp:210-231) field for field -- so a node is one dwordx4 load or store and a live pop needs
-// no look-up of its source.  Keys are non-negative floats compared as their bit patterns (unsigned).
-//
-// Round 3: pops are PIPELINED through the lanes of the wave (heap_pipe below) instead of running one after the other.
+// (dijkstra_invalidation.hpp:210-231) field for field (round 3; before: {key, voxel, source index, -}, which cost a live pop
+// two dependent look-ups, path[index] and dbf[source]) -- in the label's slice of HBM scratch, so a node is one dwordx4
+// load or store.  Keys are non-negative floats: they are compared as their bit
+// patterns (unsigned), which lets "ties go left" be written as k < sibling + (1 on left lanes).
+// A write-through LDS mirror of heap levels 0-12 was tried twice and measured 10-15 % SLOWER: the pop is
+// bound by instruction issue of its single wave more than by memory latency.
 // a native LLVM vector (HIP's uint4 is a struct around a union, which ends up in scratch memory here)
 typedef uint32_t hnode_t __attribute__((ext_vector_type(4)));
 // LDS pointers keep their address space in the type, so LDS and HBM accesses can never be merged into flat_* ones
 typedef __attribute__((address_space(3))) hnode_t lds_hnode_t;
 
-// Heap slots 0..TOP-1 live in LDS and nowhere else, slots >= TOP in the label's slice of HBM scratch (L2 resident in
-// practice).  TOPL = 1: levels 0..10 (32 KiB: the bytes the sweep's level words use while it runs) for the heap that runs
-// inside a path workgroup; TOPL = 0: levels 0..8 (8 KiB) for the heap server, whose workgroups sit beside the path
-// kernel's on the same CUs -- a thousand idle servers with 32 KiB each would leave the path kernel no LDS to start in.
+// Heap slots 0..TOP-1 live in LDS and nowhere else; slots >= TOP live in the label's slice of HBM scratch.
+// TOPL = 1: the root and the first 6-level chunk under it (127 slots, 2 KiB) -- every label affords that.
+// TOPL = 2: two chunks (8191 slots, 128 KiB): one such workgroup fits on a CU, so it is reserved for the few
+// largest labels, whose sequential chain is the critical path of the whole launch.  Every pop starts in the
+// LDS part, so the top read and the first TOPL chunks cost LDS round trips instead of L2 ones.
 template <int TOPL_>
 struct Heap {
   static constexpr int TOPL = TOPL_;
-  static constexpr uint32_t TOP = TOPL_ ? 2047u : 511u;
-  hnode_t* node;   // HBM scratch of this label; slots < TOP unused (slot TOP is read as a dummy: capacity > TOP + 1)
-  lds_hnode_t* top;  // LDS, TOP + 3 entries
+  static constexpr uint32_t TOP = TOPL_ == 1 ? 127u : 8191u;
+  hnode_t* node;   // HBM scratch of this label (L2 resident in practice); slots < TOP unused
+  lds_hnode_t* top;  // LDS, TOP + 3 entries (the last LDS chunk's lanes 62/63 read two slots past the end)
   uint32_t cap, n;
+  // per-lane constants of the 126-node speculative sub-tree (children of node m: 2m+2, 2m+3; parent of
+  // m >= 2: (m-2)>>1).  Lane l holds node m = l ("slot 0", depths 1..6) and m = l+64 ("slot 1", depth 6).
+  unsigned long long am0, am1;  // slot-0 ballot bits of the node's ancestors (am0 including itself)
+  uint32_t sh0, j0, j1;         // heap index of my slot-0 node = ((hole+1) << sh0) - 1 + j0, slot 1: << 6, + j1
+  uint32_t lf;                  // 1 on even lanes (left children), 0 on odd lanes
 };
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// value of lane l^1 (the sibling node): DPP quad_perm [1,0,3,2], no LDS crossbar round trip
+__device__ __forceinline__ uint32_t sibling_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+template <class H>
+__device__ __forceinline__ void heap_init_lane(H& h, int lane) {
+  unsigned long long a0 = 0, a1 = 0;
+  for (int m = lane; ; m = (m - 2) >> 1) { a0 |= 1ull << m; if (m < 2) break; }
+  if (lane + 64 < 126) for (int m = (lane + 62) >> 1; ; m = (m - 2) >> 1) { a1 |= 1ull << m; if (m < 2) break; }
+  h.am0 = a0;
+  h.am1 = a1;
+  const int d0 = 31 - __clz(lane + 2);
+  h.sh0 = (uint32_t)d0;
+  h.j0 = (uint32_t)(lane + 2 - (1 << d0));
+  h.j1 = (uint32_t)(lane + 2);
+  h.lf = (lane & 1) ? 0u : 1u;
+}
 
 // all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
 // the whole node of ancestor generation g+1 (from LDS or HBM, whichever holds that slot), a ballot gives
@@ -373,165 +400,89 @@ __device__ __forceinline__ bool heap_push_wave(H& h, const hnode_t fresh, int la
   return true;
 }
 
-// ---- the pop pipeline ---------------------------------------------------------------------------------------------
-// A pop of the reference = take the last element `val`, walk a hole from the root down the smaller child (ties: left)
-// while that child's key < val.key, drop val into the hole.  About 90 % of the pops of a flood are stale (the voxel is
-// dead already) and do nothing else, so a flood is mostly back-to-back sift-downs of 10-17 levels: a chain of dependent
-// round trips when run one after the other (2.4 k cycles per pop in round 2).  Here lane l of the wave owns the hole of
-// ONE in-flight pop at heap level l; a TICK moves every hole down one level at once -- read phase (each lane loads the
-// two children of its hole), decision, write phase (the chosen child, or val, goes into the hole), then the whole state
-// shifts one lane up (DPP wave_shr:1).  A new pop enters lane 0 when lanes 0 and 1 are empty: the pop before it is then
-// at least two levels ahead, so everything the new one reads was written in an earlier tick (the only read-after-write
-// dependence between consecutive pops).  One pop completes every ~2.1 ticks instead of every ~17 round trips.
-// Exactness: the pipeline executes the same comparisons on the same array contents as the sequential order does --
-// operations are only overlapped when their read / write sets are disjoint:
-//   I1  injection needs lanes 0, 1 empty (above).
-//   I2  An in-flight hole h only ever touches the sub-tree under h.  So an operation that touches slot set S may start
-//       as long as no in-flight hole is an ancestor-or-self of a slot of S.  Applied to the pushes of a live pop
-//       (S = the new leaves with their ancestor chains: the climb never leaves those chains) -- they wait a tick or
-//       two instead of draining the pipe -- and to a pop's `last` element:
-//   I3  a pop needs val = H[its last slot] as the SEQUENTIAL order would see it, i.e. after every older pop.  An older
-//       hole on the ancestor chain of that slot may still end there.  Waiting at the door for that costs 0.7 ticks per
-//       pop (the hole two levels down is an ancestor of any given slot with probability 1/4, ...), so the pop enters
-//       WITHOUT its value: it fetches it in the first tick in which no older hole is on the slot's chain (then final).
-//       Until then its stop test "child.key >= val.key" is replaced by a floor: every candidate for val -- the slot's
-//       current content or the value of an older in-flight pop -- has a key >= kfl, so child.key < kfl means
-//       "continue" whatever val turns out to be; if that is not the case the pop FREEZES for the tick together with
-//       everything younger (the lanes below it), the older pops go on and settle the question.  kfl = the smallest
-//       key any last slot held over the last >= 32 injections (two scalar accumulators taking turns: at most 16 pops
-//       are in flight, and a pop's value is the content its slot had at its injection or an older pop's value).
-//       New leaves are not written while a val-less pop is in flight (its slot lies above the heap's end).
-// tests/experiments/systolic_heap_sim.c is this machine lane for lane on the CPU, checked against libstdc++'s
-// __adjust_heap / __push_heap on 64 floods (pop sequence and final masks identical; 2.11 ticks per pop at 90 k nodes).
-static constexpr uint32_t PIPE_NONE = 0xFFFFFFFFu;
-struct HeapPipe {
-  uint32_t pos;     // hole of this lane's pop (heap slot at level == lane), PIPE_NONE = lane empty
-  uint32_t plen;    // its array length = the slot its value comes from
-  uint32_t vk;      // val.key, or the floor kfl while the value is missing
-  uint32_t vv, vs, vm;   // rest of val
-  uint32_t hv;      // 1: value present
-};
-
-// lane l gets the value of lane l - 1, lane 0 gets `first` (DPP wave_shr:1: no LDS crossbar round trip)
-__device__ __forceinline__ uint32_t lane_up(uint32_t v, uint32_t first) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false);
-}
-// is the hole `pos` of lane `lane` (heap level == lane) an ancestor of, or equal to, slot s?  (s, Ls = level of s: uniform)
-__device__ __forceinline__ bool pipe_on_chain(uint32_t pos, int lane, uint32_t s, int Ls) {
-  const int d = Ls - lane;
-  return d >= 0 && (((s + 1u) >> (d > 0 ? d : 0)) == pos + 1u);
-}
-// ... of a slot of [a, b] (a >= 63, b - a < 64: the range spans at most two levels)
-__device__ __forceinline__ bool pipe_on_chain_range(uint32_t pos, int lane, uint32_t a, uint32_t b) {
-  const int La = 31 - __clz((int)(a + 1u));
-  const uint32_t e = (2u << La) - 2u;                 // last slot of a's level
-  const uint32_t b1 = b < e ? b : e;
-  const int d1 = La - lane, s1 = d1 > 0 ? d1 : 0;
-  const uint32_t p1 = pos + 1u;
-  bool c = d1 >= 0 && p1 >= ((a + 1u) >> s1) && p1 <= ((b1 + 1u) >> s1);
-  if (b > e) {
-    const int d2 = La + 1 - lane, s2 = d2 > 0 ? d2 : 0;
-    c = c || (d2 >= 0 && p1 >= ((e + 2u) >> s2) && p1 <= ((b + 1u) >> s2));
+// removes the top; precondition h.n > 0.  libstdc++'s __adjust_heap walks the hole to a leaf along the
+// smaller child (ties: left) and then pushes the former last element up again; the result is: the path
+// nodes with key < last.key move up one level and `last` takes the slot of the deepest of them.
+// The wave fetches 6 levels (126 whole nodes, 2 per lane) per round trip.  A node is on the path iff it
+// and all its ancestors in the sub-tree beat their siblings: one sibling compare per lane, one ballot,
+// one mask test against the lane's constant ancestor mask.  The chunks nest (chunk c+1 runs inside
+// chunk c, which keeps its two nodes in registers) and every write is issued on the way back up, so the
+// load of `last` overlaps the whole descent.  Loads are unconditional (index clamped, key masked
+// to +inf): no divergent branches in the descent.  Chunk 0 is exactly the LDS part of the heap.
+// 32-bit index math is safe: the hole of chunk c sits at level 6c <= 24, so (hole+1) << 6 < 2^31.
+#define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
+template <int C, class H>
+__device__ __forceinline__ void heap_pop_chunk(const H& h, uint32_t hole, uint32_t len, uint32_t vk, int lane,
+                                               uint32_t& deepest, bool& found) {
+  const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
+  const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
+  const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
+  hnode_t n0, n1;
+  if constexpr (C < H::TOPL) { n0 = h.top[i0]; n1 = h.top[i1]; }   // an LDS chunk: i0, i1 < TOP + 3 by construction
+  else { n0 = h.node[e0 ? i0 : H::TOP]; n1 = h.node[e1 ? i1 : H::TOP]; }
+  const uint32_t k0 = e0 ? n0.x : INF_BITS, k1 = e1 ? n1.x : INF_BITS;
+  // a node beats its sibling if it is the left one and left.key <= right.key, or the right one and
+  // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
+  const bool w0 = e0 & (k0 < sibling_u32(k0) + h.lf);
+  const bool w1 = e1 & (k1 < sibling_u32(k1) + h.lf);
+  const unsigned long long W0 = ballot64(w0);
+  const bool on0 = (W0 & h.am0) == h.am0;
+  const bool on1 = w1 && ((W0 & h.am1) == h.am1);
+  if constexpr (C + 1 < KH_POP_CHUNKS) {
+    // next hole = the depth-6 node of the path, if the path got that deep and that node has children
+    const unsigned long long P0 = ballot64(on0), P1 = ballot64(on1);
+    uint32_t nh = 0;
+    if (P1) nh = rdlane_u32(i1, __ffsll((long long)P1) - 1);
+    else if (P0 >> 62) nh = rdlane_u32(i0, (P0 >> 63) ? 63 : 62);
+    if (nh != 0u && 2u * nh + 1u < len) heap_pop_chunk<C + 1, H>(h, nh, len, vk, lane, deepest, found);
   }
-  return c;
-}
-
-// One tick.  `A` = ballot of the occupied lanes (non-zero).  Returns true when lane 0's pop moved on (the root of the heap
-// was rewritten: *root receives its new content).
-// DEEP = false: every slot the tick touches is in LDS (no HBM instruction is issued at all: a small flood never pays an L2
-// round trip per tick).  DEEP = true: the HBM loads are issued for every lane, the ones that do not need them read the dummy
-// slot TOP -- no data-dependent branch between the loads, so all of them (LDS and HBM) are in flight before the first wait.
-template <bool DEEP, class H>
-__device__ __forceinline__ bool heap_pipe_tick(H& h, HeapPipe& p, int lane, unsigned long long A, bool fresh0,
-                                               uint32_t& ep_cur, uint32_t& ep_prev, uint32_t& ep_count, hnode_t& root) {
-  const bool act = p.pos != PIPE_NONE;
-  // ---- I3: which val-less pops can fetch their value now (no OLDER hole on the chain of their slot)?
-  unsigned long long fetch = 0;
-  for (unsigned long long vl = ballot64(act && !p.hv); vl; vl &= vl - 1ull) {
-    const int l = __ffsll((long long)vl) - 1;
-    const uint32_t s = rdlane_u32(p.plen, l);
-    const int Ls = 31 - __clz((int)(s + 1u));
-    const unsigned long long older = ~0ull << l << 1;                 // lanes > l (l <= 31 always)
-    if (!(ballot64(act && pipe_on_chain(p.pos, lane, s, Ls)) & older)) fetch |= 1ull << l;
-  }
-  const bool mine = (fetch >> lane) & 1ull;
-  const bool cand = mine || (fresh0 && lane == 0);      // the fresh pop reads its slot either way: value or floor candidate
-  // ---- read phase: every load of the tick is issued before the first one is waited for (one round trip per tick: a
-  // first version that initialised the HBM results with the LDS ones waited four times, 2.5 k cycles per tick)
-  const uint32_t c0 = 2u * p.pos + 1u;
-  const bool hasL = act && c0 < p.plen, hasR = act && c0 + 1u < p.plen;
-  const bool lo = !DEEP || c0 < H::TOP;                 // siblings c0 (odd), c0 + 1 share the memory space
-  const bool vlo = !DEEP || p.plen < H::TOP;
-  const uint32_t il = hasL && lo ? c0 : 0u;
-  const uint32_t iv = cand && vlo ? p.plen : 0u;
-  const hnode_t Ll = h.top[il], Rl = h.top[il + 1u], Vl = h.top[iv];
-  hnode_t L = Ll, R = Rl, V = Vl;
-  if constexpr (DEEP) {
-    const uint32_t ig = hasL && !lo ? c0 : H::TOP;
-    const hnode_t Lg = h.node[ig], Rg = h.node[ig + 1u], Vg = h.node[cand && !vlo ? p.plen : H::TOP];
-    L = lo ? Ll : Lg; R = lo ? Rl : Rg; V = vlo ? Vl : Vg;
-  }
-  // ---- values and floors
-  if (fresh0) {                                          // wave uniform
-    const uint32_t ck = rdlane_u32(V.x, 0);              // what the fresh pop's slot holds now
-    if (++ep_count == 32u) { ep_count = 0u; ep_prev = ep_cur; ep_cur = 0xFFFFFFFFu; }
-    ep_cur = ck < ep_cur ? ck : ep_cur;
-    if (lane == 0 && !mine) p.vk = ep_cur < ep_prev ? ep_cur : ep_prev;
-  }
-  if (mine) { p.vk = V.x; p.vv = V.y; p.vs = V.z; p.vm = V.w; p.hv = 1u; }
-  // ---- decision
-  const uint32_t kL = hasL ? L.x : INF_BITS, kR = hasR ? R.x : INF_BITS;
-  const bool pickR = kR < kL;                            // comp(right, left): ties go left
-  const hnode_t P = pickR ? R : L;
-  const uint32_t kP = pickR ? kR : kL;
-  const bool past = !hasL || kP >= p.vk;                 // with a value: stop here.  without: cannot be decided
-  const unsigned long long frozen = ballot64(act && !p.hv && past);
-  const int frz = frozen ? 63 - __clzll((long long)frozen) : -1;      // this lane and everything younger waits
-  const bool go = act && lane > frz;
-  const bool stop = past;                                // (lanes > frz that are val-less have past == false)
-  const hnode_t val = {p.vk, p.vv, p.vs, p.vm};
-  const hnode_t W = stop ? val : P;
-  // ---- write phase
-  if (go) {
-    if (!DEEP || p.pos < H::TOP) h.top[p.pos] = W;
-    else h.node[p.pos] = W;
-  }
-  const bool moved0 = (A & 1ull) && frz < 0;
-  if (moved0) { root.x = rdlane_u32(W.x, 0); root.y = rdlane_u32(W.y, 0); root.z = rdlane_u32(W.z, 0); root.w = rdlane_u32(W.w, 0); }
-  // ---- every pop that moved goes one lane up; lanes <= frz keep their state, lane frz + 1 is a bubble
-  const uint32_t np = (go && !stop) ? c0 + (pickR ? 1u : 0u) : PIPE_NONE;
-  HeapPipe q;
-  q.pos = lane_up(np, PIPE_NONE);
-  q.plen = lane_up(p.plen, 0u);
-  q.vk = lane_up(p.vk, 0u);
-  q.vv = lane_up(p.vv, 0u);
-  q.vs = lane_up(p.vs, 0u);
-  q.vm = lane_up(p.vm, 0u);
-  q.hv = lane_up(p.hv, 0u);
-  if (frz < 0) {
-    p = q;
+  // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
+  // deepest such node (or the root).  Path keys are non-decreasing with depth.
+  const bool mv0 = on0 && k0 < vk;
+  const bool mv1 = on1 && k1 < vk;
+  const uint32_t q0 = (i0 - 1u) >> 1, q1 = (i1 - 1u) >> 1;
+  if constexpr (C < H::TOPL) {
+    if (mv0) h.top[q0] = n0;
+    if (mv1) h.top[q1] = n1;
+  } else if constexpr (C == H::TOPL) {
+    // the parent of this chunk's two depth-1 nodes (lanes 0, 1) is the hole: a leaf of the LDS part
+    if (mv0) { if (lane < 2) h.top[hole] = n0; else h.node[q0] = n0; }
+    if (mv1) h.node[q1] = n1;
   } else {
-    const bool take = lane > frz + 1;
-    p.pos = take ? q.pos : (lane == frz + 1 ? PIPE_NONE : p.pos);
-    p.plen = take ? q.plen : p.plen;
-    p.vk = take ? q.vk : p.vk;
-    p.vv = take ? q.vv : p.vv;
-    p.vs = take ? q.vs : p.vs;
-    p.vm = take ? q.vm : p.vm;
-    p.hv = take ? q.hv : p.hv;
+    if (mv0) h.node[q0] = n0;
+    if (mv1) h.node[q1] = n1;
   }
-  return moved0;
+  if (!found) {
+    const unsigned long long M0 = ballot64(mv0), M1 = ballot64(mv1);
+    if (M1) { deepest = rdlane_u32(i1, __ffsll((long long)M1) - 1); found = true; }
+    else if (M0) { deepest = rdlane_u32(i0, 63 - __clzll((long long)M0)); found = true; }
+  }
 }
 
-// wave 0 only.  Returns the number of voxels invalidated.  PROF counts ticks / pops (cyc3[0], cyc3[1]).
+template <class H>
+__device__ __forceinline__ void heap_pop_wave(H& h, int lane) {
+  const uint32_t len = h.n - 1u;
+  h.n = len;
+  if (len == 0) return;
+  const hnode_t last = len < H::TOP ? h.top[len] : h.node[len];  // consumed only after the descent
+  uint32_t deepest = 0;
+  bool found = false;
+  if (len > 1u) heap_pop_chunk<0, H>(h, 0u, len, last.x, lane, deepest, found);
+  if (lane == 0) {
+    if (deepest < H::TOP) h.top[deepest] = last;
+    else h.node[deepest] = last;
+  }
+}
+
+// wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
+// cycle split (s_memtime waits on the scalar memory counter, so the production kernel leaves it out).
 template <bool PROF, class H>
 __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                     float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3) {
   const int lane = threadIdx.x & 63;
-  unsigned long long n_ticks = 0, n_pops = 0, n_stall = 0, n_deep = 0, c_tick = 0, c_push = 0, c_all = 0, tt = 0;
-  const unsigned long long t_begin = PROF ? clock64() : 0ull;
+  unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt = 0;
   h.n = 0;
   uint32_t npush = 0;
   bool ovf = false;
@@ -548,175 +499,103 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   int dx, dy, dz;
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
-  HeapPipe p;
-  p.pos = PIPE_NONE; p.plen = 0u; p.vk = 0u; p.vv = 0u; p.vs = 0u; p.vm = 0u; p.hv = 0u;
-  uint32_t ep_cur = 0xFFFFFFFFu, ep_prev = 0xFFFFFFFFu, ep_count = 0u;
-  // the root of the heap and whether its voxel is still alive (loaded as soon as the root is known)
-  hnode_t root = h.top[0];
-  uint8_t root_live = h.n ? __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
-  // a live pop whose pushes are still to come
-  bool firing = false;
-  uint32_t f_vox = 0, f_src = 0, f_maxd = 0, f_nm = 0, f_q = 0;
-  uint8_t f_aq = 0;
-  bool f_ready = false;
-  unsigned long long m = 0;
-  uint32_t ndb = 0;
-  for (;;) {
-    unsigned long long A = ballot64(p.pos != PIPE_NONE);
-    bool fresh0 = false;
-    if (!firing) {
-      if (h.n == 0u) { if (!A) break; }
-      else if (!(A & 3ull)) {                                  // I1
-        const uint32_t s = h.n - 1u;
-        h.n = s;
-        if (PROF) n_pops++;
-        const uint32_t vox = root.y;
-        const bool live = root_live != 0;
-        if (live) {
-          if (lane == 0) alive[vox] = 0;
-          count++;
-          f_vox = vox; f_src = root.z; f_maxd = root.w;
-          // everything the neighbour tests need, in one round trip: the connectivity word and the 26 alive bytes
-          // (addresses clamped by geometry alone, so that they do not depend on the connectivity word)
-          f_nm = nbrmask[vox];
-          const uint32_t z = vox / sxy, r = vox - z * sxy, y = r / sx, x = r - y * sx;
-          bool inside = lane < 26;
-          int ex = dx;
-          if (inside) {
-            const bool xout = (dx < 0 && x == xmin) || (dx > 0 && x == xmax);
-            if (xout) { if (lane >= 18) ex = 0; else inside = false; }
-            const int qx = (int)x + ex, qy = (int)y + dy, qz = (int)z + dz;
-            inside = inside && qx >= 0 && qy >= 0 && qz >= 0 && qx < g.sx && qy < g.sy && qz < g.sz;
-          }
-          f_q = inside ? vox + (uint32_t)(ex + (int)sx * dy + (int)sxy * dz) : vox;
-          f_aq = __hip_atomic_load(&alive[f_q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          firing = true;
-          f_ready = false;
-        }
-        if (s > 0u) {
-          if (lane == 0) { p.pos = 0u; p.plen = s; p.hv = 0u; p.vk = 0u; }
-          fresh0 = true;
-          A |= 1ull;
-        } else {
-          root_live = 0;     // the heap is empty (until the pushes of this pop, which reload the root)
-        }
+  while (h.n > 0) {
+    const hnode_t top = h.top[0];
+    const uint32_t vox = top.y, src = top.z;
+    const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
+    if (PROF) tt = clock64();
+    heap_pop_wave(h, lane);
+    if (PROF) c_pop += clock64() - tt;
+    if (!live) continue;
+    if (PROF) tt = clock64();
+    if (lane == 0) alive[vox] = 0;
+    count++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const float maxd = __uint_as_float(top.w);
+    const uint32_t z = vox / sxy, r = vox - z * sxy, y = r / sx, x = r - y * sx;
+    const uint32_t oz = src / sxy, orr = src - oz * sxy, oy = orr / sx, ox = orr - oy * sx;
+    // neighbour enumeration of dijkstra_invalidation.hpp:60-124 seen from the label's bounding box:
+    // a corner entry (k >= 18) whose x step leaves the box degenerates into the yz diagonal.
+    bool want = false;
+    uint32_t q = 0;
+    float nd = 0.0f;
+    if (lane < 26) {
+      int k = lane;
+      int ex = dx;
+      const bool xout = (dx < 0 && x == xmin) || (dx > 0 && x == xmax);
+      if (xout) {
+        if (lane >= 18) { ex = 0; k = 10 + (dy > 0 ? 2 : 0) + (dz > 0 ? 1 : 0); }
+        else k = -1;
       }
-    } else {
-      if (!f_ready) {
-        // neighbour enumeration of dijkstra_invalidation.hpp:60-124 seen from the label's bounding box:
-        // a corner entry (k >= 18) whose x step leaves the box degenerates into the yz diagonal.
-        const uint32_t vox = f_vox, src = f_src;
-        const float maxd = __uint_as_float(f_maxd);
-        const uint32_t z = vox / sxy, r = vox - z * sxy, y = r / sx, x = r - y * sx;
-        const uint32_t oz = src / sxy, orr = src - oz * sxy, oy = orr / sx, ox = orr - oy * sx;
-        bool want = false;
-        float nd = 0.0f;
-        if (lane < 26) {
-          int k = lane;
-          int ex = dx;
-          const bool xout = (dx < 0 && x == xmin) || (dx > 0 && x == xmax);
-          if (xout) {
-            if (lane >= 18) { ex = 0; k = 10 + (dy > 0 ? 2 : 0) + (dz > 0 ? 1 : 0); }
-            else k = -1;
-          }
-          if (k >= 0 && ((f_nm >> k) & 1u) && f_aq) {
-            const int qx = (int)x + ex, qy = (int)y + dy, qz = (int)z + dz;
-            const float a = g.wx * (float)(qx - (int)ox);
-            const float b = g.wy * (float)(qy - (int)oy);
-            const float c = g.wz * (float)(qz - (int)oz);
-            float s = a * a;
-            const float t = b * b;
-            const float u = c * c;
-            s = s + t;
-            s = s + u;
-            nd = sqrtf(s);
-            want = nd < maxd;
-          }
+      if (k >= 0 && ((nbrmask[vox] >> k) & 1u)) {
+        q = vox + (uint32_t)(ex + (int)sx * dy + (int)sxy * dz);
+        if (alive[q]) {
+          const int qx = (int)x + ex, qy = (int)y + dy, qz = (int)z + dz;
+          const float a = g.wx * (float)(qx - (int)ox);
+          const float b = g.wy * (float)(qy - (int)oy);
+          const float c = g.wz * (float)(qz - (int)oz);
+          float s = a * a;
+          const float t = b * b;
+          const float u = c * c;
+          s = s + t;
+          s = s + u;
+          nd = sqrtf(s);
+          want = nd < maxd;
         }
-        m = ballot64(want);
-        ndb = __float_as_uint(nd);
-        f_ready = true;
-        if (!m) firing = false;
-      }
-      if (firing) {
-        // I2: the new leaves [n, n + cnt) and their ancestor chains must be free of in-flight holes, and no val-less pop
-        // may be in flight (its slot lies at or above n).  A tiny heap (leaves that could be each other's parents) drains.
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        const bool act = p.pos != PIPE_NONE;
-        const bool busy = h.n < 64u ? A != 0ull
-                                    : ballot64(act && (!p.hv || pipe_on_chain_range(p.pos, lane, h.n, h.n + cnt - 1u))) != 0ull;
-        if (!busy) {
-          if (PROF) tt = clock64();
-          // The pushes of one fired voxel go to consecutive leaves, in direction order.  About three quarters of them do
-          // not climb (measured: 76 % on the largest label of the bench volume): such a push writes its own leaf and
-          // nothing else, and whether it climbs depends on its parent only.  So every pending lane looks at the parent
-          // of the leaf it would get, the leading run of non-climbing pushes is appended with one store per lane, the
-          // first climbing one goes through the ordinary push, and the rest is looked at again (its parents may have
-          // changed).  A new leaf is nobody's parent here because the heap is larger than the batch.
-          const hnode_t fresh = {ndb, f_q, f_src, f_maxd};
-          while (m) {
-            const uint32_t base = h.n;
-            const uint32_t pc = (uint32_t)__popcll(m);
-            if (base < 64u || base + pc > h.cap) {   // small heap (new leaves could be parents) or no room: one by one
-              const int k = __ffsll((long long)m) - 1;
-              m &= m - 1;
-              const hnode_t one = {rdlane_u32(ndb, k), rdlane_u32(f_q, k), f_src, f_maxd};
-              if (!heap_push_wave(h, one, lane)) ovf = true;
-              npush++;
-              continue;
-            }
-            const bool mine = (m >> lane) & 1ull;
-            const uint32_t leaf = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const uint32_t par = (leaf - 1u) >> 1;
-            const bool plo = !mine || par < H::TOP;
-            const uint32_t kg = h.node[plo ? H::TOP : par].x;
-            const uint32_t kl = h.top[plo && mine ? par : 0u].x;
-            const bool stay = mine && (plo ? kl : kg) < ndb;          // __push_heap climbs while parent.key >= key
-            const unsigned long long climbers = m & ~ballot64(stay);
-            const int c = climbers ? __ffsll((long long)climbers) - 1 : 64;   // first lane whose push climbs
-            const unsigned long long run = c < 64 ? (m & ((1ull << c) - 1ull)) : m;
-            if ((run >> lane) & 1ull) {
-              if (leaf < H::TOP) h.top[leaf] = fresh;
-              else h.node[leaf] = fresh;
-            }
-            const uint32_t nrun = (uint32_t)__popcll(run);
-            h.n = base + nrun;
-            npush += nrun;
-            m &= ~run;
-            if (c < 64) {
-              m &= ~(1ull << c);
-              const hnode_t one = {rdlane_u32(ndb, c), rdlane_u32(f_q, c), f_src, f_maxd};
-              if (!heap_push_wave(h, one, lane)) ovf = true;
-              npush++;
-            }
-          }
-          firing = false;
-          // the root may be one of the new nodes now
-          root = h.top[0];
-          root_live = __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (PROF) c_push += clock64() - tt;
-        } else if (PROF) n_stall++;
       }
     }
-    if (!A) continue;
-    if (PROF) { n_ticks++; tt = clock64(); }
-    // does this tick touch a slot outside LDS?  (children of the holes, the slots of the values still to be fetched)
-    const bool deep = ballot64(p.pos != PIPE_NONE && (2u * p.pos + 2u >= H::TOP || (!p.hv && p.plen >= H::TOP))) != 0ull;
-    const bool moved = deep ? heap_pipe_tick<true>(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root)
-                            : heap_pipe_tick<false>(h, p, lane, A, fresh0, ep_cur, ep_prev, ep_count, root);
-    if (moved) root_live = __hip_atomic_load(&alive[root.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (PROF) { c_tick += clock64() - tt; n_deep += deep ? 1u : 0u; }
+    unsigned long long m = ballot64(want);
+    if (PROF) { c_fire += clock64() - tt; tt = clock64(); }
+    const uint32_t ndb = __float_as_uint(nd);
+    // The pushes of one fired voxel go to consecutive leaves, in direction order.  About three quarters of them do
+    // not climb (measured: 76 % on the largest label of the bench volume): such a push writes its own leaf and
+    // nothing else, and whether it climbs depends on its parent only.  So every pending lane looks at the parent
+    // of the leaf it would get, the leading run of non-climbing pushes is appended with one store per lane, the
+    // first climbing one goes through the ordinary push, and the rest is looked at again (its parents may have
+    // changed).  A new leaf is nobody's parent here because the heap is larger than the batch.
+    while (m) {
+      const uint32_t base = h.n;
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      if (base < 64u || base + cnt > h.cap) {   // small heap (new leaves could be parents) or no room: one by one
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const hnode_t one = {rdlane_u32(ndb, k), rdlane_u32(q, k), src, top.w};
+        if (!heap_push_wave(h, one, lane)) ovf = true;
+        npush++;
+        continue;
+      }
+      const bool mine = (m >> lane) & 1ull;
+      const uint32_t leaf = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t par = (leaf - 1u) >> 1;
+      const bool plo = !mine || par < H::TOP;
+      const uint32_t kg = h.node[plo ? H::TOP : par].x;
+      const uint32_t kl = h.top[plo && mine ? par : 0u].x;
+      const bool stay = mine && (plo ? kl : kg) < ndb;          // __push_heap climbs while parent.key >= key
+      const unsigned long long climbers = m & ~ballot64(stay);
+      const int c = climbers ? __ffsll((long long)climbers) - 1 : 64;   // first lane whose push climbs
+      const unsigned long long run = c < 64 ? (m & ((1ull << c) - 1ull)) : m;
+      if ((run >> lane) & 1ull) {
+        const hnode_t fresh = {ndb, q, src, top.w};
+        if (leaf < H::TOP) h.top[leaf] = fresh;
+        else h.node[leaf] = fresh;
+      }
+      const uint32_t nrun = (uint32_t)__popcll(run);
+      h.n = base + nrun;
+      npush += nrun;
+      m &= ~run;
+      if (c < 64) {
+        m &= ~(1ull << c);
+        const hnode_t one = {rdlane_u32(ndb, c), rdlane_u32(q, c), src, top.w};
+        if (!heap_push_wave(h, one, lane)) ovf = true;
+        npush++;
+      }
+    }
+    if (PROF) c_push += clock64() - tt;
   }
   if (lane == 0) {
     if (ovf) atomicOr(status, KH_ST_HEAP_OVERFLOW);
     *pushes += npush;
-    if (PROF) {
-      cyc3[0] += n_ticks; cyc3[1] += n_pops; cyc3[2] += n_stall;
-      c_all = clock64() - t_begin;
-      if (blockIdx.x == 0 && npush > 100000u)   // developer probe: the flood of the launch's first (= largest) label
-        printf("HEAPPROF pushes=%u pops=%llu ticks=%llu deep=%llu stall_iters=%llu cycles: all=%llu tick=%llu push=%llu\n", npush, n_pops,
-               n_ticks, n_deep, n_stall, c_all, c_tick, c_push);
-    }
+    if (PROF) { cyc3[0] += c_pop; cyc3[1] += c_push; cyc3[2] += c_fire; }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   return count;
@@ -981,6 +860,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   heap.top = (lds_hnode_t*)heap_top;
   heap.cap = task->heap_capacity;
   heap.n = 0;
+  heap_init_lane(heap, lane);
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
   const uint32_t pcap = task->path_capacity;
@@ -1279,6 +1159,7 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
     heap.top = (lds_hnode_t*)heap_top;
     heap.cap = task->heap_capacity;
     heap.n = 0;
+    heap_init_lane(heap, lane);
     if (lane == 0) { sh_status = 0; sh_pushes = 0; cyc3[0] = cyc3[1] = cyc3[2] = 0; }
     __syncthreads();
     uint32_t* pverts = path_vertices + task->path_offset;
@@ -1322,6 +1203,7 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
   heap.top = (lds_hnode_t*)heap_top;
   heap.cap = task->heap_capacity;
   heap.n = 0;
+  heap_init_lane(heap, lane);
   if (tid == 0) {
     ctl.status = 0; ctl.u1 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
@@ -1575,11 +1457,11 @@ extern "C" int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_
   }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
-  const size_t lds = (size_t)(Heap<0>::TOP + 3) * sizeof(hnode_t);
-  KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&heap_server_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  const size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&heap_server_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
   const unsigned long long patience = (unsigned long long)(patience_seconds * 1e8);   // wall_clock64 ticks at 100 MHz
-  hipLaunchKernelGGL((heap_server_kernel<0>), dim3((unsigned)nblocks), dim3(64), lds, (hipStream_t)stream, tasks, nbrmask, g, dbf,
+  hipLaunchKernelGGL((heap_server_kernel<1>), dim3((unsigned)nblocks), dim3(64), lds, (hipStream_t)stream, tasks, nbrmask, g, dbf,
                      alive, scale, constant, (hnode_t*)heap_nodes, path_vertices, park, patience);
   KH_LAUNCH_CHECK();
   return KH_OK;

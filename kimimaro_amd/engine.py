@@ -64,7 +64,11 @@ class Engine:
         # path kernel instead of one busy wave inside a 256-thread path workgroup.  False: the heap runs in place.
         self.park = os.environ.get("KH_PARK", "1") != "0"
         self.park_servers = int(os.environ.get("KH_PARK_SERVERS", "256"))   # server workgroups per launch (one wave each)
-        self.park_patience = 3.0           # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
+        self.park_patience = float(os.environ.get("KH_PARK_PATIENCE", "3.0"))   # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
+        # Launches of the path kernel that may park.  1: the first launch parks, the labels it parked resume in a second
+        # launch that runs any further uncertified call in place (few labels have a second one: 7 of 380 at c3; a third
+        # launch for them would cost the volume another round trip through the host).
+        self.park_rounds = int(os.environ.get("KH_PARK_ROUNDS", "1"))
         self.last_rounds = 0                # launches of the path kernel the last run_labels call needed
         self.sweep_force_bail = False       # tests: every call of the sweep bails at once (radius limit 0) -> every call parks
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
@@ -533,6 +537,9 @@ class Engine:
             hdr = np.zeros(16, dtype=np.int32)
             d_index, ntasks = None, count
             while True:
+                if self.last_rounds > self.park_rounds:
+                    paths(ntasks, C.c_void_p(0), P(d_index))      # the last launch: nothing parks any more
+                    return
                 hdr[3] = ntasks
                 d_park[:16].copy_(t.from_numpy(hdr), non_blocking=False)
                 d_park[16:].fill_(-1)
