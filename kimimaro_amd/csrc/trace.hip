@@ -712,24 +712,22 @@ struct SweepGlobal {
 
 // ---- parking ------------------------------------------------------------------------------------------------------
 // A call the sweep cannot certify is redone on the exact heap: ONE wave working for up to seconds.  Inside the path
-// kernel that wave sits in a 256-thread, 152-VGPR, 39-KiB-LDS workgroup slot whose other three waves wait at a barrier --
+// kernel that wave sits in a 256-thread, 160-VGPR, 39-KiB-LDS workgroup slot whose other three waves wait at a barrier --
 // 55 % of the GPU's slot time at c3 (round 2).  With a park record the path kernel instead PARKS the label: its loop state
 // goes to its task record, its index into the queue below, and the workgroup ends.  A second kernel of 64-thread
-// workgroups (heap_server_kernel, launched beside the path kernel on another stream) takes parked labels from the queue
-// as they arrive and runs their heap call; the host then launches the path kernel again over the parked labels, which
-// resume behind the invalidation.  Nobody ever waits for the server: the path kernel only appends and exits, the server
-// polls until the path kernel's workgroups are all gone (t_done == t_total) and the queue is drained.  The queue has one
-// entry per task of the launch plus one per server workgroup (a ticket may lie that far beyond the last entry); the host
-// fills it with ~0 = "not written yet".
+// workgroups (heap_server_kernel, 2 KiB of LDS, on another stream) takes parked labels from the queue as they arrive,
+// runs their heap call and lists them in the `served` list; the host polls that list and launches the path kernel again
+// over the newly served labels (on a third stream), which resume behind the invalidation -- and may park again.  Nobody on
+// the device ever waits for anybody: the path kernel only appends and exits; a server leaves when it has nothing to do and
+// every path workgroup launched so far has ended (t_done == t_total) or when it has been idle for too long, so idle servers
+// can never starve the kernel they would wait for; the host starts servers with every path launch.
+// Record (u32 words): [0] parked (entries appended to the queue)  [1] taken (entries handed to servers)  [2] t_done (path
+// workgroups ended)  [3] t_total (path workgroups launched so far: host)  [4] idle exits (diagnostic)  [5] served (entries
+// appended to the served list)  [6] capacity of either list (host)  [7] overflow flag  [8..15] -, then queue[capacity],
+// then served[capacity].  Queue entries start as ~0 = "not written yet".
 struct ParkCtl {
-  uint32_t q_count;     // labels appended (path kernel)
-  uint32_t q_taken;     // tickets handed out (server)
-  uint32_t t_done;      // path workgroups that have ended
-  uint32_t t_total;     // ... of this launch (host)
-  uint32_t error;       // server: workgroups that left because they were idle for too long
-  uint32_t served;      // server: calls done (diagnostic)
-  uint32_t pad[10];
-  // uint32_t queue[] follows (64 bytes in)
+  uint32_t q_count, q_taken, t_done, t_total, idle_exits, served, cap, overflow;
+  uint32_t pad[8];
 };
 static constexpr uint32_t KH_PARKED = 0xFFFFFFFFu;
 // kh_label_t.park_phase
@@ -822,8 +820,10 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.sh = swsh;
 }
 
+// (INPLACE: 2 workgroups per CU by registers instead of 3 -- with the heap code inside, 168 VGPRs meant 568 B of scratch
+// per lane and a path loop 1.6 x slower; this variant runs when there is no sweep, i.e. in tests and comparisons)
 template <bool PROF, bool INPLACE>
-__global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
+__global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,
@@ -1099,19 +1099,19 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     if (parked) {
       uint32_t* queue = sg.park + 16;
       const uint32_t slot = atomicAdd(&park->q_count, 1u);
-      __hip_atomic_store(&queue[slot], task_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (entries start as ~0)
+      if (slot < park->cap) __hip_atomic_store(&queue[slot], task_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else atomicOr(&park->overflow, 1u);       // (the host sizes the lists for 8 parks per label; it raises on this flag)
       __threadfence();
     }
     atomicAdd(&park->t_done, 1u);
   }
 }
 
-// The heap server: 64-thread workgroups that take parked labels (tickets in queue order) and run the invalidation call they
-// parked at on the exact heap (invalidate_ball: the pop pipeline).  A workgroup with a ticket beyond the queue's end waits
-// for the entry to appear -- or for the path kernel to be over (t_done == t_total; the queue is final then, because a path
-// workgroup publishes its entry before it counts itself done) -- or until it has been idle for `patience` (wall clock): it
-// then leaves, so that idle servers can never starve the path kernel they are waiting for (word 4 counts such exits; the
-// host serves what they left behind with a launch that has no path kernel beside it: t_total = 0).
+// The heap server: 64-thread workgroups that take parked labels in queue order and run the invalidation call they parked at
+// on the exact heap (invalidate_ball), then list the label as served.  An entry is taken with a CAS on `taken` only when
+// it exists (taken < parked), so no ticket is ever lost to a server that leaves.  A server leaves when the queue is empty
+// and every path workgroup launched so far has ended -- a path workgroup publishes its entry BEFORE it counts itself done,
+// so after reading t_done == t_total one more look at the queue is conclusive -- or when it has been idle for `patience`.
 template <int TOPL>
 __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, const uint32_t* __restrict__ nbrmask, Geometry g,
                                                          const float* __restrict__ dbf, uint8_t* alive, float scale,
@@ -1122,28 +1122,36 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
   __shared__ unsigned long long cyc3[3];
   extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
   ParkCtl* park = reinterpret_cast<ParkCtl*>(park_words);
+  const uint32_t cap = park->cap;
   const uint32_t* queue = park_words + 16;
+  uint32_t* served_list = park_words + 16 + cap;
   const int lane = threadIdx.x;
   if (lane == 0) geo = g;
   __syncthreads();
   for (;;) {
     if (lane == 0) {
-      const uint32_t ticket = atomicAdd(&park->q_taken, 1u);
       const unsigned long long t_start = wall_clock64();
-      uint32_t go = 2;                                    // 1: entry readable, 0: leave, 2: keep waiting
+      uint32_t go = 2, ticket = 0;                        // go 1: entry taken, 0: leave, 2: keep looking
       while (go == 2) {
-        if (__hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu) { go = 1; break; }
+        const uint32_t k = __hip_atomic_load(&park->q_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t c = __hip_atomic_load(&park->q_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > cap) c = cap;
+        if (k < c) {
+          if (atomicCAS(&park->q_taken, k, k + 1u) == k) { ticket = k; go = 1; }
+          continue;
+        }
         if (__hip_atomic_load(&park->t_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >=
             __hip_atomic_load(&park->t_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          // the path kernel is over: every entry it will ever write is written
-          go = __hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu ? 1u : 0u;
-          break;
+          uint32_t c2 = __hip_atomic_load(&park->q_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (c2 > cap) c2 = cap;
+          if (__hip_atomic_load(&park->q_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c2) { go = 0; break; }
+          continue;
         }
-        // idle for too long: leave (the slot, the registers and the LDS go back to the path kernel).  A label that parks
-        // at this ticket later is found unserved by the host and served by a launch of its own.
-        if (wall_clock64() - t_start > patience) { atomicAdd(&park->error, 1u); go = 0; break; }
+        if (wall_clock64() - t_start > patience) { atomicAdd(&park->idle_exits, 1u); go = 0; break; }
         __builtin_amdgcn_s_sleep(32);
       }
+      if (go == 1)    // (the appender bumps the count first and writes the entry right after)
+        while (__hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);
       sh_ticket = ticket;
       sh_go = go;
     }
@@ -1152,7 +1160,8 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
     // what the path kernel wrote for this label (task record, path vertices, restored alive bytes) is read with ordinary
     // loads below: drop whatever this CU's vector cache still holds from an earlier call
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    kh_label_t* task = &tasks[__hip_atomic_load(&queue[sh_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    const uint32_t task_index = __hip_atomic_load(&queue[sh_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    kh_label_t* task = &tasks[task_index];
     const uint32_t phase = task->park_phase;
     Heap<TOPL> heap;
     heap.node = heap_nodes + task->heap_offset;
@@ -1176,7 +1185,9 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
       task->status |= sh_status;
       task->stat_heap_pushes += sh_pushes;
       task->park_phase = phase + PARK_DONE;
-      atomicAdd(&park->served, 1u);
+      __threadfence();                                    // the record and the alive bytes before the label is listed
+      const uint32_t at = atomicAdd(&park->served, 1u);
+      __hip_atomic_store(&served_list[at], task_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence();
     __syncthreads();

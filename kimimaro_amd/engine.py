@@ -58,17 +58,14 @@ class Engine:
         # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
         self.torch.cuda.set_device(self.device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
-        self._side = None     # second stream: the heap server runs there beside the path kernel
+        self._side = None     # three more streams: heap servers, resume launches, polling (created on first use)
         self.split_slots = 0  # (rounds 1-2: the biggest labels on a second stream; superseded by the heap server)
         # Calls the sweep cannot certify go to the heap server (csrc/trace.hip "parking"): 64-thread workgroups beside the
         # path kernel instead of one busy wave inside a 256-thread path workgroup.  False: the heap runs in place.
         self.park = os.environ.get("KH_PARK", "1") != "0"
         self.park_servers = int(os.environ.get("KH_PARK_SERVERS", "256"))   # server workgroups per launch (one wave each)
         self.park_patience = float(os.environ.get("KH_PARK_PATIENCE", "3.0"))   # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
-        # Launches of the path kernel that may park.  1: the first launch parks, the labels it parked resume in a second
-        # launch that runs any further uncertified call in place (few labels have a second one: 7 of 380 at c3; a third
-        # launch for them would cost the volume another round trip through the host).
-        self.park_rounds = int(os.environ.get("KH_PARK_ROUNDS", "1"))
+        self.park_poll = float(os.environ.get("KH_PARK_POLL", "0.004"))   # seconds between two looks at the served list
         self.last_rounds = 0                # launches of the path kernel the last run_labels call needed
         self.sweep_force_bail = False       # tests: every call of the sweep bails at once (radius limit 0) -> every call parks
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
@@ -510,69 +507,90 @@ class Engine:
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
         use_park = bool(self.park) and d_rank is not None
         n_srv = int(max(1, min(self.park_servers, nl))) if use_park else 0
-        d_park = t.zeros(16 + nl + n_srv + 16, dtype=t.int32, device=self.device) if use_park else None
+        # park record (csrc/trace.hip "parking"): 16 header words, the queue of parked labels, the list of served labels
+        pcap_q = 8 * nl + 4096
+        d_park = None
+        if use_park:
+            d_park = t.full((16 + 2 * pcap_q,), -1, dtype=t.int32, device=self.device)
         isz = _abi.LABEL_T.itemsize
 
         def launch(first, count, stream):
-            """the path loop of tasks [first, first + count), to completion: with the heap server, as many launches of the
-            path kernel as the labels need (a label parks at a call the sweep cannot certify, the server runs that call,
-            the next launch resumes the parked labels)."""
+            """the path loop of tasks [first, first + count), to completion.  With the heap server: a label parks at a call
+            the sweep cannot certify, a server workgroup runs that call and lists the label as served, this thread polls
+            the list and launches the path kernel again over the newly served labels -- until every label is through."""
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * isz)
 
-            def paths(ntasks, park_ptr, index_ptr):
+            def paths(ntasks, park_ptr, index_ptr, strm):
                 _abi.check(lib.kh_trace_paths(tasks_ptr, ntasks, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
                                               P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                               np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                               P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
-                                              P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), park_ptr, index_ptr, stream))
+                                              P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), park_ptr, index_ptr, strm))
 
             self.last_rounds = 1
             if not use_park:
-                paths(count, C.c_void_p(0), C.c_void_p(0))
+                paths(count, C.c_void_p(0), C.c_void_p(0), stream)
                 return
+            import time as _t
+            trace_t = os.environ.get("KH_PARK_TRACE") == "1"      # developer probe: time line of the launches
+            t_0 = _t.perf_counter()
+            log = []
             cur = t.cuda.current_stream(self.device)
             if self._side is None:
-                self._side = t.cuda.Stream(device=self.device)
-            side = self._side
-            hdr = np.zeros(16, dtype=np.int32)
-            d_index, ntasks = None, count
-            while True:
-                if self.last_rounds > self.park_rounds:
-                    paths(ntasks, C.c_void_p(0), P(d_index))      # the last launch: nothing parks any more
-                    return
-                hdr[3] = ntasks
-                d_park[:16].copy_(t.from_numpy(hdr), non_blocking=False)
-                d_park[16:].fill_(-1)
-                side.wait_stream(cur)      # (the server starts behind the reset above, not behind the path kernel)
-                # path kernel first: should the two launches ever be serialised (fewer hardware queues than streams), the
-                # server then runs behind it and drains the queue instead of waiting for a kernel that cannot start
-                paths(ntasks, P(d_park), P(d_index) if d_index is not None else C.c_void_p(0))
+                self._side = [t.cuda.Stream(device=self.device) for _ in range(3)]
+            side, res, poll = self._side          # servers / resume launches / this thread's look at the record
+
+            def servers(n):
                 _abi.check(lib.kh_heap_server(tasks_ptr, P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_alive),
                                               np.float32(params["scale"]), np.float32(params["const"]), P(d_heap), P(d_pverts),
-                                              P(d_park), min(n_srv, ntasks), float(self.park_patience),
-                                              C.c_void_p(side.cuda_stream)))
+                                              P(d_park), int(n), float(self.park_patience), C.c_void_p(side.cuda_stream)))
+
+            hdr = np.zeros(16, dtype=np.int32)
+            t_total = count
+            hdr[3], hdr[6] = t_total, pcap_q
+            d_park[:16].copy_(t.from_numpy(hdr))
+            for s_ in (side, res, poll):
+                s_.wait_stream(cur)               # (behind the set-up of the record and of the fields, not behind the path kernel)
+            # path kernel first: should two launches ever be serialised (fewer hardware queues than streams), the servers then
+            # run behind it and drain the queue instead of idling in front of a kernel that cannot start
+            paths(count, P(d_park), C.c_void_p(0), stream)
+            servers(min(n_srv, count))
+            resumed = 0
+            served_base = d_park.data_ptr() + 4 * (16 + pcap_q)
+            try:
+                while True:
+                    _t.sleep(self.park_poll)
+                    with t.cuda.stream(poll):
+                        head = d_park[:16].cpu().numpy().view(np.uint32)
+                    if int(head[7]):
+                        raise _abi.KimiHipError("kimimaro_amd: more than 8 parked calls per label on average (park lists full)")
+                    served = int(head[5])
+                    launched = False
+                    if served > resumed:
+                        with t.cuda.stream(poll):
+                            lst = d_park[16 + pcap_q + resumed:16 + pcap_q + served].cpu().numpy()
+                        gap = np.flatnonzero(lst == -1)         # (a server bumps the count first and writes the entry right after)
+                        n_ok = int(gap[0]) if gap.size else int(lst.size)
+                        if n_ok > 0:
+                            t_total += n_ok
+                            with t.cuda.stream(poll):
+                                d_park[3:4].copy_(t.from_numpy(np.array([t_total], dtype=np.int32)))
+                                poll.synchronize()            # the servers must see the new total before the launch can end
+                            paths(n_ok, P(d_park), C.c_void_p(served_base + 4 * resumed), C.c_void_p(res.cuda_stream))
+                            servers(min(n_srv, n_ok))
+                            resumed += n_ok
+                            self.last_rounds += 1
+                            launched = True
+                            if trace_t:
+                                log.append(("resume", n_ok, round(_t.perf_counter() - t_0, 3)))
+                    if not launched and int(head[2]) >= t_total and int(head[0]) == served == resumed:
+                        break                                  # every path workgroup has ended and nothing is parked
+            finally:
                 cur.wait_stream(side)
-                head = d_park[:16].cpu().numpy().view(np.uint32)      # (synchronises: the launch and its server are over)
-                nparked = int(head[0])
-                if nparked == 0:
-                    return
-                d_index = d_park[16:16 + nparked].clone()
-                if int(head[5]) != nparked:
-                    # servers that had been idle for too long left before these labels parked: serve them now (t_total = 0)
-                    phase_at = (d_index.to(t.int64) * (isz // 4) + _abi.LABEL_T.fields["park_phase"][1] // 4)
-                    phases = d_tasks[first * isz:].view(t.int32)[phase_at].cpu().numpy()
-                    left = d_index[t.from_numpy(np.flatnonzero(phases <= 2)).to(self.device)]
-                    hdr[3] = 0
-                    hdr[0] = int(left.numel())
-                    d_park[:16].copy_(t.from_numpy(hdr))
-                    d_park[16:].fill_(-1)
-                    d_park[16:16 + left.numel()] = left
-                    _abi.check(lib.kh_heap_server(tasks_ptr, P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_alive),
-                                                  np.float32(params["scale"]), np.float32(params["const"]), P(d_heap), P(d_pverts),
-                                                  P(d_park), min(max(n_srv, 64), int(left.numel())), float(self.park_patience), stream))
-                    hdr[0] = 0
-                ntasks = nparked
-                self.last_rounds += 1
+                cur.wait_stream(res)
+            if trace_t:
+                log.append(("done", "parked", int(head[0]), "idle_exits", int(head[4]), round(_t.perf_counter() - t_0, 3)))
+                print("PARKTRACE", log[-12:], "launches", self.last_rounds, file=sys.stderr, flush=True)
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""

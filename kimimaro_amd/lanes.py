@@ -25,7 +25,7 @@ def ensure_hw_queues(width):
     another lane's seconds-long path kernel (profiles/r02b_inflight_timeline.txt).  The HIP runtime reads
     GPU_MAX_HW_QUEUES once, when it initialises (default 4): set it here while that is still possible, otherwise verify it
     and fail loudly rather than run with the silently serialised lanes that were measured as broken."""
-    want = max(8, 2 * int(width))
+    want = min(32, max(16, 4 * int(width) + 4))   # a lane = its own stream + three of its engine (servers, resumes, polling)
     have = os.environ.get("GPU_MAX_HW_QUEUES")
     try:
         import torch

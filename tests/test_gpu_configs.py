@@ -86,7 +86,6 @@ def test_every_call_parked_and_served(patience):
     params["const"] = 64
     e = Engine()
     e.sweep_force_bail = True
-    e.park_rounds = 1000          # (default 1: only the first launch parks)
     e.park_patience = patience
     got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=300, fix_borders=True, fix_branching=True,
                                    progress=False, _engine=e)
