@@ -205,13 +205,15 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.
- * park (nullable): a 64-byte aligned device record of 16 + ntasks + (server workgroups) u32 words -- words 0..15 =
- *   {labels parked, tickets taken, path workgroups done, path workgroups of this launch, error, calls served, ...}, then the
- *   queue of parked task indices; the caller zeroes the counters, sets word 3 to ntasks and fills the queue with 0xFFFFFFFF
- *   before every launch.  With it, a label whose call the sweep cannot certify is PARKED (its loop state goes to its task
- *   record, its index to the queue, its workgroup ends) instead of running the heap in place; kh_heap_server, launched
- *   beside this call on another stream, runs the parked calls; afterwards the caller launches kh_trace_paths again with
- *   task_index = the parked task indices (ntasks of them) and the labels resume.  Repeat until word 0 stays 0.
+ * park (nullable): a 64-byte aligned device record of 16 + 2 * capacity u32 words -- words 0..15 = {labels parked, entries
+ *   taken by servers, path workgroups ended, path workgroups launched (caller), idle exits, labels served, capacity (caller),
+ *   overflow flag, stop (caller), servers ended, ...}, then the queue of parked task indices, then the list of served task
+ *   indices (both `capacity` entries, filled with 0xFFFFFFFF by the caller).  With it, a label whose call the sweep cannot
+ *   certify is PARKED (its loop state goes to its task record, its index to the queue, its workgroup ends) instead of running
+ *   the heap in place; kh_heap_server workgroups, launched on another stream, run the parked calls and list the labels as
+ *   served; the caller launches kh_trace_paths again with task_index = the newly served entries of that list (after adding
+ *   their number to word 3) and the labels resume; they may park again.  The call is over when word 2 == word 3 and words
+ *   0 == 5 == the number of labels resumed; the caller then sets word 8 and the servers end.
  * task_index (nullable): workgroup b traces tasks[task_index[b]] instead of tasks[b].
  * The out fields of kh_label_t accumulate over the launches of a label; the caller zeroes them once.       */
 #define KH_TRACE_PROFILE 1
@@ -229,12 +231,11 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
 
 /* The heap server of kh_trace_paths' park record: `nblocks` 64-thread workgroups that take parked labels from the queue as
  * they arrive and run the invalidation call they parked at as the exact emulation of std::priority_queue
- * (dijkstra_invalidation.hpp:239-332), one wave per call; a label's park_phase goes from 1 / 2 to 3 / 4 and park_count
- * receives the number of voxels invalidated.  Launch it on ANOTHER stream than the kh_trace_paths call it serves, before or
- * after it: a server workgroup ends when that call's workgroups have all ended and the queue is drained, or when it has
- * been idle for patience_seconds (word 4 of the record counts those; idle servers must never starve the path kernel they
- * wait for).  A label left parked (park_phase 1 / 2) is served by calling kh_heap_server on a record whose queue lists it
- * and whose word 3 (path workgroups of the launch) is 0.  Arguments as for kh_trace_paths.                       */
+ * (dijkstra_invalidation.hpp:239-332), one wave per call; a label's park_phase goes from 1 / 2 to 3 / 4, park_count
+ * receives the number of voxels invalidated and the label is appended to the served list.  Launch it on ANOTHER stream than
+ * the kh_trace_paths calls it serves.  A workgroup ends when word 8 (stop) of the record is set, or when it has been idle
+ * for patience_seconds (word 4 counts those, word 9 all that have ended: the caller starts new ones when labels are parked
+ * and none is left).  Arguments as for kh_trace_paths.                                                            */
 int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz,
                    float wx, float wy, float wz, const float* dbf, uint8_t* alive, float scale, float constant,
                    void* heap_nodes, uint32_t* path_vertices, uint32_t* park, int64_t nblocks,

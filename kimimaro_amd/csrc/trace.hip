@@ -717,17 +717,19 @@ struct SweepGlobal {
 // goes to its task record, its index into the queue below, and the workgroup ends.  A second kernel of 64-thread
 // workgroups (heap_server_kernel, 2 KiB of LDS, on another stream) takes parked labels from the queue as they arrive,
 // runs their heap call and lists them in the `served` list; the host polls that list and launches the path kernel again
-// over the newly served labels (on a third stream), which resume behind the invalidation -- and may park again.  Nobody on
-// the device ever waits for anybody: the path kernel only appends and exits; a server leaves when it has nothing to do and
-// every path workgroup launched so far has ended (t_done == t_total) or when it has been idle for too long, so idle servers
-// can never starve the kernel they would wait for; the host starts servers with every path launch.
+// over the newly served labels (on further streams), which resume behind the invalidation -- and may park again.  Nobody on
+// the device ever waits for anybody: the path kernel only appends and exits; the servers stay for the whole call of
+// run_labels -- an idle one looks at the queue every ~20 us (a hundred pollers on one cache line every microsecond would be
+// an L2 hot spot) and holds a quarter of a SIMD's registers and 2 KiB of LDS, nothing a path workgroup needs -- until the
+// host raises `stop`; one that has been idle for `patience` leaves on its own (never spin for ever), and the host starts
+// new ones when labels are parked and no server is left.
 // Record (u32 words): [0] parked (entries appended to the queue)  [1] taken (entries handed to servers)  [2] t_done (path
 // workgroups ended)  [3] t_total (path workgroups launched so far: host)  [4] idle exits (diagnostic)  [5] served (entries
-// appended to the served list)  [6] capacity of either list (host)  [7] overflow flag  [8..15] -, then queue[capacity],
-// then served[capacity].  Queue entries start as ~0 = "not written yet".
+// appended to the served list)  [6] capacity of either list (host)  [7] overflow flag  [8] stop (host)  [9] servers that
+// have ended  [10..15] -, then queue[capacity], then served[capacity].  Queue entries start as ~0 = "not written yet".
 struct ParkCtl {
-  uint32_t q_count, q_taken, t_done, t_total, idle_exits, served, cap, overflow;
-  uint32_t pad[8];
+  uint32_t q_count, q_taken, t_done, t_total, idle_exits, served, cap, overflow, stop, exited;
+  uint32_t pad[6];
 };
 static constexpr uint32_t KH_PARKED = 0xFFFFFFFFu;
 // kh_label_t.park_phase
@@ -1109,9 +1111,8 @@ __global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_la
 
 // The heap server: 64-thread workgroups that take parked labels in queue order and run the invalidation call they parked at
 // on the exact heap (invalidate_ball), then list the label as served.  An entry is taken with a CAS on `taken` only when
-// it exists (taken < parked), so no ticket is ever lost to a server that leaves.  A server leaves when the queue is empty
-// and every path workgroup launched so far has ended -- a path workgroup publishes its entry BEFORE it counts itself done,
-// so after reading t_done == t_total one more look at the queue is conclusive -- or when it has been idle for `patience`.
+// it exists (taken < parked), so no ticket is ever lost to a server that leaves.  A server leaves when the host raises
+// `stop`, or when it has been idle for `patience`.
 template <int TOPL>
 __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, const uint32_t* __restrict__ nbrmask, Geometry g,
                                                          const float* __restrict__ dbf, uint8_t* alive, float scale,
@@ -1133,6 +1134,7 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
       const unsigned long long t_start = wall_clock64();
       uint32_t go = 2, ticket = 0;                        // go 1: entry taken, 0: leave, 2: keep looking
       while (go == 2) {
+        if (__hip_atomic_load(&park->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
         const uint32_t k = __hip_atomic_load(&park->q_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t c = __hip_atomic_load(&park->q_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (c > cap) c = cap;
@@ -1140,16 +1142,10 @@ __global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, cons
           if (atomicCAS(&park->q_taken, k, k + 1u) == k) { ticket = k; go = 1; }
           continue;
         }
-        if (__hip_atomic_load(&park->t_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >=
-            __hip_atomic_load(&park->t_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          uint32_t c2 = __hip_atomic_load(&park->q_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          if (c2 > cap) c2 = cap;
-          if (__hip_atomic_load(&park->q_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c2) { go = 0; break; }
-          continue;
-        }
         if (wall_clock64() - t_start > patience) { atomicAdd(&park->idle_exits, 1u); go = 0; break; }
-        __builtin_amdgcn_s_sleep(32);
+        for (int i = 0; i < 6; i++) __builtin_amdgcn_s_sleep(127);      // ~20 us
       }
+      if (go == 0) atomicAdd(&park->exited, 1u);
       if (go == 1)    // (the appender bumps the count first and writes the entry right after)
         while (__hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);
       sh_ticket = ticket;

@@ -64,8 +64,8 @@ class Engine:
         # path kernel instead of one busy wave inside a 256-thread path workgroup.  False: the heap runs in place.
         self.park = os.environ.get("KH_PARK", "1") != "0"
         self.park_servers = int(os.environ.get("KH_PARK_SERVERS", "256"))   # server workgroups per launch (one wave each)
-        self.park_patience = float(os.environ.get("KH_PARK_PATIENCE", "3.0"))   # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
-        self.park_poll = float(os.environ.get("KH_PARK_POLL", "0.004"))   # seconds between two looks at the served list
+        self.park_patience = float(os.environ.get("KH_PARK_PATIENCE", "20.0"))   # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
+        self.park_poll = float(os.environ.get("KH_PARK_POLL", "0.002"))   # seconds between two looks at the served list
         self.last_rounds = 0                # launches of the path kernel the last run_labels call needed
         self.sweep_force_bail = False       # tests: every call of the sweep bails at once (radius limit 0) -> every call parks
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
@@ -537,26 +537,34 @@ class Engine:
             log = []
             cur = t.cuda.current_stream(self.device)
             if self._side is None:
-                self._side = [t.cuda.Stream(device=self.device) for _ in range(3)]
-            side, res, poll = self._side          # servers / resume launches / this thread's look at the record
+                self._side = [t.cuda.Stream(device=self.device) for _ in range(6)]
+            side, poll = self._side[0], self._side[1]      # servers / this thread's look at the record
+            res = self._side[2:]                             # resume launches, round robin: a long one must not hold up the next
+
+            launched_servers = [0]
 
             def servers(n):
                 _abi.check(lib.kh_heap_server(tasks_ptr, P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_alive),
                                               np.float32(params["scale"]), np.float32(params["const"]), P(d_heap), P(d_pverts),
                                               P(d_park), int(n), float(self.park_patience), C.c_void_p(side.cuda_stream)))
+                launched_servers[0] += int(n)
+
+            def poke(word, value):
+                with t.cuda.stream(poll):
+                    d_park[word:word + 1].copy_(t.from_numpy(np.array([value], dtype=np.int32)))
+                    poll.synchronize()
 
             hdr = np.zeros(16, dtype=np.int32)
             t_total = count
             hdr[3], hdr[6] = t_total, pcap_q
             d_park[:16].copy_(t.from_numpy(hdr))
-            for s_ in (side, res, poll):
+            for s_ in self._side:
                 s_.wait_stream(cur)               # (behind the set-up of the record and of the fields, not behind the path kernel)
-            # path kernel first: should two launches ever be serialised (fewer hardware queues than streams), the servers then
-            # run behind it and drain the queue instead of idling in front of a kernel that cannot start
             paths(count, P(d_park), C.c_void_p(0), stream)
             servers(min(n_srv, count))
             resumed = 0
             served_base = d_park.data_ptr() + 4 * (16 + pcap_q)
+            head = hdr.view(np.uint32)
             try:
                 while True:
                     _t.sleep(self.park_poll)
@@ -573,24 +581,27 @@ class Engine:
                         n_ok = int(gap[0]) if gap.size else int(lst.size)
                         if n_ok > 0:
                             t_total += n_ok
-                            with t.cuda.stream(poll):
-                                d_park[3:4].copy_(t.from_numpy(np.array([t_total], dtype=np.int32)))
-                                poll.synchronize()            # the servers must see the new total before the launch can end
-                            paths(n_ok, P(d_park), C.c_void_p(served_base + 4 * resumed), C.c_void_p(res.cuda_stream))
-                            servers(min(n_srv, n_ok))
+                            poke(3, t_total)
+                            rs = res[self.last_rounds % len(res)]
+                            paths(n_ok, P(d_park), C.c_void_p(served_base + 4 * resumed), C.c_void_p(rs.cuda_stream))
                             resumed += n_ok
                             self.last_rounds += 1
                             launched = True
                             if trace_t:
                                 log.append(("resume", n_ok, round(_t.perf_counter() - t_0, 3)))
+                    backlog = int(head[0]) - int(head[1])
+                    if backlog > 0 and launched_servers[0] - int(head[9]) <= 0:
+                        servers(min(n_srv, backlog))           # every server had left (idle for too long)
                     if not launched and int(head[2]) >= t_total and int(head[0]) == served == resumed:
                         break                                  # every path workgroup has ended and nothing is parked
             finally:
+                poke(8, 1)                                     # the servers end
                 cur.wait_stream(side)
-                cur.wait_stream(res)
+                for s_ in res:
+                    cur.wait_stream(s_)
             if trace_t:
                 log.append(("done", "parked", int(head[0]), "idle_exits", int(head[4]), round(_t.perf_counter() - t_0, 3)))
-                print("PARKTRACE", log[-12:], "launches", self.last_rounds, file=sys.stderr, flush=True)
+                print("PARKTRACE", log[:6], "...", log[-6:], "launches", self.last_rounds, file=sys.stderr, flush=True)
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
