@@ -49,7 +49,7 @@ import numpy as np
 
 # one hardware queue per lane stream (up to 12 lanes + RCCL): with the default of 4, a fifth stream shares a queue and its kernels wait for the
 # seconds-long path kernel queued before them (profiles/r02b_inflight_timeline.txt)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -142,12 +142,6 @@ typedef struct kh_label_t {
   uint32_t stat_sweep_levels; /* out: levels processed */
   uint32_t stat_sweep_events; /* out: events processed (low 32 bits) */
   uint32_t stat_sweep_why;    /* out: OR of the bail reasons (sweep.h SW_BAIL_*) */
-  /* parking (kh_trace_paths with a park record): the loop state of a label whose invalidation call went to the heap server.
-   * All zero on the first launch; 0 again in park_phase when the label is finished. */
-  uint32_t park_phase;   /* 0 = not parked; 1 / 2 = parked at the soma call / in the path loop; + 2 once kh_heap_server has run the call */
-  uint32_t park_count;   /* heap server: voxels the parked call invalidated */
-  uint32_t park_valid, park_npaths, park_nverts, park_nb, park_na, park_max_paths;   /* loop state */
-  uint32_t park_plen;    /* vertices of the path whose invalidation is pending (at path_offset + park_nverts; soma call: 1 at path_offset) */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
@@ -204,18 +198,7 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * up to 256 bytes, at the front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
- * from the root, paths returned root -> target.
- * park (nullable): a 64-byte aligned device record of 16 + 2 * capacity u32 words -- words 0..15 = {labels parked, entries
- *   taken by servers, path workgroups ended, path workgroups launched (caller), idle exits, labels served, capacity (caller),
- *   overflow flag, stop (caller), servers ended, ...}, then the queue of parked task indices, then the list of served task
- *   indices (both `capacity` entries, filled with 0xFFFFFFFF by the caller).  With it, a label whose call the sweep cannot
- *   certify is PARKED (its loop state goes to its task record, its index to the queue, its workgroup ends) instead of running
- *   the heap in place; kh_heap_server workgroups, launched on another stream, run the parked calls and list the labels as
- *   served; the caller launches kh_trace_paths again with task_index = the newly served entries of that list (after adding
- *   their number to word 3) and the labels resume; they may park again.  The call is over when word 2 == word 3 and words
- *   0 == 5 == the number of labels resumed; the caller then sets word 8 and the servers end.
- * task_index (nullable): workgroup b traces tasks[task_index[b]] instead of tasks[b].
- * The out fields of kh_label_t accumulate over the launches of a label; the caller zeroes them once.       */
+ * from the root, paths returned root -> target.                                                  */
 #define KH_TRACE_PROFILE 1
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
@@ -226,20 +209,7 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
                    uint32_t* queues, void* heap_nodes,
                    uint32_t* path_vertices, uint32_t* path_lengths,
                    const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                   uint64_t* cstate, void* event_arena, int flags, int fix_branching,
-                   uint32_t* park, const uint32_t* task_index, void* stream);
-
-/* The heap server of kh_trace_paths' park record: `nblocks` 64-thread workgroups that take parked labels from the queue as
- * they arrive and run the invalidation call they parked at as the exact emulation of std::priority_queue
- * (dijkstra_invalidation.hpp:239-332), one wave per call; a label's park_phase goes from 1 / 2 to 3 / 4, park_count
- * receives the number of voxels invalidated and the label is appended to the served list.  Launch it on ANOTHER stream than
- * the kh_trace_paths calls it serves.  A workgroup ends when word 8 (stop) of the record is set, or when it has been idle
- * for patience_seconds (word 4 counts those, word 9 all that have ended: the caller starts new ones when labels are parked
- * and none is left).  Arguments as for kh_trace_paths.                                                            */
-int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz,
-                   float wx, float wy, float wz, const float* dbf, uint8_t* alive, float scale, float constant,
-                   void* heap_nodes, uint32_t* path_vertices, uint32_t* park, int64_t nblocks,
-                   double patience_seconds, void* stream);
+                   uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream);
 
 /* keys[a + ra*(b + rb*c)] = the flood's key of the voxel offset (a, b, c): sqrt(fl(fl((wx*a)^2 + (wy*b)^2) + (wz*c)^2)),
  * float operation order of dijkstra_invalidation.hpp:310-316.  Device array of ra*rb*rc floats.              */

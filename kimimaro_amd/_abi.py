@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
 # every symbol include/kimi_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_nd", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
-    "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_heap_server", "kh_fill_f32", "kh_fill_u8",
+    "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
     "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_invalidate_ball", "kh_path_search", "kh_zero2inf", "kh_inf2zero", "kh_pdrf_field", "kh_target_max", "kh_find_target", "kh_first_label", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
 
@@ -29,7 +29,7 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 55 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 46 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
@@ -43,10 +43,8 @@ LABEL_T = np.dtype([
     ("nlev", "<u4"), ("sweep_rmax", "<f4"), ("ev_offset", "<u4"), ("ev_chunks", "<u4"), ("ev_shift", "<u4"),
     ("stat_sweep_calls", "<u4"), ("stat_sweep_bails", "<u4"), ("stat_sweep_levels", "<u4"), ("stat_sweep_events", "<u4"),
     ("stat_sweep_why", "<u4"),
-    ("park_phase", "<u4"), ("park_count", "<u4"), ("park_valid", "<u4"), ("park_npaths", "<u4"), ("park_nverts", "<u4"),
-    ("park_nb", "<u4"), ("park_na", "<u4"), ("park_max_paths", "<u4"), ("park_plen", "<u4"),
 ])
-assert LABEL_T.itemsize == 220
+assert LABEL_T.itemsize == 184
 SWEEP_LDS_LEVELS = 16384  # KH_SWEEP_LDS_LEVELS
 SWEEP_MAX_LEVELS = 1 << 22  # labels with more levels than this use the heap emulation only
 PDRF_BASE, PDRF_FINISH = -1, -2  # KH_PDRF_BASE / KH_PDRF_FINISH
@@ -98,8 +96,7 @@ def lib():
     L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp]
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
-                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, ci, ci, vp, vp, vp]
-    L.kh_heap_server.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, f32, f32, vp, vp, vp, i64, C.c_double, vp]
+                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, ci, ci, vp]
     L.kh_invalidate_ball.argtypes = [vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, i64, f32, f32,
                                      vp, i64, i64, i64, i64, vp, vp, vp, vp]
     L.kh_path_search.argtypes = [vp, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, i64, vp, vp]

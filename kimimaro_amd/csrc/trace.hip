@@ -315,10 +315,8 @@ __global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int 
 //           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
 //           per memory round trip: 126 speculative child nodes are fetched by the 64 lanes, the path
 //           is resolved from registers, and the nodes on it are moved up in one parallel step.
-// Nodes are 16-byte records {key bits, voxel, source voxel, max_dist bits} -- the reference's HeapDistanceNode
-// (dijkstra_invalidation.hpp:210-231) field for field (round 3; before: {key, voxel, source index, -}, which cost a live pop
-// two dependent look-ups, path[index] and dbf[source]) -- in the label's slice of HBM scratch, so a node is one dwordx4
-// load or store.  Keys are non-negative floats: they are compared as their bit
+// Nodes are 16-byte records {key bits, voxel, source index, -} in the label's slice of HBM scratch, so
+// a node is one dwordx4 load or store.  Keys are non-negative floats: they are compared as their bit
 // patterns (unsigned), which lets "ties go left" be written as k < sibling + (1 on left lanes).
 // A write-through LDS mirror of heap levels 0-12 was tried twice and measured 10-15 % SLOWER: the pop is
 // bound by instruction issue of its single wave more than by memory latency.
@@ -372,9 +370,8 @@ __device__ __forceinline__ void heap_init_lane(H& h, int lane) {
 // to child), lanes < m write their ancestor one generation down and lane m drops the new node into
 // generation m's slot.
 template <class H>
-__device__ __forceinline__ bool heap_push_wave(H& h, const hnode_t fresh, int lane) {
+__device__ __forceinline__ bool heap_push_wave(H& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
   if (h.n >= h.cap) return false;
-  const uint32_t kbits = fresh.x;
   const uint32_t pos = h.n++;
   const int sh = lane + 1 < 32 ? lane + 1 : 31;
   const uint32_t q = (pos + 1u) >> sh;
@@ -392,6 +389,7 @@ __device__ __forceinline__ bool heap_push_wave(H& h, const hnode_t fresh, int la
   const unsigned long long climb = ballot64(valid && a.x >= kbits);
   const int m = __ffsll((long long)~climb) - 1;  // length of the leading run of set bits (lane 63 never set)
   const uint32_t dest = ((pos + 1u) >> (lane < 31 ? lane : 31)) - 1u;  // slot of generation `lane` (lane 0: the new leaf)
+  const hnode_t fresh = {kbits, vox, src, 0u};
   const hnode_t val = lane < m ? a : fresh;
   if (lane <= m) {
     if (dest < H::TOP) h.top[dest] = val;
@@ -487,11 +485,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   uint32_t npush = 0;
   bool ovf = false;
   for (uint32_t i = 0; i < npath; i++) {
-    const uint32_t src = path[i];
-    float maxd = scale * dbf[src];   // skeletontricks.pyx:393-395, f32 ops
-    maxd = maxd + constant;
-    const hnode_t fresh = {0u, src, src, __float_as_uint(maxd)};
-    if (!heap_push_wave(h, fresh, lane)) ovf = true;
+    if (!heap_push_wave(h, 0u, path[i], i, lane)) ovf = true;
     npush++;
   }
   const uint32_t sx = (uint32_t)g.sx, sxy = (uint32_t)g.sxy;
@@ -501,7 +495,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
   uint32_t count = 0;
   while (h.n > 0) {
     const hnode_t top = h.top[0];
-    const uint32_t vox = top.y, src = top.z;
+    const uint32_t vox = top.y, si = top.z;
     const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
     if (PROF) tt = clock64();
     heap_pop_wave(h, lane);
@@ -511,7 +505,9 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
     if (lane == 0) alive[vox] = 0;
     count++;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    const float maxd = __uint_as_float(top.w);
+    const uint32_t src = path[si];
+    float maxd = scale * dbf[src];   // skeletontricks.pyx:393-395, f32 ops
+    maxd = maxd + constant;
     const uint32_t z = vox / sxy, r = vox - z * sxy, y = r / sx, x = r - y * sx;
     const uint32_t oz = src / sxy, orr = src - oz * sxy, oy = orr / sx, ox = orr - oy * sx;
     // neighbour enumeration of dijkstra_invalidation.hpp:60-124 seen from the label's bounding box:
@@ -559,8 +555,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
       if (base < 64u || base + cnt > h.cap) {   // small heap (new leaves could be parents) or no room: one by one
         const int k = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const hnode_t one = {rdlane_u32(ndb, k), rdlane_u32(q, k), src, top.w};
-        if (!heap_push_wave(h, one, lane)) ovf = true;
+        if (!heap_push_wave(h, rdlane_u32(ndb, k), rdlane_u32(q, k), si, lane)) ovf = true;
         npush++;
         continue;
       }
@@ -575,7 +570,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
       const int c = climbers ? __ffsll((long long)climbers) - 1 : 64;   // first lane whose push climbs
       const unsigned long long run = c < 64 ? (m & ((1ull << c) - 1ull)) : m;
       if ((run >> lane) & 1ull) {
-        const hnode_t fresh = {ndb, q, src, top.w};
+        const hnode_t fresh = {ndb, q, si, 0u};
         if (leaf < H::TOP) h.top[leaf] = fresh;
         else h.node[leaf] = fresh;
       }
@@ -585,8 +580,7 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
       m &= ~run;
       if (c < 64) {
         m &= ~(1ull << c);
-        const hnode_t one = {rdlane_u32(ndb, c), rdlane_u32(q, c), src, top.w};
-        if (!heap_push_wave(h, one, lane)) ovf = true;
+        if (!heap_push_wave(h, rdlane_u32(ndb, c), rdlane_u32(q, c), si, lane)) ovf = true;
         npush++;
       }
     }
@@ -706,51 +700,18 @@ struct SweepGlobal {
   unsigned long long* cstate;   // one word per voxel, all zero on entry and on exit
   unsigned char* arena;         // event arenas (per label: kh_label_t.ev_offset, in units of 256 bytes)
   uint32_t lds_levels;          // labels with more levels keep their level words in the arena instead of LDS
-  uint32_t* park;               // nullptr: a call the sweep cannot certify runs on the heap in place; else see ParkCtl
-  const uint32_t* index;        // nullptr: workgroup b traces tasks[b]; else tasks[index[b]] (a resume launch)
 };
-
-// ---- parking ------------------------------------------------------------------------------------------------------
-// A call the sweep cannot certify is redone on the exact heap: ONE wave working for up to seconds.  Inside the path
-// kernel that wave sits in a 256-thread, 160-VGPR, 39-KiB-LDS workgroup slot whose other three waves wait at a barrier --
-// 55 % of the GPU's slot time at c3 (round 2).  With a park record the path kernel instead PARKS the label: its loop state
-// goes to its task record, its index into the queue below, and the workgroup ends.  A second kernel of 64-thread
-// workgroups (heap_server_kernel, 2 KiB of LDS, on another stream) takes parked labels from the queue as they arrive,
-// runs their heap call and lists them in the `served` list; the host polls that list and launches the path kernel again
-// over the newly served labels (on further streams), which resume behind the invalidation -- and may park again.  Nobody on
-// the device ever waits for anybody: the path kernel only appends and exits; the servers stay for the whole call of
-// run_labels -- an idle one looks at the queue every ~20 us (a hundred pollers on one cache line every microsecond would be
-// an L2 hot spot) and holds a quarter of a SIMD's registers and 2 KiB of LDS, nothing a path workgroup needs -- until the
-// host raises `stop`; one that has been idle for `patience` leaves on its own (never spin for ever), and the host starts
-// new ones when labels are parked and no server is left.
-// Record (u32 words): [0] parked (entries appended to the queue)  [1] taken (entries handed to servers)  [2] t_done (path
-// workgroups ended)  [3] t_total (path workgroups launched so far: host)  [4] idle exits (diagnostic)  [5] served (entries
-// appended to the served list)  [6] capacity of either list (host)  [7] overflow flag  [8] stop (host)  [9] servers that
-// have ended  [10..15] -, then queue[capacity], then served[capacity].  Queue entries start as ~0 = "not written yet".
-struct ParkCtl {
-  uint32_t q_count, q_taken, t_done, t_total, idle_exits, served, cap, overflow, stop, exited;
-  uint32_t pad[6];
-};
-static constexpr uint32_t KH_PARKED = 0xFFFFFFFFu;
-// kh_label_t.park_phase
-static constexpr uint32_t PARK_NONE = 0, PARK_SOMA = 1, PARK_LOOP = 2, PARK_DONE = 2;   // + PARK_DONE once the server has run the call
 
 // One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
-// certifies the call, the heap emulation otherwise -- by wave 0 in place, or, with can_park, by the heap server: then
-// KH_PARKED is returned (alive is as it was before the call) and the caller parks the label.  A call the sweep cannot
-// even try (no table for the label, path too long) always runs in place: such a label would park at every path.
-// Returns the number of voxels invalidated.  INPLACE = false (the path kernel that is launched with a park record) has no
-// heap code at all -- its registers are the sweep's -- and parks every call the sweep does not certify.
-template <bool PROF, bool INPLACE, class H>
+// certifies the call, the heap emulation (wave 0) otherwise.  Returns the number of voxels invalidated.
+template <bool PROF, class H>
 __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                                const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                                float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
-                                               uint32_t* sweep_stats, bool can_park) {
+                                               uint32_t* sweep_stats) {
   const int tid = threadIdx.x;
   bool ok = false;
-  bool tried = false;
   if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
-    tried = true;
     uint32_t cnt = 0;
     ok = sweep_ball(*sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt);
     if (tid == 0) {
@@ -771,15 +732,10 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   }
   if (!ok) {
     __syncthreads();
-    if constexpr (!INPLACE) {
-      return KH_PARKED;
-    } else {
-      if (tried && can_park) return KH_PARKED;
-      if (tid < 64) {
-        const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                                    &ctl->status, &ctl->u3, ctl->cyc3);
-        if (tid == 0) ctl->u1 = c;
-      }
+    if (tid < 64) {
+      const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+                                                  &ctl->status, &ctl->u3, ctl->cyc3);
+      if (tid == 0) ctl->u1 = c;
     }
   }
   __syncthreads();
@@ -822,10 +778,8 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.sh = swsh;
 }
 
-// (INPLACE: 2 workgroups per CU by registers instead of 3 -- with the heap code inside, 168 VGPRs meant 568 B of scratch
-// per lane and a path loop 1.6 x slower; this variant runs when there is no sweep, i.e. in tests and comparisons)
-template <bool PROF, bool INPLACE>
-__global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
+template <bool PROF, int TOPL>
+__global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,
@@ -838,13 +792,9 @@ __global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_la
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
   __shared__ uint32_t sweep_stats[5];
-  // (Heap<1>::TOP + 3) nodes for the heap emulation; the sweep's level words and lists use the same bytes
+  // (Heap<TOPL>::TOP + 3) nodes for the heap emulation; the sweep's level words and lists use the same bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
-  constexpr int TOPL = 1;
-  const uint32_t task_index = sg.index ? sg.index[blockIdx.x] : blockIdx.x;
-  kh_label_t* task = &tasks[task_index];
-  ParkCtl* park = reinterpret_cast<ParkCtl*>(sg.park);
-  const bool can_park = !INPLACE || park != nullptr;
+  kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
@@ -871,63 +821,38 @@ __global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_la
   const uint32_t* after = before + task->n_before;
   const bool soma = task->soma_mode != 0;
   const bool implicit = task->n_before == 0 && !soma;   // trace.py:160-172
-  // a resumed label (park_phase: the heap server has run the call the label parked at) picks its loop state up again
-  const uint32_t resume = task->park_phase;             // PARK_NONE, PARK_SOMA + PARK_DONE or PARK_LOOP + PARK_DONE
   uint32_t nb = implicit ? 1u : task->n_before;
   uint32_t na = task->n_after;
   uint32_t valid = nf;
-  uint32_t npaths = 0, nverts = 0, max_paths = 0;
-  if (resume != PARK_NONE) {
-    valid = task->park_valid; npaths = task->park_npaths; nverts = task->park_nverts; nb = task->park_nb; na = task->park_na;
-    max_paths = task->park_max_paths;
-  }
+  uint32_t npaths = 0, nverts = 0;
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
   if (tid == 0) {
-    // (a resumed label whose parked call failed on the server -- heap scratch too small -- stops right behind it)
-    ctl.status = resume != PARK_NONE ? task->status : 0u;
-    ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
+    ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
     sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top);
   }
   __syncthreads();
-  uint32_t parked = PARK_NONE, park_plen = 0;
-  bool finished = false;                                // trace.py:217-218: nothing to trace
-  if (resume != PARK_LOOP + PARK_DONE) {
-    if (soma) {
-      // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
-      uint32_t c;
-      if (resume == PARK_SOMA + PARK_DONE) {
-        c = task->park_count;
-      } else {
-        if (tid == 0) pverts[0] = root;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        c = invalidate<PROF, INPLACE, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                         heap, list, nf, sweep_stats, can_park);
-      }
-      if (c == KH_PARKED) { parked = PARK_SOMA; park_plen = 1; }
-      else valid -= c;                                    // trace.py:211 counts what is left
-    }
-    if (!parked) {
-      max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
-      if (nb + na >= max_paths) {                           // trace.py:217-218
-        finished = true;
-      } else if (fix_branching) {
-        if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
-      } else {
-        // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
-        sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
-      }
-    }
+  if (soma) {
+    // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
+    if (tid == 0) pverts[0] = root;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+                                          heap, list, nf, sweep_stats);   // trace.py:211 counts what is left
   }
-  bool redo = resume == PARK_LOOP + PARK_DONE;          // the first turn of the loop resumes behind its invalidation
-  while (!parked && !finished && (redo || ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths))) {
-    uint32_t plen = 0;
-    uint32_t* out = pverts + nverts;
-    if (redo) {
-      plen = task->park_plen;
-    } else {
+  const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
+  if (nb + na >= max_paths) {                           // trace.py:217-218
+    if (tid == 0) { task->n_paths = 0; task->n_vertices = 0; task->status |= ctl.status; }
+    return;
+  }
+  if (fix_branching) {
+    if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
+  } else {
+    // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
+    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
+  }
+  __syncthreads();
+  while ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths) {
     // ---- target selection, trace.py:225-230
     t0 = clock64();
     uint32_t target;
@@ -956,11 +881,13 @@ __global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_la
     }
     // ---- railroad, trace.py:240-242
     t_target += clock64() - t0; t0 = clock64();
+    uint32_t plen = 0;
     if (nverts >= pcap || npaths >= pcap) {
       if (tid == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW);
       __syncthreads();
       break;
     }
+    uint32_t* out = pverts + nverts;
     if (!fix_branching) {
       // dijkstra3d.path_from_parents (trace.py:244): walk target -> root, return root -> target
       if (tid == 0) ctl.u0 = 0;
@@ -1042,19 +969,11 @@ __global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_la
       __syncthreads();
       if (plen == 0) break;
     }
-    t_rail += clock64() - t0;
-    }
     // ---- invalidation, trace.py:253-259
-    t0 = clock64();
-    if (redo) {
-      valid -= task->park_count;                          // the call the label parked at, done by the heap server
-      redo = false;
-    } else if (valid > 0) {
-      const uint32_t c = invalidate<PROF, INPLACE, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list,
-                                                      nf, sweep_stats, can_park);
-      if (c == KH_PARKED) { parked = PARK_LOOP; park_plen = plen; break; }
-      valid -= c;
-    }
+    t_rail += clock64() - t0; t0 = clock64();
+    if (valid > 0)
+      valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list, nf,
+                                            sweep_stats);
     // ---- rails, trace.py:261-263
     t_inval += clock64() - t0;
     if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
@@ -1065,128 +984,26 @@ __global__ __launch_bounds__(256, INPLACE ? 2 : 3) void trace_paths_kernel(kh_la
     if (ctl.status) break;
   }
   __syncthreads();
-  if (!parked && !fix_branching && !finished) {  // leave dist = +inf behind
+  if (!fix_branching) {  // leave dist = +inf behind
     for (uint32_t i = tid; i < nf; i += nthr) st_f32_l2(&dist[list[i]], KH_INF);
   }
   if (tid == 0) {
-    if (parked) {
-      task->park_phase = parked;
-      task->park_valid = valid; task->park_npaths = npaths; task->park_nverts = nverts; task->park_nb = nb; task->park_na = na;
-      task->park_max_paths = max_paths; task->park_plen = park_plen;
-    } else {
-      task->park_phase = PARK_NONE;
-      task->n_paths = finished ? 0u : npaths;
-      task->n_vertices = finished ? 0u : nverts;
-    }
-    // (counters accumulate over the launches of a label that parked; the host zeroes them)
+    task->n_paths = npaths;
+    task->n_vertices = nverts;
     task->status |= ctl.status;
-    task->stat_settled += ctl.u2;
-    task->stat_heap_pushes += ctl.u3;
-    task->cyc_target += (uint32_t)(t_target >> 10);
-    task->cyc_rail += (uint32_t)(t_rail >> 10);
-    task->cyc_inval += (uint32_t)(t_inval >> 10);
-    if (PROF) task->cyc_pop += (uint32_t)(ctl.cyc3[0] >> 10);
-    if (PROF) task->cyc_push += (uint32_t)(ctl.cyc3[1] >> 10);
-    if (PROF) task->cyc_fire += (uint32_t)(ctl.cyc3[2] >> 10);
-    task->stat_sweep_calls += sweep_stats[0];
-    task->stat_sweep_bails += sweep_stats[1];
-    task->stat_sweep_levels += sweep_stats[2];
-    task->stat_sweep_events += sweep_stats[3];
-    task->stat_sweep_why |= sweep_stats[4];
-  }
-  if (park != nullptr && tid == 0) {
-    // the task record (and, through the barrier above, the workgroup's alive / pdrf / path writes) must be visible to the
-    // server before the label shows up in the queue, and the queue entry before this workgroup counts as done
-    __threadfence();
-    if (parked) {
-      uint32_t* queue = sg.park + 16;
-      const uint32_t slot = atomicAdd(&park->q_count, 1u);
-      if (slot < park->cap) __hip_atomic_store(&queue[slot], task_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      else atomicOr(&park->overflow, 1u);       // (the host sizes the lists for 8 parks per label; it raises on this flag)
-      __threadfence();
-    }
-    atomicAdd(&park->t_done, 1u);
-  }
-}
-
-// The heap server: 64-thread workgroups that take parked labels in queue order and run the invalidation call they parked at
-// on the exact heap (invalidate_ball), then list the label as served.  An entry is taken with a CAS on `taken` only when
-// it exists (taken < parked), so no ticket is ever lost to a server that leaves.  A server leaves when the host raises
-// `stop`, or when it has been idle for `patience`.
-template <int TOPL>
-__global__ __launch_bounds__(64) void heap_server_kernel(kh_label_t* tasks, const uint32_t* __restrict__ nbrmask, Geometry g,
-                                                         const float* __restrict__ dbf, uint8_t* alive, float scale,
-                                                         float constant, hnode_t* heap_nodes, uint32_t* path_vertices,
-                                                         uint32_t* park_words, unsigned long long patience) {
-  __shared__ Geometry geo;
-  __shared__ uint32_t sh_status, sh_pushes, sh_ticket, sh_go;
-  __shared__ unsigned long long cyc3[3];
-  extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
-  ParkCtl* park = reinterpret_cast<ParkCtl*>(park_words);
-  const uint32_t cap = park->cap;
-  const uint32_t* queue = park_words + 16;
-  uint32_t* served_list = park_words + 16 + cap;
-  const int lane = threadIdx.x;
-  if (lane == 0) geo = g;
-  __syncthreads();
-  for (;;) {
-    if (lane == 0) {
-      const unsigned long long t_start = wall_clock64();
-      uint32_t go = 2, ticket = 0;                        // go 1: entry taken, 0: leave, 2: keep looking
-      while (go == 2) {
-        if (__hip_atomic_load(&park->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
-        const uint32_t k = __hip_atomic_load(&park->q_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t c = __hip_atomic_load(&park->q_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (c > cap) c = cap;
-        if (k < c) {
-          if (atomicCAS(&park->q_taken, k, k + 1u) == k) { ticket = k; go = 1; }
-          continue;
-        }
-        if (wall_clock64() - t_start > patience) { atomicAdd(&park->idle_exits, 1u); go = 0; break; }
-        for (int i = 0; i < 6; i++) __builtin_amdgcn_s_sleep(127);      // ~20 us
-      }
-      if (go == 0) atomicAdd(&park->exited, 1u);
-      if (go == 1)    // (the appender bumps the count first and writes the entry right after)
-        while (__hip_atomic_load(&queue[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);
-      sh_ticket = ticket;
-      sh_go = go;
-    }
-    __syncthreads();
-    if (sh_go == 0u) return;
-    // what the path kernel wrote for this label (task record, path vertices, restored alive bytes) is read with ordinary
-    // loads below: drop whatever this CU's vector cache still holds from an earlier call
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const uint32_t task_index = __hip_atomic_load(&queue[sh_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    kh_label_t* task = &tasks[task_index];
-    const uint32_t phase = task->park_phase;
-    Heap<TOPL> heap;
-    heap.node = heap_nodes + task->heap_offset;
-    heap.top = (lds_hnode_t*)heap_top;
-    heap.cap = task->heap_capacity;
-    heap.n = 0;
-    heap_init_lane(heap, lane);
-    if (lane == 0) { sh_status = 0; sh_pushes = 0; cyc3[0] = cyc3[1] = cyc3[2] = 0; }
-    __syncthreads();
-    uint32_t* pverts = path_vertices + task->path_offset;
-    const bool soma_call = phase == PARK_SOMA;
-    const uint32_t* path = soma_call ? pverts : pverts + task->park_nverts;
-    const long long t_call = clock64();
-    const uint32_t c = invalidate_ball<false, Heap<TOPL>>(geo, task, nbrmask, dbf, alive, path, task->park_plen,
-                                                          soma_call ? task->soma_scale : scale,
-                                                          soma_call ? task->soma_const : constant, heap, &sh_status, &sh_pushes, cyc3);
-    __syncthreads();
-    if (lane == 0) {
-      task->park_count = c;
-      task->cyc_fire += (uint32_t)((unsigned long long)(clock64() - t_call) >> 10);   // kilo-cycles on the heap server
-      task->status |= sh_status;
-      task->stat_heap_pushes += sh_pushes;
-      task->park_phase = phase + PARK_DONE;
-      __threadfence();                                    // the record and the alive bytes before the label is listed
-      const uint32_t at = atomicAdd(&park->served, 1u);
-      __hip_atomic_store(&served_list[at], task_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __threadfence();
-    __syncthreads();
+    task->stat_settled = ctl.u2;
+    task->stat_heap_pushes = ctl.u3;
+    task->cyc_target = (uint32_t)(t_target >> 10);
+    task->cyc_rail = (uint32_t)(t_rail >> 10);
+    task->cyc_inval = (uint32_t)(t_inval >> 10);
+    if (PROF) task->cyc_pop = (uint32_t)(ctl.cyc3[0] >> 10);
+    if (PROF) task->cyc_push = (uint32_t)(ctl.cyc3[1] >> 10);
+    task->cyc_fire = (uint32_t)(ctl.cyc3[2] >> 10);
+    task->stat_sweep_calls = sweep_stats[0];
+    task->stat_sweep_bails = sweep_stats[1];
+    task->stat_sweep_levels = sweep_stats[2];
+    task->stat_sweep_events = sweep_stats[3];
+    task->stat_sweep_why = sweep_stats[4];
   }
 }
 
@@ -1217,8 +1034,8 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
     sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top);
   }
   __syncthreads();
-  const uint32_t c = invalidate<false, true, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                               lists + task->list_offset, nf, sweep_stats, false);
+  const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+                                               lists + task->list_offset, nf, sweep_stats);
   if (tid == 0) {
     *invalidated = (long long)c;
     task->status |= ctl.status;
@@ -1348,13 +1165,6 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
 }
 
 namespace kh {
-static size_t trace_lds_bytes(const SweepGlobal& sg, uint32_t max_nlev) {
-  // (the variant launched with a park record runs no heap: its LDS is the sweep's alone)
-  size_t lds = sg.park ? (size_t)SW_CHAIN * 4 : (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
-  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
-  if (sg.rank && swl > lds) lds = swl;
-  return lds;
-}
 template <bool PROF>
 static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
@@ -1362,27 +1172,22 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                         int fix_branching, const SweepGlobal& sg, uint32_t max_nlev) {
   if (count <= 0) return KH_OK;
-  const size_t lds = trace_lds_bytes(sg, max_nlev);
+  size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
+  if (sg.rank && swl > lds) lds = swl;
   {
     // More than 48 KiB of dynamic LDS has to be allowed per kernel.  The attribute belongs to the function, not to the
     // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
     // launch can ask for -- so that a concurrent caller never lowers it under somebody else's launch.
     const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
-    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
-    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, false>),
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
   const char* thr_env = getenv("KH_TRACE_THREADS");   // developer knob
   const unsigned nthreads = thr_env ? (unsigned)atoi(thr_env) : 256u;
-  if (sg.park)   // every uncertified call goes to the heap server: the variant without any heap code
-    hipLaunchKernelGGL((trace_paths_kernel<PROF, false>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
-                       g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                       path_lengths, fix_branching, sg);
-  else
-    hipLaunchKernelGGL((trace_paths_kernel<PROF, true>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
-                       g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                       path_lengths, fix_branching, sg);
+  hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
+                     g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
+                     path_lengths, fix_branching, sg);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -1419,12 +1224,10 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
                               void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                               const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                              uint64_t* cstate, void* event_arena, int flags, int fix_branching,
-                              uint32_t* park, const uint32_t* task_index, void* stream) {
+                              uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
-  if (park && ((uintptr_t)park & 63) != 0) { set_error("kh_trace_paths: the park record must be 64-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
@@ -1441,8 +1244,6 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
-  sg.park = park;
-  sg.index = task_index;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
@@ -1451,27 +1252,6 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
               : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                     scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
                                     (uint32_t)max_nlev);
-}
-
-extern "C" int kh_heap_server(kh_label_t* tasks, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
-                              float wz, const float* dbf, uint8_t* alive, float scale, float constant, void* heap_nodes,
-                              uint32_t* path_vertices, uint32_t* park, int64_t nblocks, double patience_seconds, void* stream) {
-  if (int rc2 = require_device()) return rc2;
-  if (!tasks || !nbrmask || !dbf || !alive || !heap_nodes || !path_vertices || !park || nblocks <= 0 || nblocks > 65536 ||
-      sx * sy * sz >= (1ll << 32) || ((uintptr_t)heap_nodes & 15) != 0 || ((uintptr_t)park & 63) != 0 || !(patience_seconds > 0)) {
-    set_error("kh_heap_server: bad arguments");
-    return KH_EINVAL;
-  }
-  Geometry g;
-  make_geometry(g, sx, sy, sz, wx, wy, wz);
-  const size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
-  KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&heap_server_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-  const unsigned long long patience = (unsigned long long)(patience_seconds * 1e8);   // wall_clock64 ticks at 100 MHz
-  hipLaunchKernelGGL((heap_server_kernel<1>), dim3((unsigned)nblocks), dim3(64), lds, (hipStream_t)stream, tasks, nbrmask, g, dbf,
-                     alive, scale, constant, (hnode_t*)heap_nodes, path_vertices, park, patience);
-  KH_LAUNCH_CHECK();
-  return KH_OK;
 }
 
 extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,
@@ -1498,8 +1278,6 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
-  sg.park = nullptr;
-  sg.index = nullptr;
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (level_rank && swl > lds) lds = swl;

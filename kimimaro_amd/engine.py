@@ -58,16 +58,9 @@ class Engine:
         # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
         self.torch.cuda.set_device(self.device)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
-        self._side = None     # three more streams: heap servers, resume launches, polling (created on first use)
-        self.split_slots = 0  # (rounds 1-2: the biggest labels on a second stream; superseded by the heap server)
-        # Calls the sweep cannot certify go to the heap server (csrc/trace.hip "parking"): 64-thread workgroups beside the
-        # path kernel instead of one busy wave inside a 256-thread path workgroup.  False: the heap runs in place.
-        self.park = os.environ.get("KH_PARK", "1") != "0"
-        self.park_servers = int(os.environ.get("KH_PARK_SERVERS", "256"))   # server workgroups per launch (one wave each)
-        self.park_patience = float(os.environ.get("KH_PARK_PATIENCE", "20.0"))   # seconds a server workgroup may sit idle before it leaves (csrc/trace.hip)
-        self.park_poll = float(os.environ.get("KH_PARK_POLL", "0.002"))   # seconds between two looks at the served list
-        self.last_rounds = 0                # launches of the path kernel the last run_labels call needed
-        self.sweep_force_bail = False       # tests: every call of the sweep bails at once (radius limit 0) -> every call parks
+        self._side = None     # second stream: the biggest labels run there while the others are collected
+        self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
+        self.split_min_voxels = 16384       # ... if they have at least this many voxels
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
@@ -279,7 +272,7 @@ class Engine:
         _abi.check(lib.kh_scatter_lists(P(d_cc), 4, nvox, P(d_slot), 1, P(d_off), P(d_cur), P(d_lists), st))
         _abi.check(lib.kh_neighbor_mask(P(d_cc), 4, shape[0], shape[1], shape[2], P(d_nbr), st))
         ctx.update(d_slot=d_slot, d_lists=d_lists, d_nbr=d_nbr, d_queues=self.empty(4 * (cnt + 64), t.int32),
-                   d_heap=self.empty(2 * hcap + 128, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
+                   d_heap=self.empty(2 * hcap, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
         d_rank, rdims, max_nlev, ev_units = None, (0, 0, 0), 0, 0
         rmax = float(np.float32(rmax))
         if self.sweep and cnt > 0 and np.isfinite(rmax) and rmax > 0:
@@ -372,8 +365,7 @@ class Engine:
         q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
         # heap / path scratch are sized for the common case; a label that overflows them is traced again on its own
         # with `scratch_scale` times as much (below) -- the reference has no such limits
-        # (the sweep's lists live here too; the first 2047 slots of a heap are in LDS, slot 2047 must exist: csrc/trace.hip Heap)
-        hcap = np.maximum(np.maximum((3 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256), 2304)
+        hcap = np.maximum((3 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256)  # (the sweep's lists live here too)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
         pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
@@ -425,7 +417,7 @@ class Engine:
                 if ev_total >= 2 ** 32:
                     raise ValueError("kimimaro_amd: event arena offsets exceed 32 bits; shard the labels")
                 tasks["nlev"] = nlev
-                tasks["sweep_rmax"] = np.where(ok, rmax_t if not self.sweep_force_bail else 0.0, 0).astype(np.float32)
+                tasks["sweep_rmax"] = np.where(ok, rmax_t, 0).astype(np.float32)
                 tasks["ev_offset"] = ev_off
                 tasks["ev_chunks"] = np.where(nlev > 0, chunks, 0)
                 tasks["ev_shift"] = shift
@@ -497,111 +489,25 @@ class Engine:
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
-        d_heap = self.empty(2 * int(hcap.sum()) + 128, t.int64)  # 16-byte nodes (+ slack: a pop reads one node past its array)
+        d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
         d_cstate = t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device)
         d_arena = self.empty(max(ev_total, 1) * 32 + 32, t.int64)   # units of 256 bytes, 256-byte aligned start
         arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
+        # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
+        # are consumed incrementally they go to a second stream and the others are collected while they still run
+        n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
         prof = 1 if self.profile else 0
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
-        use_park = bool(self.park) and d_rank is not None
-        n_srv = int(max(1, min(self.park_servers, nl))) if use_park else 0
-        # park record (csrc/trace.hip "parking"): 16 header words, the queue of parked labels, the list of served labels
-        pcap_q = 8 * nl + 4096
-        d_park = None
-        if use_park:
-            d_park = t.full((16 + 2 * pcap_q,), -1, dtype=t.int32, device=self.device)
-        isz = _abi.LABEL_T.itemsize
 
         def launch(first, count, stream):
-            """the path loop of tasks [first, first + count), to completion.  With the heap server: a label parks at a call
-            the sweep cannot certify, a server workgroup runs that call and lists the label as served, this thread polls
-            the list and launches the path kernel again over the newly served labels -- until every label is through."""
-            tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * isz)
-
-            def paths(ntasks, park_ptr, index_ptr, strm):
-                _abi.check(lib.kh_trace_paths(tasks_ptr, ntasks, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
-                                              P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
-                                              np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
-                                              P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
-                                              P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), park_ptr, index_ptr, strm))
-
-            self.last_rounds = 1
-            if not use_park:
-                paths(count, C.c_void_p(0), C.c_void_p(0), stream)
-                return
-            import time as _t
-            trace_t = os.environ.get("KH_PARK_TRACE") == "1"      # developer probe: time line of the launches
-            t_0 = _t.perf_counter()
-            log = []
-            cur = t.cuda.current_stream(self.device)
-            if self._side is None:
-                self._side = [t.cuda.Stream(device=self.device) for _ in range(6)]
-            side, poll = self._side[0], self._side[1]      # servers / this thread's look at the record
-            res = self._side[2:]                             # resume launches, round robin: a long one must not hold up the next
-
-            launched_servers = [0]
-
-            def servers(n):
-                _abi.check(lib.kh_heap_server(tasks_ptr, P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_dbf), P(d_alive),
-                                              np.float32(params["scale"]), np.float32(params["const"]), P(d_heap), P(d_pverts),
-                                              P(d_park), int(n), float(self.park_patience), C.c_void_p(side.cuda_stream)))
-                launched_servers[0] += int(n)
-
-            def poke(word, value):
-                with t.cuda.stream(poll):
-                    d_park[word:word + 1].copy_(t.from_numpy(np.array([value], dtype=np.int32)))
-                    poll.synchronize()
-
-            hdr = np.zeros(16, dtype=np.int32)
-            t_total = count
-            hdr[3], hdr[6] = t_total, pcap_q
-            d_park[:16].copy_(t.from_numpy(hdr))
-            for s_ in self._side:
-                s_.wait_stream(cur)               # (behind the set-up of the record and of the fields, not behind the path kernel)
-            paths(count, P(d_park), C.c_void_p(0), stream)
-            servers(min(n_srv, count))
-            resumed = 0
-            served_base = d_park.data_ptr() + 4 * (16 + pcap_q)
-            head = hdr.view(np.uint32)
-            try:
-                while True:
-                    _t.sleep(self.park_poll)
-                    with t.cuda.stream(poll):
-                        head = d_park[:16].cpu().numpy().view(np.uint32)
-                    if int(head[7]):
-                        raise _abi.KimiHipError("kimimaro_amd: more than 8 parked calls per label on average (park lists full)")
-                    served = int(head[5])
-                    launched = False
-                    if served > resumed:
-                        with t.cuda.stream(poll):
-                            lst = d_park[16 + pcap_q + resumed:16 + pcap_q + served].cpu().numpy()
-                        gap = np.flatnonzero(lst == -1)         # (a server bumps the count first and writes the entry right after)
-                        n_ok = int(gap[0]) if gap.size else int(lst.size)
-                        if n_ok > 0:
-                            t_total += n_ok
-                            poke(3, t_total)
-                            rs = res[self.last_rounds % len(res)]
-                            paths(n_ok, P(d_park), C.c_void_p(served_base + 4 * resumed), C.c_void_p(rs.cuda_stream))
-                            resumed += n_ok
-                            self.last_rounds += 1
-                            launched = True
-                            if trace_t:
-                                log.append(("resume", n_ok, round(_t.perf_counter() - t_0, 3)))
-                    backlog = int(head[0]) - int(head[1])
-                    if backlog > 0 and launched_servers[0] - int(head[9]) <= 0:
-                        servers(min(n_srv, backlog))           # every server had left (idle for too long)
-                    if not launched and int(head[2]) >= t_total and int(head[0]) == served == resumed:
-                        break                                  # every path workgroup has ended and nothing is parked
-            finally:
-                poke(8, 1)                                     # the servers end
-                cur.wait_stream(side)
-                for s_ in res:
-                    cur.wait_stream(s_)
-            if trace_t:
-                log.append(("done", "parked", int(head[0]), "idle_exits", int(head[4]), round(_t.perf_counter() - t_0, 3)))
-                print("PARKTRACE", log[:6], "...", log[-6:], "launches", self.last_rounds, file=sys.stderr, flush=True)
+            tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
+            _abi.check(lib.kh_trace_paths(tasks_ptr, count, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
+                                          P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
+                                          np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
+                                          P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
+                                          P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), stream))
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
@@ -650,6 +556,31 @@ class Engine:
                                    sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
                                    consume=sink, scratch_scale=scratch_scale * 8)
 
+        if consume is not None and 0 < n_large < nl:
+            # The largest labels are the tail of the run.  They go to a second stream (as large-LDS workgroups); the
+            # rest runs on the caller's stream and its results are copied back and handed to `consume` (the Skeleton
+            # assembly on the host) while the big labels are still being traced.
+            cur = t.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = t.cuda.Stream(device=self.device)
+            self._side.wait_stream(cur)
+            launch(0, n_large, C.c_void_p(self._side.cuda_stream))
+            try:
+                launch(n_large, nl - n_large, st)
+                small = collect(n_large, nl)
+                consume(small)                  # overlaps the big labels' kernel: no device-wide sync in here
+            finally:
+                cur.wait_stream(self._side)     # the scratch of this call must outlive the side stream's kernel
+                if sys.exc_info()[0] is not None:
+                    self._side.synchronize()
+            big = collect(0, n_large)
+            mark("paths")
+            consume(big)
+            mark("d2h")
+            tasks_done = np.concatenate([big["tasks"], small["tasks"]])
+            run_retry(consume)
+            LAST_TASKS = tasks_done
+            return None
         launch(0, nl, st)
         mark("paths")
         res = collect(0, nl)

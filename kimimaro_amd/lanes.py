@@ -25,7 +25,7 @@ def ensure_hw_queues(width):
     another lane's seconds-long path kernel (profiles/r02b_inflight_timeline.txt).  The HIP runtime reads
     GPU_MAX_HW_QUEUES once, when it initialises (default 4): set it here while that is still possible, otherwise verify it
     and fail loudly rather than run with the silently serialised lanes that were measured as broken."""
-    want = min(32, max(16, 4 * int(width) + 4))   # a lane = its own stream + three of its engine (servers, resumes, polling)
+    want = max(8, 2 * int(width))
     have = os.environ.get("GPU_MAX_HW_QUEUES")
     try:
         import torch
@@ -64,11 +64,6 @@ class Lanes:
             def stream_factory(eng):
                 return _StreamScope(torch, eng)
         self.engines = [engine_factory() for _ in range(self.width)]
-        for e in self.engines:
-            # heap-server workgroups per launch (csrc/trace.hip "parking"): about a thousand on the GPU over all lanes -- each
-            # holds 8 KiB of LDS on a CU that path workgroups (38 KiB each) share
-            if hasattr(e, "park_servers"):
-                e.park_servers = max(32, min(e.park_servers, 1024 // self.width))
         self._scopes = [stream_factory(e) if stream_factory is not None else None for e in self.engines]
 
     def run(self, job, n, width=None, stagger=0.0):

@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # before the HIP runtime starts: kimimaro_amd.lanes needs a queue per stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts: kimimaro_amd.lanes needs a queue per stream
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

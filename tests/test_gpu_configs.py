@@ -70,32 +70,6 @@ def test_shard_small_volume_two_and_three_ranks(eng):
             _same(got[k], want[k], k)
 
 
-@pytest.mark.parametrize("patience", [3.0, 1e-7])
-def test_every_call_parked_and_served(patience):
-    """the parking machinery under stress: with the sweep forced to bail at once EVERY invalidation call parks its label, the
-    heap server runs it, and the label resumes in the next launch of the path kernel -- as many launches as the longest
-    label has paths.  patience ~ 0: the servers leave as soon as they find nothing to do, so most calls are served by the
-    launch the host adds for labels left parked.  Skeletons equal to the oracle's either way."""
-    import kimimaro_amd
-    from kimimaro_amd.engine import Engine
-    from oracle import pipeline as P
-    from shapes import voronoi_labels
-    an = (16, 16, 40)
-    lab = voronoi_labels((96, 96, 64), 24, seed=44, pts_per_label=5, step=12.0, anisotropy=an)
-    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
-    params["const"] = 64
-    e = Engine()
-    e.sweep_force_bail = True
-    e.park_patience = patience
-    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=300, fix_borders=True, fix_branching=True,
-                                   progress=False, _engine=e)
-    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=300, fix_borders=True, fix_branching=True)
-    assert e.last_rounds >= 3                     # labels with several paths: park, resume, park again, ...
-    assert sorted(got) == sorted(want) and len(want) > 8
-    for k in want:
-        _same(got[k], want[k], k)
-
-
 @pytest.fixture(scope="module")
 def c2():
     import bench
