@@ -466,9 +466,18 @@ def main():
              "voxels_of_labels_with_fallback": int(tk["count"][tk["stat_sweep_bails"] > 0].astype(np.int64).sum()),
              "voxels": int(tk["count"].astype(np.int64).sum()),
              "note": "order-free level sweep (csrc/sweep.h); a call it cannot certify is redone by the exact heap emulation"}
+    # HBM traffic of that kernel from the committed counter passes (tools/pmc_trace_r3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs over one c3 volume, FETCH x 2 on gfx950): only valid for c3
+    tr_traffic, tr_src = None, None
+    tpmc = os.path.join(ROOT, "profiles", "r03_c3_trace_pmc.json")
+    if args.workload == "c3" and os.path.exists(tpmc):
+        for name, v in json.load(open(tpmc))["kernels"].items():
+            if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected"):
+                tr_traffic, tr_src = v["hbm_bytes_corrected"], "profiles/r03_c3_trace_pmc.json (PMC passes, not live)"
     roofline_trace = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / tr_s / 1e9, 3),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / tr_s / 1e9 / HBM_PEAK_GBS, 6),
-                      "traffic": None, "seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
+                      "traffic": tr_traffic, "traffic_source": tr_src, "bytes_per_launch": int(trace_bytes),
+                      "seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
                       "note": "latency bound: level-synchronous sweep per label; the wall clock is the largest label whose call "
                               "needed the exact heap emulation"}
 
