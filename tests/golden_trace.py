@@ -23,3 +23,21 @@ def cases():
             paths.append(verts[pos:pos + n])
             pos += n
         yield i, np.asfortranarray(mask), tuple(float(a) for a in z["an_%d" % i]), kw, extra, paths
+
+
+def tie_cases():
+    """tests/golden/trace_paths_ties.npz: the runs of the reference's trace() that the oracle does NOT reproduce, because
+    numpy's unstable argsort in CachedTargetFinder (skeletontricks.pyx:1001-1006) broke a DAF tie the other way (SURVEY
+    0-7a).  Yields (i, mask, anisotropy, kw, extra, reference paths, index of the first path that differs)."""
+    z = np.load(os.path.join(G, "trace_paths_ties.npz"))
+    for i in range(int(z["n"])):
+        shape = tuple(int(v) for v in z["shape_%d" % i])
+        mask = np.unpackbits(z["mask_%d" % i])[: int(np.prod(shape))].reshape(shape, order="F").astype(np.uint8)
+        kw = dict(ast.literal_eval(str(z["kw_%d" % i])))
+        extra = dict(ast.literal_eval(str(z["extra_%d" % i])))
+        verts = z["verts_%d" % i].astype(np.int64)
+        paths, pos = [], 0
+        for n in z["lens_%d" % i].tolist():
+            paths.append(verts[pos:pos + n])
+            pos += n
+        yield i, np.asfortranarray(mask), tuple(float(a) for a in z["an_%d" % i]), kw, extra, paths, int(z["first_diff_%d" % i])

@@ -256,6 +256,35 @@ def test_trace_control_flow_matches_reference_trace():
     assert seen >= 20 and len(kinds) >= 5
 
 
+def test_documented_differences_from_the_reference_are_daf_ties():
+    """The 6 runs of the reference's own trace() that the oracle (and the HIP path) do NOT reproduce
+    (tests/golden/trace_paths_ties.npz).  What the difference is, shown on each of them: the path lists agree up to path k;
+    path k of the reference and path k of the oracle end in DIFFERENT targets that have the SAME distance from the root --
+    the reference's CachedTargetFinder sorts with numpy's unstable argsort (skeletontricks.pyx:1001-1006), which may hand
+    out either; oracle and HIP take the larger linear index."""
+    from oracle import pipeline as P
+    from golden_trace import tie_cases
+    seen = 0
+    for i, mask, an, kw, extra, ref, k in tie_cases():
+        dbf = K.edt(mask, an, black_border=bool(np.all(mask)))
+        call = {kk: (list(v) if isinstance(v, list) else v) for kk, v in extra.items()}
+        mine = P.trace(mask.astype(bool), dbf, anisotropy=an, return_paths=True, **kw, **call)
+        assert k < len(mine) and k < len(ref)
+        for a, b in zip(mine[:k], ref[:k]):
+            np.testing.assert_array_equal(np.asarray(a), b, err_msg="case %d: paths before the tie" % i)
+        # a path ends at its target in both branching modes (railroad: rail end first; parents: root first)
+        t_mine, t_ref = tuple(int(v) for v in np.asarray(mine[k])[-1]), tuple(int(v) for v in ref[k][-1])
+        assert t_mine != t_ref, i
+        root = call.get("root") or P.find_root(mask, an)
+        daf, _ = K.euclidean_distance_field(mask, tuple(int(v) for v in root), an)
+        assert daf[t_mine] == daf[t_ref], (i, daf[t_mine], daf[t_ref])          # the tie
+        sx, sy = mask.shape[0], mask.shape[1]
+        lin = lambda p: p[0] + sx * (p[1] + sy * p[2])
+        assert lin(t_mine) > lin(t_ref), i                                       # canonical rule: the larger index
+        seen += 1
+    assert seen == 6
+
+
 def test_legacy_find_target_golden():
     """the definition kh_find_target implements (first maximum of the x-outermost / z-innermost scan, strict > from -inf),
     restated in numpy, against the compiled reference's vectors (tests/golden/legacy_targets.npz) -- and first_label."""
