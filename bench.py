@@ -472,8 +472,9 @@ def main():
     tpmc = os.path.join(ROOT, "profiles", "r03_c3_trace_pmc.json")
     if args.workload == "c3" and os.path.exists(tpmc):
         for name, v in json.load(open(tpmc))["kernels"].items():
-            if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected"):
-                tr_traffic, tr_src = v["hbm_bytes_corrected"], "profiles/r03_c3_trace_pmc.json (PMC passes, not live)"
+            if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected_per_volume"):
+                tr_traffic = v["hbm_bytes_corrected_per_volume"]
+                tr_src = "profiles/r03_c3_trace_pmc.json (PMC passes over one volume, not live; all path-kernel launches of the volume)"
     roofline_trace = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / tr_s / 1e9, 3),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / tr_s / 1e9 / HBM_PEAK_GBS, 6),
                       "traffic": tr_traffic, "traffic_source": tr_src, "bytes_per_launch": int(trace_bytes),

@@ -33,20 +33,28 @@ for log in sorted(glob.glob(os.path.join(src, "pmc_trace_*.log"))):
         algo = int(m.group(1))
 out = {"source": "rocprofv3 --pmc <one set per run> --kernel-trace -- python tools/trace_only.py c3 (tools/pmc_trace_r3.sh); " + pre,
        "units": "per launch (mean over the launches of the run); FETCH_SIZE / WRITE_SIZE are reported in KiB and converted to bytes",
-       "correction": "FETCH_SIZE on gfx950 counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section; calibrated in round 1 on "
-                     "edt_x_kernel): x2.  WRITE_SIZE needs none.",
+       "correction": "FETCH_SIZE = memory-side read requests x 64 B; on gfx950 a full 128-B line request is tallied as 64 B (MI355X_MICROARCH.md, "
+                     "HBM section; calibrated in round 1 on the streaming edt_x_kernel): x2 = fetch_bytes_corrected, exact if every miss of these "
+                     "scattered narrow accesses fills a whole 128-B line (uncalibrated for this pattern: the raw figure is given too).  WRITE_SIZE "
+                     "as reported.  Infinity-Cache hits are counted (these are the L2's fabric-side requests).  *_per_volume = mean per launch x "
+                     "launches of the run (one c3 volume; the largest 128 labels run as a launch of their own on a second stream).",
        "algorithmic_bytes_path_kernel": algo, "kernels": {}}
 for k, ctr in acc.items():
     e = {c: sum(v) / len(v) for c, v in ctr.items()}
     e["launches_seen"] = max(len(v) for v in ctr.values())
+    nl = {c: len(v) for c, v in ctr.items()}
     if "FETCH_SIZE" in e:
+        e["fetch_bytes_raw"] = e["FETCH_SIZE"] * 1024.0
         e["fetch_bytes_corrected"] = e["FETCH_SIZE"] * 1024.0 * 2.0
     if "WRITE_SIZE" in e:
         e["write_bytes"] = e["WRITE_SIZE"] * 1024.0
     if "fetch_bytes_corrected" in e and "write_bytes" in e:
         e["hbm_bytes_corrected"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+        e["hbm_bytes_corrected_per_volume"] = e["fetch_bytes_corrected"] * nl["FETCH_SIZE"] + e["write_bytes"] * nl["WRITE_SIZE"]
+        e["hbm_bytes_raw_per_volume"] = e["fetch_bytes_raw"] * nl["FETCH_SIZE"] + e["write_bytes"] * nl["WRITE_SIZE"]
         if algo and "trace_paths" in k:
-            e["traffic_over_algorithmic"] = e["hbm_bytes_corrected"] / algo
+            e["traffic_over_algorithmic"] = e["hbm_bytes_corrected_per_volume"] / algo
+            e["traffic_over_algorithmic_raw"] = e["hbm_bytes_raw_per_volume"] / algo
     if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
         e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
     if "SQ_WAVE_CYCLES" in e and "SQ_BUSY_CYCLES" in e and e["SQ_BUSY_CYCLES"] > 0:
