@@ -128,6 +128,47 @@ def test_oracle_pool_equals_serial_oracle():
         np.testing.assert_array_equal(a[k].radii, b[k].radii)
 
 
+def test_batch_consolidation_equals_the_per_label_one():
+    """intake.consolidate_paths_batch (all labels of a result group in one sort) against consolidate_paths label by label:
+    random paths with shared vertices, empty slots, one-vertex paths (dropped: no edge refers to them), repeated vertices."""
+    from kimimaro_amd.intake import consolidate_paths, consolidate_paths_batch
+    rng = np.random.default_rng(3)
+    shape = (40, 36, 20)
+    verts, lens, voff, loff = [], [], [0], [0]
+    for s in range(60):
+        npaths = 0 if s % 11 == 0 else int(rng.integers(1, 5))
+        tot = 0
+        base = rng.integers(5, 15, 3)
+        for p in range(npaths):
+            n = 1 if (s + p) % 7 == 0 else int(rng.integers(2, 40))
+            pts = np.clip(base + np.cumsum(rng.integers(-1, 2, (n, 3)), axis=0), 0, np.array(shape) - 1)
+            verts.append((pts[:, 0] + shape[0] * (pts[:, 1] + shape[1] * pts[:, 2])).astype(np.uint32))
+            lens.append(n)
+            tot += n
+        voff.append(voff[-1] + tot)
+        loff.append(loff[-1] + npaths)
+    res = {"verts": np.concatenate(verts), "radii": rng.random(voff[-1]).astype(np.float32), "lens": np.asarray(lens, dtype=np.uint32),
+           "voff": np.asarray(voff), "loff": np.asarray(loff)}
+    got = {s: (v, e, r) for s, v, e, r in consolidate_paths_batch(res, shape)}
+    seen = 0
+    for s in range(60):
+        v0, v1 = res["voff"][s], res["voff"][s + 1]
+        if v1 == v0:
+            assert s not in got
+            continue
+        wv, we, wr = consolidate_paths(res["verts"][v0:v1].astype(np.int64), res["lens"][res["loff"][s]:res["loff"][s + 1]].astype(np.int64),
+                                       res["radii"][v0:v1], shape)
+        gv, ge, gr = got[s]
+        assert gv.dtype == wv.dtype and ge.dtype == we.dtype
+        np.testing.assert_array_equal(gv, wv)
+        np.testing.assert_array_equal(ge, we)
+        np.testing.assert_array_equal(gr, wr)
+        seen += 1
+    assert seen > 40
+    assert list(consolidate_paths_batch({"verts": np.zeros(0, np.uint32), "radii": np.zeros(0, np.float32), "lens": np.zeros(0, np.uint32),
+                                         "voff": np.array([0, 0]), "loff": np.array([0, 0])}, shape)) == []
+
+
 def test_precomputed_roundtrip():
     """Skeleton.to_precomputed / from_precomputed (the wire format of row f4): byte layout and round trip."""
     from kimimaro_amd.skeleton import Skeleton
