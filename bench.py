@@ -298,6 +298,14 @@ def main():
         return 4
 
     widths = {m: width_of(m) for m in (("weak", "strong") if world > 1 else (args.scaling,))}
+    if dist:
+        # every rank must run the same number of fill steps (each ends in the gather collective): the ranks agree on the
+        # smallest lane count any of them came up with from its own free memory
+        dev_w = eng.device if backend == "nccl" else "cpu"
+        for m_ in sorted(widths):
+            wt = torch.tensor([widths[m_]], dtype=torch.int64, device=dev_w)
+            dist.all_reduce(wt, op=dist.ReduceOp.MIN)
+            widths[m_] = int(wt.item())
     lanes = Lanes(max(widths.values()), device=eng.device) if max(widths.values()) > 1 else None
 
     def run_steps(n, width):
