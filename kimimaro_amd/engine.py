@@ -526,8 +526,13 @@ class Engine:
             # gather the used part of the path buffers: build a flat index on the host (small), gather on device
             nverts = part["n_vertices"].astype(np.int64)
             npaths = part["n_paths"].astype(np.int64)
-            vidx = np.concatenate([p_off[lo + s] + np.arange(nverts[s]) for s in range(hi - lo)] + [np.zeros(0, np.int64)])
-            lidx = np.concatenate([p_off[lo + s] + np.arange(npaths[s]) for s in range(hi - lo)] + [np.zeros(0, np.int64)])
+            def ranges(starts, counts):
+                """concatenation of starts[s] + arange(counts[s]) over s, without a Python loop"""
+                total = int(counts.sum())
+                before = np.cumsum(counts) - counts
+                return np.repeat(starts - before, counts) + np.arange(total, dtype=np.int64)
+            vidx = ranges(p_off[lo:hi].astype(np.int64), nverts)
+            lidx = ranges(p_off[lo:hi].astype(np.int64), npaths)
             d_vidx = t.from_numpy(vidx).to(self.device)
             d_lidx = t.from_numpy(lidx).to(self.device)
             verts_dev = d_pverts[d_vidx]

@@ -463,8 +463,8 @@ class Assembler:
             self.skeletons[self.remapping[segid]].append((segid, verts, edges, radii))
 
     def _skeleton(self, orig, verts, edges, radii):
-        return Skeleton(np.multiply(verts, self.an, dtype=np.float32), edges, radii=radii, segid=orig,  # intake.py:513
-                        transform=self.transform, space="physical")
+        return Skeleton.wrap(np.multiply(verts, self.an, dtype=np.float32), edges, radii, orig,  # intake.py:513
+                             self.transform.copy(), "physical")
 
     def finish(self):
         """one Skeleton per original label.  The components of a label are disjoint voxel sets, so

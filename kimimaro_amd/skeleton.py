@@ -52,6 +52,24 @@ class Skeleton:
 
     # -- construction -------------------------------------------------------
     @classmethod
+    def wrap(cls, vertices, edges, radii, segid, transform, space):
+        """a Skeleton around arrays that already have the right dtypes and shapes (f32 (n,3), u32 (m,2), f32 (n)): no
+        conversions, no copies -- the assembly of a 512^3 volume builds thousands of them on the host thread of its lane."""
+        self = cls.__new__(cls)
+        self.id = segid
+        self.space = space
+        self.vertices = vertices
+        self.edges = edges
+        self.radii = radii
+        self.vertex_types = np.zeros(vertices.shape[0], dtype=np.uint8)
+        self.transform = transform
+        self.extra_attributes = [
+            {"id": "radius", "data_type": "float32", "num_components": 1},
+            {"id": "vertex_types", "data_type": "uint8", "num_components": 1},
+        ]
+        return self
+
+    @classmethod
     def from_path(cls, path):
         path = np.asarray(path, dtype=np.float32).reshape(-1, 3)
         if path.shape[0] == 0:
