@@ -141,42 +141,66 @@ extern "C" int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx
   }
 }
 
-// ---- row f2 (host side): skeletontricks.find_border_targets (skeletontricks.pyx:591-647) with
-// compute_centroids (:528-588) and compute_tiebreaker_maxima (:650-760) restated op for op
-// (float vs double arithmetic exactly as the Cython source compiles, including the reference's
-// use of sx in the fourth corner of `cornerness`, :744).
+// ---- row f2 (host side): skeletontricks.find_border_targets (skeletontricks.pyx:591-647, with compute_centroids
+// :528-588 and compute_tiebreaker_maxima :650-760) on one face of the volume.
+//
+// What the reference computes, said without its control flow: for every component of the plane, the pixel with the largest
+// (non-zero) distance-transform value; among several such pixels the one with the smallest tie-break tuple
+//     ( squared distance to the component's centroid pixel, squared distance to the centre of the plane,
+//       "cornerness" = squared distance to the nearest corner of the plane, "edgeness" = distance to the nearest edge ),
+// compared lexicographically, and among equal tuples the first pixel of the (y outer, x inner) raster -- the reference's
+// scan replaces its current pick only on a strictly smaller tuple, which is exactly "first minimum".  The ids are reported in
+// the order in which the components first show a non-zero value in that raster (the insertion order of the reference's dict).
+// Here: pass 1 = per-component statistics (coordinate sums, pixel count, maximum, first appearance), pass 2 = one
+// first-minimum reduction over the pixels that hold their component's maximum.  The arithmetic of the tuple follows the
+// compiled Cython exactly (which operands are float, which double), because its bits decide ties -- including the
+// reference's fourth "corner", which is at (-0.5, sx - 0.5) instead of (-0.5, sy - 0.5) (:744).
 namespace {
-inline float bt_distsq(float p1x, float p1y, float p2x, float p2y, float wx, float wy) {
-  p1x = wx * (p1x - p2x);
-  p1y = wy * (p1y - p2y);
-  const float a = p1x * p1x;
-  const float b = p1y * p1y;
-  return a + b;
+struct PlaneGeometry {
+  float wx, wy;        // pixel pitch
+  float fsx, fsy;      // extent as floats
+  float mid_x, mid_y;  // centre of the plane in physical units
+};
+
+inline float scaled_sq(float ax, float ay, float bx, float by, const PlaneGeometry& g) {
+  const float ex = g.wx * (ax - bx);
+  const float ey = g.wy * (ay - by);
+  const float e2x = ex * ex;
+  const float e2y = ey * ey;
+  return e2x + e2y;
 }
-inline float bt_min4f(float a, float b, float c, float d) {
-  float m = a;
-  if (b < m) m = b;
-  if (c < m) m = c;
-  if (d < m) m = d;
-  return m;
-}
-inline float bt_cornerness(float x, float y, float sx, float sy, float wx, float wy) {
-  const float a = bt_distsq(x, y, -0.5f, -0.5f, wx, wy);
-  const float b = bt_distsq(x, y, (float)((double)sx - 0.5), -0.5f, wx, wy);
-  const float c = bt_distsq(x, y, (float)((double)sx - 0.5), (float)((double)sy - 0.5), wx, wy);
-  const float d = bt_distsq(x, y, -0.5f, (float)((double)sx - 0.5), wx, wy);
-  return bt_min4f(a, b, c, d);
-}
-inline float bt_edgeness(float x, float y, float sx, float sy, float wx, float wy) {
-  const double a = (double)wx * ((double)x - 0.5);
-  const double b = (double)wx * ((double)sx - 0.5 - (double)x);
-  const double c = (double)wy * ((double)y - 0.5);
-  const double d = (double)wy * ((double)sy - 0.5 - (double)y);
-  double m = a;
-  if (b < m) m = b;
-  if (c < m) m = c;
-  if (d < m) m = d;
-  return (float)m;
+
+struct TieKey {
+  float k[4];
+  bool operator<(const TieKey& o) const {
+    for (int i = 0; i < 4; i++) {
+      if (k[i] < o.k[i]) return true;
+      if (!(k[i] == o.k[i])) return false;
+    }
+    return false;
+  }
+};
+
+inline TieKey tie_key(float x, float y, float cpx, float cpy, const PlaneGeometry& g) {
+  TieKey t;
+  t.k[0] = scaled_sq(x, y, cpx, cpy, g);
+  t.k[1] = scaled_sq(x, y, g.mid_x, g.mid_y, g);
+  // nearest of the four "corners" (the last one as the reference has it, see above)
+  const float hx = (float)((double)g.fsx - 0.5), hy = (float)((double)g.fsy - 0.5);
+  const float corner[4][2] = {{-0.5f, -0.5f}, {hx, -0.5f}, {hx, hy}, {-0.5f, hx}};
+  float near = scaled_sq(x, y, corner[0][0], corner[0][1], g);
+  for (int c = 1; c < 4; c++) {
+    const float d = scaled_sq(x, y, corner[c][0], corner[c][1], g);
+    if (d < near) near = d;
+  }
+  t.k[2] = near;
+  // nearest edge, in double like the reference's expression, rounded once
+  const double to_edge[4] = {(double)g.wx * ((double)x - 0.5), (double)g.wx * ((double)g.fsx - 0.5 - (double)x),
+                             (double)g.wy * ((double)y - 0.5), (double)g.wy * ((double)g.fsy - 0.5 - (double)y)};
+  double e = to_edge[0];
+  for (int c = 1; c < 4; c++) if (to_edge[c] < e) e = to_edge[c];
+  t.k[3] = (float)e;
+  return t;
 }
 }  // namespace
 
@@ -185,72 +209,64 @@ inline float bt_edgeness(float x, float y, float sx, float sy, float wx, float w
 // lists the ids in dict insertion order.  Returns the number of ids written to `order`.
 extern "C" int64_t kh_host_find_border_targets(const float* dt, const uint32_t* cc, int64_t sx, int64_t sy, float wx,
                                                float wy, int64_t nlab, float* out_xy, int32_t* order) {
-  const int64_t n1 = nlab + 1;
-  float* xsum = (float*)calloc((size_t)n1, sizeof(float));
-  float* ysum = (float*)calloc((size_t)n1, sizeof(float));
-  uint32_t* ct = (uint32_t*)calloc((size_t)n1, sizeof(uint32_t));
-  double* mx = (double*)calloc((size_t)n1, sizeof(double));
-  uint8_t* have = (uint8_t*)calloc((size_t)n1, 1);
-  float* cent = (float*)calloc((size_t)n1 * 2, sizeof(float));
-  if (!xsum || !ysum || !ct || !mx || !have || !cent) return -1;
+  struct Stat { float sum_x, sum_y; uint32_t pixels; float peak; int64_t first_seen; float cpx, cpy; bool picked; TieKey best; };
+  const size_t n1 = (size_t)nlab + 1;
+  Stat* st = (Stat*)calloc(n1, sizeof(Stat));
+  if (!st) return -1;
+  for (size_t l = 0; l < n1; l++) st[l].first_seen = -1;
+  PlaneGeometry g;
+  g.wx = wx; g.wy = wy;
+  g.fsx = (float)(uint64_t)sx; g.fsy = (float)(uint64_t)sy;
+  g.mid_x = (float)((double)(wx * g.fsx) / 2.0);
+  g.mid_y = (float)((double)(wy * g.fsy) / 2.0);
+  // pass 1a: coordinate sums in the reference's accumulation order (x outer, y inner: float sums are order sensitive)
   for (int64_t x = 0; x < sx; x++)
     for (int64_t y = 0; y < sy; y++) {
-      const uint32_t L = cc[x + sx * y];
-      if (L == 0) continue;
-      xsum[L] = xsum[L] + (float)(uint64_t)x;
-      ysum[L] = ysum[L] + (float)(uint64_t)y;
-      ct[L] += 1;
+      const uint32_t l = cc[x + sx * y];
+      if (!l) continue;
+      Stat& s = st[l];
+      s.sum_x = s.sum_x + (float)(uint64_t)x;
+      s.sum_y = s.sum_y + (float)(uint64_t)y;
+      s.pixels++;
     }
-  const float cx = (float)((double)(wx * (float)(uint64_t)sx) / 2.0);
-  const float cy = (float)((double)(wy * (float)(uint64_t)sy) / 2.0);
-  for (int64_t L = 0; L < n1; L++) {
-    if (ct[L] == 0) continue;
-    float px = wx * xsum[L] / (float)ct[L];
-    float py = wy * ysum[L] / (float)ct[L];
-    if (!(px - cx >= 0)) px = px + wx;
-    if (!(py - cy >= 0)) py = py + wy;
-    cent[2 * L] = (float)(int)(px / wx);
-    cent[2 * L + 1] = (float)(int)(py / wy);
+  // pass 1b: peak value and first appearance of a non-zero value, in the raster the ids are reported in
+  for (int64_t i = 0, n = sx * sy; i < n; i++) {
+    const uint32_t l = cc[i];
+    const float d = dt[i];
+    if (!l || d == 0) continue;
+    Stat& s = st[l];
+    if (s.first_seen < 0) s.first_seen = i;
+    if (d > s.peak) s.peak = d;
   }
+  // centroid pixel: the mean position, moved one pixel up when it lies below the centre of the plane, truncated
+  for (size_t l = 1; l < n1; l++) {
+    Stat& s = st[l];
+    if (!s.pixels) continue;
+    float px = wx * s.sum_x / (float)s.pixels;
+    float py = wy * s.sum_y / (float)s.pixels;
+    if (!(px - g.mid_x >= 0)) px = px + wx;
+    if (!(py - g.mid_y >= 0)) py = py + wy;
+    s.cpx = (float)(int)(px / wx);
+    s.cpy = (float)(int)(py / wy);
+  }
+  // pass 2: first minimum of the tie-break tuple over the pixels at their component's peak
   int64_t norder = 0;
-  const float fsx = (float)(uint64_t)sx, fsy = (float)(uint64_t)sy;
   for (int64_t y = 0; y < sy; y++)
     for (int64_t x = 0; x < sx; x++) {
-      const uint32_t L = cc[x + sx * y];
-      if (L == 0) continue;
-      const float d = dt[x + sx * y];
-      if (d == 0) continue;
-      if ((double)d > mx[L]) {
-        mx[L] = (double)d;
-        if (!have[L]) { have[L] = 1; order[norder++] = (int32_t)L; }
-        out_xy[2 * L] = (float)x;
-        out_xy[2 * L + 1] = (float)y;
-      } else if (mx[L] == (double)d) {
-        const float px = out_xy[2 * L], py = out_xy[2 * L + 1];
-        const float fx = (float)x, fy = (float)y;
-        const float centx = cent[2 * L], centy = cent[2 * L + 1];
-        bool take = false;
-        float d1 = bt_distsq(px, py, centx, centy, wx, wy);
-        float d2 = bt_distsq(fx, fy, centx, centy, wx, wy);
-        if (d2 < d1) take = true;
-        else if (d1 == d2) {
-          d1 = bt_distsq(px, py, cx, cy, wx, wy);
-          d2 = bt_distsq(fx, fy, cx, cy, wx, wy);
-          if (d2 < d1) take = true;
-          else if (d1 == d2) {
-            d1 = bt_cornerness(px, py, fsx, fsy, wx, wy);
-            d2 = bt_cornerness(fx, fy, fsx, fsy, wx, wy);
-            if (d2 < d1) take = true;
-            else if (d1 == d2) {
-              d1 = bt_edgeness(px, py, fsx, fsy, wx, wy);
-              d2 = bt_edgeness(fx, fy, fsx, fsy, wx, wy);
-              if (d2 < d1) take = true;
-            }
-          }
-        }
-        if (take) { out_xy[2 * L] = fx; out_xy[2 * L + 1] = fy; }
+      const int64_t i = x + sx * y;
+      const uint32_t l = cc[i];
+      if (!l) continue;
+      Stat& s = st[l];
+      if (s.first_seen == i) order[norder++] = (int32_t)l;
+      if (dt[i] == 0 || dt[i] != s.peak) continue;
+      const TieKey t = tie_key((float)x, (float)y, s.cpx, s.cpy, g);
+      if (!s.picked || t < s.best) {
+        s.picked = true;
+        s.best = t;
+        out_xy[2 * l] = (float)x;
+        out_xy[2 * l + 1] = (float)y;
       }
     }
-  free(xsum); free(ysum); free(ct); free(mx); free(have); free(cent);
+  free(st);
   return norder;
 }

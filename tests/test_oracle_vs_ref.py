@@ -79,3 +79,34 @@ def test_find_border_targets_kat(refmod):
     got = find_border_targets(dt, labels, 100, 100, 1)
     assert {k: (int(v[0]), int(v[1])) for k, v in got.items()} == {1: (128, 128)}
     assert {k: (int(v[0]), int(v[1])) for k, v in want.items()} == {1: (128, 128)}
+
+
+def test_find_border_targets_random_planes_with_ties(refmod):
+    """the product's host helper (kh_host_find_border_targets: per-pixel tie-break tuples + a first-minimum reduction)
+    against the reference's find_border_targets on random multi-component planes whose distance values are plateaus,
+    so that every rule of the tie-break cascade decides somewhere: same pixel per component, same dict order."""
+    from kimimaro_amd.border import find_border_targets
+    rng = np.random.default_rng(591)
+    decided_by_ties = 0
+    for t in range(120):
+        sx, sy = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        nlab = int(rng.integers(1, 6))
+        # components as vertical / horizontal bands and blocks (ids 1..nlab, 0 = background)
+        cc = np.zeros((sx, sy), np.uint32, order="F")
+        for l in range(1, nlab + 1):
+            x0, y0 = int(rng.integers(0, sx)), int(rng.integers(0, sy))
+            x1, y1 = int(rng.integers(x0, sx)) + 1, int(rng.integers(y0, sy)) + 1
+            cc[x0:x1, y0:y1] = l
+        # plateau-valued "distance transform": few distinct values, zeros included
+        levels = [1, 2, 3, 8][t % 4]
+        dt = np.asfortranarray(np.floor(rng.random((sx, sy)) * (levels + 1)).astype(np.float32))
+        if t % 5 == 0:
+            dt[...] = 1.0                                  # one plateau: the tie-break decides everything
+        wx, wy = [(1, 1), (16, 16), (16, 40), (40, 16), (3, 7)][t % 5]
+        want = refmod.find_border_targets(dt, cc, wx, wy)
+        got = find_border_targets(dt, cc, wx, wy, nlab)
+        assert list(got.keys()) == list(want.keys()), t
+        for k in want:
+            assert (int(got[k][0]), int(got[k][1])) == (int(want[k][0]), int(want[k][1])), (t, k)
+            decided_by_ties += int(np.count_nonzero((cc == k) & (dt == dt[cc == k].max())) > 1)
+    assert decided_by_ties > 100
