@@ -388,7 +388,7 @@ def main():
             i_orig = state["flat"][i_rep[1:].astype(np.int64)]
             intake.skeletonize_cc(ieng, intake.LazyVolume(ieng, i_cc, lab0.shape), i_n, {i + 1: i_orig[i].item() for i in range(i_n)},
                                   params, an, dust, True, fix_borders, empty, empty, black_border=False, d_cc=i_cc, timings=timings)
-            tk = E.LAST_TASKS
+            tk = ieng.last_tasks
             del i_cc
     lanes = None
     torch.cuda.empty_cache()

@@ -19,7 +19,8 @@ import numpy as np
 from . import _abi
 
 NONE32 = 0xFFFFFFFF
-LAST_TASKS = None  # developer probe: task records of the most recent run_labels call
+LAST_TASKS = None  # developer probe: task records of the most recent run_labels call of ANY engine (single-engine tools and
+# tests read it; with several lanes use Engine.last_tasks, which belongs to the engine that ran the call)
 
 
 def _torch():
@@ -57,6 +58,7 @@ class Engine:
         self.device = self.torch.device("cuda", device) if isinstance(device, int) else self.torch.device(device)
         # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
         self.torch.cuda.set_device(self.device)
+        self.last_tasks = None   # task records (statistics, status) of this engine's most recent run_labels call
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
         self._side = None     # second stream: the biggest labels run there while the others are collected
         self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
@@ -351,8 +353,8 @@ class Engine:
                                     pick_list(targets_after, g), params, fix_branching=fix_branching, max_paths=max_paths,
                                     timings=timings, soma=sub_soma, consume=consume,
                                     scratch_scale=scratch_scale)
-                    done.append(LAST_TASKS)
-                LAST_TASKS = np.concatenate(done)
+                    done.append(self.last_tasks)
+                LAST_TASKS = self.last_tasks = np.concatenate(done)
                 return None
         order = np.argsort(-counts, kind="stable")  # big labels first: their workgroups start first
         slot_of_label = -np.ones(nlabels + 1, dtype=np.int32)
@@ -584,7 +586,7 @@ class Engine:
             mark("d2h")
             tasks_done = np.concatenate([big["tasks"], small["tasks"]])
             run_retry(consume)
-            LAST_TASKS = tasks_done
+            LAST_TASKS = self.last_tasks = tasks_done
             return None
         launch(0, nl, st)
         mark("paths")
@@ -593,7 +595,7 @@ class Engine:
         if consume is not None:
             consume(res)
             run_retry(consume)
-            LAST_TASKS = res["tasks"]
+            LAST_TASKS = self.last_tasks = res["tasks"]
             return None
         if retry:
             # splice the re-traced labels into the result (callers without a sink: single labels, tests)
@@ -616,7 +618,7 @@ class Engine:
             res["lens"] = np.concatenate(per_l) if per_l else res["lens"]
             res["voff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_v])])
             res["loff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_l])])
-        LAST_TASKS = res["tasks"]
+        LAST_TASKS = self.last_tasks = res["tasks"]
         if return_fields:
             res["daf"] = d_field.cpu().numpy()
             res["pdrf"] = d_pdrf.cpu().numpy()
