@@ -35,7 +35,12 @@ Extra objects on the JSON line:
                 pass duration measured with HIP events on the launch stream (kh_edt_timed).
   roofline_trace  the per-label path kernel (where the wall clock goes): SURVEY 8d per-label bytes.
   cpu_baseline  the oracle (CPU restatement, 1 core) on a bounded sample of the same labels.
-  cpu_baseline_all_cores  the same work on a process pool over every host core (SURVEY 8d asks for both).
+  cpu_baseline_all_cores  the same work on a process pool over every USABLE host core (affinity and cgroup quota are
+                printed: the pool's 256-core boxes grant 16), components largest first, in two legs -- `latency`: one
+                volume's components; `throughput`: as many volumes' components at once as the GPU run has in flight.
+  speedup_latency / speedup_throughput  the like-for-like ratios: one volume alone on the GPU vs the latency leg, the
+                pipelined `value` vs the throughput leg.  Never mixed.
+  rank_times    (N > 1) every rank's own seconds per step and the seconds it spent in the skeleton gather.
 """
 from __future__ import annotations
 
