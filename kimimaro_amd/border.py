@@ -91,7 +91,9 @@ def compute_border_targets(cc_labels, anisotropy, eng=None, edt2d=None, faces=No
         lab_of = dict(zip(uniq.tolist(), plane.reshape(-1, order="F")[idx[first_idx]].tolist()))
         for label, pt in plane_targets.items():
             target_list[lab_of[label]].add(rotatefn(int(pt[0]), int(pt[1])))
-    out = defaultdict(lambda: np.array([], np.uint32))
+    none = np.array([], np.uint32)      # (shared: a label without targets is looked up per component, thousands of times per volume)
+    none.setflags(write=False)
+    out = defaultdict(lambda: none)
     for label, pts in target_list.items():
         out[label] = np.array(list(pts), dtype=np.uint32)
     return out
