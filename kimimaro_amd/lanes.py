@@ -27,6 +27,8 @@ def ensure_hw_queues(width):
     and fail loudly rather than run with the silently serialised lanes that were measured as broken."""
     want = max(8, 2 * int(width))
     have = os.environ.get("GPU_MAX_HW_QUEUES")
+    if have is not None and not have.strip().isdigit():
+        have = None           # not a number: treat as unset
     try:
         import torch
         started = torch.cuda.is_initialized()
