@@ -196,6 +196,8 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * ev_chunks / ev_shift / nlev of each task; max_nlev = the largest task.nlev that is <= KH_SWEEP_LDS_LEVELS (sizes
  * the LDS of the launch); a task with more levels keeps its 4-byte level words and the bitmap (nlev / 8 bytes), rounded
  * up to 256 bytes, at the front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
+ * sched (nullable) = one u32 per voxel, 0xFFFFFFFF on entry for every voxel that is alive (and again on exit): the sweep's
+ * pending-deadline filter (csrc/sweep.h) -- with it a voxel is handed ~1.3 events per call instead of ~13; NULL = unfiltered.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.                                                  */
@@ -209,7 +211,7 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
                    uint32_t* queues, void* heap_nodes,
                    uint32_t* path_vertices, uint32_t* path_lengths,
                    const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                   uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream);
+                   uint64_t* cstate, uint32_t* sched, void* event_arena, int flags, int fix_branching, void* stream);
 
 /* keys[a + ra*(b + rb*c)] = the flood's key of the voxel offset (a, b, c): sqrt(fl(fl((wx*a)^2 + (wy*b)^2) + (wz*c)^2)),
  * float operation order of dijkstra_invalidation.hpp:310-316.  Device array of ra*rb*rc floats.              */
@@ -227,7 +229,7 @@ int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* 
                        const float* dbf, uint8_t* alive, uint32_t* queues, void* heap_nodes,
                        const uint32_t* path, int64_t npath, float scale, float constant,
                        const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                       uint64_t* cstate, void* event_arena, int64_t* invalidated, void* stream);
+                       uint64_t* cstate, uint32_t* sched, void* event_arena, int64_t* invalidated, void* stream);
 
 /* ---- a7 / a8 on their own: one search on one object (the path loop has them inside kh_trace_paths).
  * field: the weight volume (PDRF; +inf outside the object); dist: f32 volume, +inf on entry; qstate / queues as for

@@ -34,7 +34,7 @@ int require_device();  // KH_OK or KH_ENODEVICE (+message); cached after the fir
 static constexpr float KH_INF = __builtin_huge_valf();
 
 // 26-neighbourhood in the order of dijkstra_invalidation.hpp:60-124
-__host__ __device__ inline void dir_delta(int i, int& dx, int& dy, int& dz) {
+__host__ __device__ constexpr inline void dir_delta(int i, int& dx, int& dy, int& dz) {
   // packed table: 2 bits per component (0 -> -1, 1 -> 0, 2 -> +1)
   constexpr int8_t T[26][3] = {
       {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},

@@ -43,6 +43,8 @@ static constexpr unsigned long long SW_DYING = 1ull << 63;
 static constexpr uint32_t SW_P = 1u << 16, SW_D = 1u << 17;     // event meta = source index (15 bits) | type
 static constexpr uint32_t SW_CHAIN = 1024;                       // chunks per level the reader can take (LDS list)
 static constexpr uint32_t SW_NOCHUNK = 0x3FFFFFu;                // 22-bit chunk ids
+static constexpr uint32_t SW_SCHED_NONE = 0xFFFFFFFFu;           // sched word of a voxel without a pending deadline
+static constexpr uint32_t SW_SCHED_LEVELS = (1u << 17) - 1u;     // the filter packs the level into 17 bits
 // bail reasons (kh_label_t.stat_sweep_bail is the OR over the label's calls)
 static constexpr uint32_t SW_BAIL_M = 1, SW_BAIL_CAND = 2, SW_BAIL_ARENA = 4, SW_BAIL_LEVEL = 8, SW_BAIL_LIST = 16,
                           SW_BAIL_UNTOUCHED = 32;
@@ -63,6 +65,8 @@ struct Sweep {
   const uint32_t* nbrmask;
   uint8_t* alive;
   unsigned long long* cstate;
+  uint32_t* sched;                 // per voxel: earliest pending deadline (level << 15 | source + 1), SW_SCHED_NONE = none;
+                                   // nullptr = no filter (every event is pushed)
   const uint32_t* rank;            // [ra * rb * rc]
   int ra, rb;
   const uint4* srcs;               // per path vertex {x, y, z, radius bits} (HBM)
@@ -201,11 +205,89 @@ __device__ __forceinline__ uint32_t sweep_eval13(const Sweep& s, const uint4 src
   }
   return cov;
 }
-__device__ __forceinline__ uint32_t sweep_pick13(const uint32_t (&a)[13], int j) {
-  uint32_t r = a[0];
+// covered neighbours whose rank lies above `lvl` (the ranks are looked at with constant indices only: a rank picked by a
+// run-time index turns the two arrays into a scratch-memory table -- 26 stores per event and a dependent load per pick)
+__device__ __forceinline__ uint32_t sweep_above(const uint32_t (&rk0)[13], const uint32_t (&rk1)[13], uint32_t cov, uint32_t lvl) {
+  uint32_t up = 0;
 #pragma unroll
-  for (int i = 1; i < 13; i++) r = (j == i) ? a[i] : r;
-  return r;
+  for (int j = 0; j < 13; j++) {
+    up |= (uint32_t)(rk0[j] > lvl) << j;
+    up |= (uint32_t)(rk1[j] > lvl) << (13 + j);
+  }
+  return up & cov;
+}
+// direction k by a run-time index: 2 bits per component and direction in three 64-bit constants (from dir_delta's table)
+constexpr unsigned long long sweep_dir_word(int comp) {
+  unsigned long long w = 0;
+  for (int k = 0; k < 26; k++) {
+    int d[3] = {0, 0, 0};
+    dir_delta(k, d[0], d[1], d[2]);
+    w |= (unsigned long long)(d[comp] + 1) << (2 * k);
+  }
+  return w;
+}
+__device__ __forceinline__ void sweep_dir(int k, int& dx, int& dy, int& dz) {
+  constexpr unsigned long long WX = sweep_dir_word(0), WY = sweep_dir_word(1), WZ = sweep_dir_word(2);
+  dx = (int)((WX >> (2 * k)) & 3ull) - 1;
+  dy = (int)((WY >> (2 * k)) & 3ull) - 1;
+  dz = (int)((WZ >> (2 * k)) & 3ull) - 1;
+}
+// neighbour k (run-time index) of v = (x, y, z), known to be covered by src: its voxel index and the rank of its key
+__device__ __forceinline__ uint32_t sweep_nbr_rank(const Sweep& s, const uint4 src, uint32_t v, int x, int y, int z, int k,
+                                                   uint32_t& q) {
+  int dx, dy, dz;
+  sweep_dir(k, dx, dy, dz);
+  q = v + (uint32_t)(dx + s.g->sx * dy + s.g->sxy * dz);
+  const int ex = x + dx - (int)src.x, ey = y + dy - (int)src.y, ez = z + dz - (int)src.z;
+  const int ax = ex < 0 ? -ex : ex, ay = ey < 0 ? -ey : ey, az = ez < 0 ? -ez : ez;
+  return s.rank[ax + s.ra * (ay + s.rb * az)];
+}
+
+// ---- pending-deadline filter.  An event that carries a deadline (D or PD) for voxel q at level t makes every event of q
+// at a later level a no-op (q is dead once level t is complete: sweep_possible and sweep_deadline return at their alive
+// test), and a second identical event is a no-op as well (the first adds the candidate / sets the dying bit, the second
+// returns at its first test).  A voxel is handed such events by every neighbour that dies before it does -- about a dozen
+// per voxel, nearly all of them the voxel's own key from the same source -- so unfiltered the sweep stores, reloads and
+// dismisses ~13 events per voxel.  sched[q] holds the smallest (level << 15 | code) over the deadline-carrying events
+// pushed to q so far (code = source + 1 for PD, 0 for a pure D).  A new event is pushed iff it lowers the word (an earlier
+// deadline) or ties its level under another code (two sources on the same key: the tie the certificate is about).
+// Skipped are only exact duplicates and events at a level above a pending deadline: the machine's states, bails and
+// result are those of the unfiltered sweep.  Every word that is ever set belongs to a voxel that is dead at the end of a
+// certified call (its deadline was processed) and dead voxels are never offered events, so the words of live voxels
+// read SW_SCHED_NONE at the start of every call; a bail resets the label's words together with cstate.
+__device__ __forceinline__ bool sweep_claim(const Sweep& s, uint32_t q, uint32_t tr, uint32_t code) {
+  if (s.sched == nullptr) return true;
+  const uint32_t val = (tr << 15) | code;
+  const uint32_t old = atomicMin(&s.sched[q], val);
+  return val < old || ((old >> 15) == tr && old != val);
+}
+// a pure P event of q at level tr is a no-op when a deadline of q is pending at an earlier level
+__device__ __forceinline__ bool sweep_moot(const Sweep& s, uint32_t q, uint32_t tr) {
+  return s.sched != nullptr && (sweep_ld(&s.sched[q]) >> 15) < tr;
+}
+// the same for neighbours K0 .. K0+12 of v at once (`want`: bit k = neighbour k gets a PD event of source code - 1 at
+// level rk[k - K0]): all atomics are in flight before the first result is looked at.  Returns the events to push.
+// (sched, sx, sxy are handed over in registers: the Sweep record lives in LDS, and a flat atomic counts on the LDS
+// counter as well, so an LDS read between two atomics would wait for the first one to return)
+template <int K0>
+__device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, int sx, int sxy, uint32_t v, uint32_t want,
+                                                  const uint32_t (&rk)[13], uint32_t code) {
+  uint32_t old[13];
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    const int k = K0 + j;
+    int dx, dy, dz;
+    dir_delta(k, dx, dy, dz);
+    old[j] = 0u;
+    if ((want >> k) & 1u) old[j] = atomicMin(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)], (rk[j] << 15) | code);
+  }
+  uint32_t keep = 0;
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    const uint32_t val = (rk[j] << 15) | code;
+    keep |= (uint32_t)(val < old[j] || ((old[j] >> 15) == rk[j] && old[j] != val)) << (K0 + j);
+  }
+  return keep & want;
 }
 
 // a P event (c may own v from this level on)
@@ -274,10 +356,10 @@ __device__ __forceinline__ void sweep_emit_possible(const Sweep& s, uint32_t& sp
   sweep_coords(s, v, x, y, z);
   uint32_t rk0[13], rk1[13];
   const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
-  for (uint32_t m = cov; m; m &= m - 1u) {
-    const int k = __ffs((int)m) - 1;
-    const uint32_t r = k < 13 ? sweep_pick13(rk0, k) : sweep_pick13(rk1, k - 13);
-    if (r > lvl) sweep_push(s, spare, r, v + (uint32_t)s.g->off[k], c | SW_P);
+  for (uint32_t m = sweep_above(rk0, rk1, cov, lvl); m; m &= m - 1u) {
+    uint32_t q;
+    const uint32_t r = sweep_nbr_rank(s, src, v, x, y, z, __ffs((int)m) - 1, q);
+    if (!sweep_moot(s, q, r)) sweep_push(s, spare, r, q, c | SW_P);
   }
 }
 
@@ -286,17 +368,23 @@ __device__ __forceinline__ void sweep_deadline_one(const Sweep& s, uint32_t& spa
                                                    const uint4 src, int x, int y, int z, uint32_t am) {
   uint32_t rk0[13], rk1[13];
   const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
-  for (uint32_t m = cov; m; m &= m - 1u) {
-    const int k = __ffs((int)m) - 1;
-    const uint32_t tr = k < 13 ? sweep_pick13(rk0, k) : sweep_pick13(rk1, k - 13);
-    const uint32_t q = v + (uint32_t)s.g->off[k];
-    if (tr <= lvl) {
-      if (s.cstate[q] & SW_DYING) continue;
-      const uint32_t p = atomicAdd(&s.sh->nb, 1u);
-      if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
-    } else {
-      sweep_push(s, spare, tr, q, cid | SW_P | SW_D);
-    }
+  const uint32_t up = sweep_above(rk0, rk1, cov, lvl);   // covered neighbours whose own key lies above this level: a PD event there
+  uint32_t push = up;
+  uint32_t* const sched = s.sched;
+  if (sched != nullptr) {
+    const int sx = s.g->sx, sxy = s.g->sxy;
+    push = sweep_claim13<0>(sched, sx, sxy, v, up, rk0, cid + 1u) | sweep_claim13<13>(sched, sx, sxy, v, up, rk1, cid + 1u);
+  }
+  for (uint32_t m = cov & ~up; m; m &= m - 1u) {      // same level: the cascade of this level
+    const uint32_t q = v + (uint32_t)s.g->off[__ffs((int)m) - 1];
+    if (s.cstate[q] & SW_DYING) continue;
+    const uint32_t p = atomicAdd(&s.sh->nb, 1u);
+    if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
+  }
+  for (uint32_t m = push; m; m &= m - 1u) {
+    uint32_t q;
+    const uint32_t tr = sweep_nbr_rank(s, src, v, x, y, z, __ffs((int)m) - 1, q);
+    sweep_push(s, spare, tr, q, cid | SW_P | SW_D);
   }
 }
 
@@ -309,20 +397,31 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
   if (old & SW_DYING) return;
   if (old == 0ull) { sweep_bail(s, SW_BAIL_UNTOUCHED); return; }
   s.killed[atomicAdd(&s.sh->nkill, 1u)] = v;
-  uint4 src[4];
+  // the candidate slots stay where they are in the word (no compaction: every array below is indexed by constants only,
+  // so nothing of this lives in scratch memory)
   uint32_t cid[4];
+  bool has[4];
   int nc = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const uint32_t sl = (uint32_t)(old >> (16 * i)) & 0x7fffu;
-    if (sl) { cid[nc] = sl - 1u; src[nc] = s.srcs[sl - 1u]; nc++; }
+    has[i] = sl != 0u;
+    cid[i] = sl - 1u;
+    nc += has[i] ? 1 : 0;
   }
+  uint4 src[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) src[i] = s.srcs[has[i] ? cid[i] : 0u];
   const uint32_t am = sweep_alive_nbrs(s, v, nm);
   if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
   if (nc == 1) {
-    sweep_deadline_one(s, spare, lvl, v, cid[0], src[0], x, y, z, am);
+    uint32_t c1 = cid[0];
+    uint4 s1 = src[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) if (has[i]) { c1 = cid[i]; s1 = src[i]; }
+    sweep_deadline_one(s, spare, lvl, v, c1, s1, x, y, z, am);
     return;
   }
   for (uint32_t m = am; m; m &= m - 1u) {
@@ -333,22 +432,28 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
     bool all = true;
     uint32_t tr = 0, rk[4];
     bool cov[4];
-    for (int i = 0; i < nc; i++) {
-      cov[i] = sweep_eval(s, src[i], x + dx, y + dy, z + dz, rk[i]);
-      all = all && cov[i];
-      if (cov[i] && rk[i] > tr) tr = rk[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      cov[i] = false;
+      rk[i] = 0u;
+      if (has[i]) {
+        cov[i] = sweep_eval(s, src[i], x + dx, y + dy, z + dz, rk[i]);
+        all = all && cov[i];
+        if (cov[i] && rk[i] > tr) tr = rk[i];
+      }
     }
     if (all) {
       if (tr <= lvl) {
         if (s.cstate[q] & SW_DYING) continue;
         const uint32_t p = atomicAdd(&s.sh->nb, 1u);
         if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
-      } else {
+      } else if (sweep_claim(s, q, tr, 0u)) {
         sweep_push(s, spare, tr, q, SW_D);
       }
     }
-    for (int i = 0; i < nc; i++)
-      if (cov[i] && rk[i] > lvl) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (cov[i] && rk[i] > lvl && !sweep_moot(s, q, rk[i])) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
   }
 }
 
@@ -518,6 +623,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     if (tid == 0) sh->bail = bail;
     for (uint32_t i = tid; i < nk; i += nthr) s.alive[s.killed[i]] = 1;
     for (uint32_t i = tid; i < nf; i += nthr) s.cstate[list[i]] = 0ull;
+    if (s.sched != nullptr) for (uint32_t i = tid; i < nf; i += nthr) s.sched[list[i]] = SW_SCHED_NONE;
     __syncthreads();
     return false;
   }

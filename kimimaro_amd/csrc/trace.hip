@@ -698,6 +698,7 @@ struct SweepGlobal {
   const uint32_t* rank;         // level table [ra * rb * rc], nullptr = sweep disabled
   int ra, rb, rc;
   unsigned long long* cstate;   // one word per voxel, all zero on entry and on exit
+  uint32_t* sched;              // one word per voxel (sweep.h, pending-deadline filter), SW_SCHED_NONE for live voxels; nullable
   unsigned char* arena;         // event arenas (per label: kh_label_t.ev_offset, in units of 256 bytes)
   uint32_t lds_levels;          // labels with more levels keep their level words in the arena instead of LDS
 };
@@ -753,6 +754,7 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.nbrmask = nbrmask;
   sw.alive = alive;
   sw.cstate = sg.cstate;
+  sw.sched = nlev <= SW_SCHED_LEVELS ? sg.sched : nullptr;
   sw.rank = nlev ? sg.rank : nullptr;
   sw.ra = sg.ra; sw.rb = sg.rb;
   // the heap's HBM slice (>= 3 * nf + 256 nodes of 16 bytes) is free while the sweep runs: source records
@@ -1224,7 +1226,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
                               void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                               const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                              uint64_t* cstate, void* event_arena, int flags, int fix_branching, void* stream) {
+                              uint64_t* cstate, uint32_t* sched, void* event_arena, int flags, int fix_branching, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
@@ -1242,6 +1244,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   sg.rank = level_rank;
   sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
+  sg.sched = sched;
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
   hipStream_t st = (hipStream_t)stream;
@@ -1258,7 +1261,7 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
                                   int64_t sz, float wx, float wy, float wz, const float* dbf, uint8_t* alive, uint32_t* queues,
                                   void* heap_nodes, const uint32_t* path, int64_t npath, float scale, float constant,
                                   const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                                  uint64_t* cstate, void* event_arena, int64_t* invalidated, void* stream) {
+                                  uint64_t* cstate, uint32_t* sched, void* event_arena, int64_t* invalidated, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (!task || !lists || !nbrmask || !dbf || !alive || !queues || !heap_nodes || !path || !invalidated || npath < 0 ||
       npath >= (1ll << 32) || sx * sy * sz >= (1ll << 32) || ((uintptr_t)heap_nodes & 15) != 0) {
@@ -1276,6 +1279,7 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
   sg.rank = level_rank;
   sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
   sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
+  sg.sched = sched;
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);

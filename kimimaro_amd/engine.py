@@ -64,6 +64,7 @@ class Engine:
         self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
         self.split_min_voxels = 16384       # ... if they have at least this many voxels
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
+        self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
         # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
@@ -97,6 +98,18 @@ class Engine:
     @staticmethod
     def ptr(t):
         return C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def optr(t):
+        """pointer of an optional tensor (None -> NULL)"""
+        return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+    def sched_volume(self, nvox):
+        """the pending-deadline words of the invalidation sweep (csrc/sweep.h): one u32 per voxel, all ones; None when the
+        filter is switched off (`Engine.sweep_filter`, KH_SWEEP_FILTER=0: every event is pushed, as in rounds 2-3)."""
+        if not self.sweep_filter:
+            return None
+        return self.torch.full((int(nvox),), -1, dtype=self.torch.int32, device=self.device)
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -293,6 +306,7 @@ class Engine:
         ctx.update(d_rank=d_rank, rdims=rdims, max_nlev=max_nlev, d_arena=d_arena,
                    arena_ptr=C.c_void_p((d_arena.data_ptr() + 255) & ~255),
                    d_cstate=t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device),
+                   d_sched=self.sched_volume(nvox) if d_rank is not None else None,
                    d_task=t.from_numpy(task.view(np.uint8).reshape(-1).copy()).to(self.device), task=task)
         return ctx
 
@@ -310,7 +324,8 @@ class Engine:
                                                float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(ctx["d_dbf"]),
                                                P(d_alive), P(ctx["d_queues"]), P(ctx["d_heap"]), P(d_path), int(d_path.numel()),
                                                np.float32(scale), np.float32(const), rank_ptr, rd[0], rd[1], rd[2], ctx["max_nlev"],
-                                               P(ctx["d_cstate"]), ctx["arena_ptr"], P(d_cnt), self.stream()))
+                                               P(ctx["d_cstate"]), self.optr(ctx["d_sched"]), ctx["arena_ptr"], P(d_cnt),
+                                               self.stream()))
         task = ctx["d_task"].cpu().numpy().view(_abi.LABEL_T).copy()
         if int(task["status"][0]):
             raise _abi.KimiHipError("kh_invalidate_ball: %s" % _abi.describe_status(int(task["status"][0])))
@@ -493,6 +508,7 @@ class Engine:
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
         d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
         d_cstate = t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device)
+        d_sched = self.sched_volume(nvox) if d_rank is not None else None
         d_arena = self.empty(max(ev_total, 1) * 32 + 32, t.int64)   # units of 256 bytes, 256-byte aligned start
         arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
@@ -509,7 +525,7 @@ class Engine:
                                           P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
-                                          P(d_cstate), arena_ptr, prof, int(bool(fix_branching)), stream))
+                                          P(d_cstate), self.optr(d_sched), arena_ptr, prof, int(bool(fix_branching)), stream))
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
