@@ -51,12 +51,19 @@ PDRF_BASE, PDRF_FINISH = -1, -2  # KH_PDRF_BASE / KH_PDRF_FINISH
 
 
 def is_pow2_exponent(e):
-    """kimimaro/trace.py:343: is_power_of_two(pdrf_exponent) and pdrf_exponent < 2**16 (the repeated-squaring branch)"""
+    """kimimaro/trace.py:343: is_power_of_two(pdrf_exponent) and pdrf_exponent < 2**16 (the repeated-squaring branch).
+    The reference's test (trace.py:310-313) evaluates `num & (num - 1)`: an integral FLOAT exponent (16.0, np.float64(4))
+    passes its `int(num) != num` line and then raises TypeError there; so does this mirror."""
     try:
         i = int(e)
     except (TypeError, ValueError):
         return False
-    return i == e and i > 0 and (i & (i - 1)) == 0 and i < 2 ** 16
+    if i != e:
+        return False
+    if isinstance(e, (float, np.floating)):
+        raise TypeError("unsupported operand type(s) for &: 'float' and 'float' (pdrf_exponent must be an integer type, "
+                        "kimimaro/trace.py:313)")
+    return i > 0 and (i & (i - 1)) == 0 and i < 2 ** 16
 
 ST_BITS = {1: "work-list overflow", 2: "invalidation heap overflow", 4: "path buffer overflow",
            8: "no rail reachable from a target", 16: "float-absorption plateau while back-tracking",

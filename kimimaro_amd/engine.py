@@ -19,8 +19,6 @@ import numpy as np
 from . import _abi
 
 NONE32 = 0xFFFFFFFF
-LAST_TASKS = None  # developer probe: task records of the most recent run_labels call of ANY engine (single-engine tools and
-# tests read it; with several lanes use Engine.last_tasks, which belongs to the engine that ran the call)
 
 
 def _torch():
@@ -342,7 +340,6 @@ class Engine:
         kimimaro/trace.py:225-228).  Returns a dict with per-label path arrays -- or, when `consume` is given,
         hands such dicts (one per group of labels, as the groups finish) to `consume` and returns None.
         """
-        global LAST_TASKS
         t = self.torch
         lib = self.lib
         st = self.stream()
@@ -369,7 +366,7 @@ class Engine:
                                     timings=timings, soma=sub_soma, consume=consume,
                                     scratch_scale=scratch_scale)
                     done.append(self.last_tasks)
-                LAST_TASKS = self.last_tasks = np.concatenate(done)
+                self.last_tasks = np.concatenate(done)
                 return None
         order = np.argsort(-counts, kind="stable")  # big labels first: their workgroups start first
         slot_of_label = -np.ones(nlabels + 1, dtype=np.int32)
@@ -495,11 +492,16 @@ class Engine:
         else:
             # trace.py:346-347: np.power.  Its rounding is the host numpy's (libm / SVML powf), which no device powf can
             # promise, so exactly that function is applied -- by numpy itself -- between the two device halves.
+            # Only the selected labels' voxels make the trip (their list is on the device already): gathered into a compact
+            # array, raised on the host, scattered back -- 8 B per foreground voxel instead of 8 B per voxel of the volume.
             pdrf_call(_abi.PDRF_BASE)
-            base = d_pdrf.cpu().numpy()
+            d_base = self.empty(max(total, 1), t.float32)
+            _abi.check(lib.kh_gather_f32(P(d_pdrf), P(d_lists), total, P(d_base), st))
+            base = d_base[:total].cpu().numpy()
             with np.errstate(all="ignore"):
                 np.power(base, expo, out=base)
-            d_pdrf.copy_(t.from_numpy(base))
+            idx = d_lists[:total].to(t.int64) & 0xFFFFFFFF       # u32 linear indices kept in an int32 tensor
+            d_pdrf.index_copy_(0, idx, t.from_numpy(base).to(self.device))
             pdrf_call(_abi.PDRF_FINISH)
         mark("pdrf")
         d_dist = self.empty(nvox, t.float32)
@@ -579,6 +581,17 @@ class Engine:
                                    sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
                                    consume=sink, scratch_scale=scratch_scale * 8)
 
+        def splice_retried(records):
+            """consume paths: re-trace the overflowed labels (their groups go to `consume`) and put the nested call's records
+            -- the good attempt's status bits and statistics -- in the place of the failed attempt's."""
+            if not retry:
+                return records
+            run_retry(consume)
+            pos = {int(sid): i for i, sid in enumerate(records["segid"])}
+            for rec in self.last_tasks:
+                records[pos[int(rec["segid"])]] = rec
+            return records
+
         if consume is not None and 0 < n_large < nl:
             # The largest labels are the tail of the run.  They go to a second stream (as large-LDS workgroups); the
             # rest runs on the caller's stream and its results are copied back and handed to `consume` (the Skeleton
@@ -600,9 +613,7 @@ class Engine:
             mark("paths")
             consume(big)
             mark("d2h")
-            tasks_done = np.concatenate([big["tasks"], small["tasks"]])
-            run_retry(consume)
-            LAST_TASKS = self.last_tasks = tasks_done
+            self.last_tasks = splice_retried(np.concatenate([big["tasks"], small["tasks"]]))
             return None
         launch(0, nl, st)
         mark("paths")
@@ -610,8 +621,7 @@ class Engine:
         mark("d2h")
         if consume is not None:
             consume(res)
-            run_retry(consume)
-            LAST_TASKS = self.last_tasks = res["tasks"]
+            self.last_tasks = splice_retried(res["tasks"])
             return None
         if retry:
             # splice the re-traced labels into the result (callers without a sink: single labels, tests)
@@ -634,7 +644,7 @@ class Engine:
             res["lens"] = np.concatenate(per_l) if per_l else res["lens"]
             res["voff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_v])])
             res["loff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_l])])
-        LAST_TASKS = self.last_tasks = res["tasks"]
+        self.last_tasks = res["tasks"]
         if return_fields:
             res["daf"] = d_field.cpu().numpy()
             res["pdrf"] = d_pdrf.cpu().numpy()

@@ -227,6 +227,15 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
                    fix_branching, fix_borders, before, after, black_border, timings=None,
                    rank=0, world=1, d_cc=None):
     """Everything after the connected components (intake.py:174-221 + skeletonize_subset :434-517)."""
+    try:
+        return _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold, fix_branching,
+                               fix_borders, before, after, black_border, timings, rank, world, d_cc)
+    finally:
+        eng._narrow = None      # the u16 copy of this volume's ids (2 B / voxel of HBM) is not kept alive past the call
+
+
+def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
+                    fix_branching, fix_borders, before, after, black_border, timings, rank, world, d_cc):
     import time as _time
 
     def _mark(name):
@@ -297,7 +306,6 @@ def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy
     if soma_jobs:
         _trace_soma_labels(eng, soma_jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out)
         _mark("soma_labels")
-    eng._narrow = None      # the u16 copy of this volume's ids is not kept alive past the call
     return out
 
 
@@ -475,7 +483,9 @@ class Assembler:
         for orig, parts in self.skeletons.items():
             if len(parts) == 1:
                 _, verts, edges, radii = parts[0]
-                merged[orig] = self._skeleton(orig, verts, edges, radii)
+                # edges / radii are slices of arrays that cover a whole result group (thousands of labels): a copy, so that
+                # one kept Skeleton does not pin the group's buffers and the public arrays own their memory
+                merged[orig] = self._skeleton(orig, verts, edges.copy(), radii.copy())
                 continue
             parts = sorted(parts, key=lambda p: p[0])        # component order of intake.py:444
             verts = np.concatenate([p[1] for p in parts])

@@ -36,6 +36,10 @@ def ensure_hw_queues(width):
         started = False
     if not started:
         if have is None or int(have) < width + 1:
+            if have is not None:
+                import warnings
+                warnings.warn("kimimaro_amd.Lanes(%d): GPU_MAX_HW_QUEUES=%s is too small for %d lanes; raised to %d"
+                              % (width, have, width, want))
             os.environ["GPU_MAX_HW_QUEUES"] = str(want)
         return
     if (have is None and width > 3) or (have is not None and int(have) < width + 1):
@@ -86,6 +90,7 @@ class Lanes:
         stop = [False]
 
         alive = [0]
+        failed = [None]   # the first failure of a lane outside its jobs
 
         def worker(eng, scope, delay):
             def loop():
@@ -104,6 +109,7 @@ class Lanes:
                     except BaseException as ex:  # handed to the caller at position k
                         out[k] = (False, ex)
                     ready[k].set()
+            failure = None
             try:
                 if scope is None:
                     loop()
@@ -111,20 +117,23 @@ class Lanes:
                     with scope:
                         loop()
             except BaseException as ex:
-                # the lane itself failed (its stream scope, not a job).  The other lanes take over its jobs; when it was
-                # the last one, nobody would ever set the remaining events: hand the failure to every job not yet taken
-                # so that the consumer raises instead of waiting forever.
-                with lock:
-                    last = alive[0] == 1
-                    if last:
-                        first, nxt[0] = nxt[0], n
+                failure = ex   # the lane itself failed (its stream scope, not a job); the other lanes take over its jobs
+            # Leaving and "was I the last one" are ONE critical section: two lanes failing at the same moment (a lost GPU
+            # makes every scope fail together) must not both conclude that somebody else is still there.  The last lane
+            # to leave after a lane failure hands that failure to every job not yet taken, so that the consumer raises
+            # instead of waiting forever on events nobody would set.
+            with lock:
+                alive[0] -= 1
+                if failure is not None and failed[0] is None:
+                    failed[0] = failure
+                last = alive[0] == 0 and failed[0] is not None
+                first = nxt[0]
                 if last:
-                    for k in range(first, n):
-                        out[k] = (False, RuntimeError("kimimaro_amd.Lanes: every lane failed outside its job: %r" % (ex,)))
-                        ready[k].set()
-            finally:
-                with lock:
-                    alive[0] -= 1
+                    nxt[0] = n
+            if last:
+                for k in range(first, n):
+                    out[k] = (False, RuntimeError("kimimaro_amd.Lanes: every lane failed outside its job: %r" % (failed[0],)))
+                    ready[k].set()
 
         threads = [threading.Thread(target=worker, args=(self.engines[i], self._scopes[i], i * float(stagger)), daemon=True)
                    for i in range(min(width, n))]

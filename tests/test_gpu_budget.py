@@ -14,7 +14,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def test_small_budget_splits_the_labels_and_changes_nothing():
     import kimimaro_amd
-    import kimimaro_amd.engine as E
     from kimimaro_amd.engine import Engine
     from oracle import pipeline as P
     from shapes import voronoi_labels
@@ -24,11 +23,11 @@ def test_small_budget_splits_the_labels_and_changes_nothing():
     kw = dict(anisotropy=an, dust_threshold=300, fix_borders=True, fix_branching=True, progress=False)
     eng = Engine()
     whole = kimimaro_amd.skeletonize(lab, params, _engine=eng, **kw)
-    n_all = len(E.LAST_TASKS)
+    n_all = len(eng.last_tasks)
     eng2 = Engine()
     eng2.scratch_budget = 40 << 20           # ~130 k voxels of labels per launch
     split = kimimaro_amd.skeletonize(lab, params, _engine=eng2, **kw)
-    assert len(E.LAST_TASKS) == n_all
+    assert len(eng2.last_tasks) == n_all
     want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=300, fix_borders=True, fix_branching=True)
     assert sorted(split) == sorted(want) == sorted(whole)
     for k in want:

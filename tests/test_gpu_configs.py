@@ -116,33 +116,69 @@ def test_c2_sharded_over_two_ranks(eng, c2):
 
 
 def test_c5_sample_matches_oracle(eng):
-    """1024^3 / (8,8,40): the sweep's certificate at the third anisotropy, the multi-launch path at full size."""
+    """1024^3 / (8,8,40): the sweep's certificate at the third anisotropy, the multi-launch path at full size.
+    The sample is drawn by LABEL -- every component of a sampled label is traced by the oracle -- so every skeleton of the
+    sample is complete and every one is compared: a wrong invalidation changes the number of paths, i.e. the shape."""
     if os.environ.get("KIMI_SKIP_C5") == "1":
         pytest.skip("KIMI_SKIP_C5=1")
     import bench
     import kimimaro_amd
-    import kimimaro_amd.engine as E
     from oracle import pool
     lab, an = bench.make_volume("c5")
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
     got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=1000, fix_borders=True, fix_branching=True,
                                    progress=False, _engine=eng)
-    tk = E.LAST_TASKS
+    tk = eng.last_tasks
     assert len(tk) > 8000 and int(tk["stat_sweep_calls"].sum()) > 20000
-    # the sample, from the device's own component ids and sizes (kh_ccl26 numbers the components like the oracle's CCL:
-    # by first appearance in the F-order raster, tests/test_gpu_ccl.py)
+    # component -> label from the device's own numbering (kh_ccl26 numbers the components like the oracle's CCL: by first
+    # appearance in the F-order raster, tests/test_gpu_ccl.py): the label at the component's smallest linear index
+    _, ncomp, rep = eng.ccl(lab)
+    label_of = np.zeros(ncomp + 1, dtype=np.int64)
+    label_of[1:] = np.asfortranarray(lab).reshape(-1, order="F")[rep[1:ncomp + 1].astype(np.int64)]
     segs, cnts = tk["segid"].astype(np.int64), tk["count"].astype(np.int64)
     big = segs[np.argsort(-cnts, kind="stable")[:32]]
     rng = np.random.default_rng(5)
     nrand = 480 if (os.cpu_count() or 1) >= 64 else 96
-    only = set(big.tolist()) | set(rng.choice(np.sort(segs), size=min(nrand, segs.size), replace=False).tolist())
+    labels = np.unique(label_of[segs])
+    chosen = set(label_of[big].tolist()) | set(rng.choice(labels, size=min(nrand, labels.size), replace=False).tolist())
+    only = set(np.flatnonzero(np.isin(label_of, list(chosen)) & (np.arange(ncomp + 1) > 0)).tolist())
     want, _, _ = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True, fix_borders=True,
                                        only=only)
-    checked = 0
+    assert sorted(want) == sorted(k for k in chosen if k in got) and len(want) >= 64
     for k, w in want.items():
-        g = got[k]
-        if g.vertices.shape != w.vertices.shape:
-            continue   # a label with several components of which only some were sampled
-        _same(g, w, k)
-        checked += 1
-    assert checked >= 0.8 * len(want) and checked >= 64
+        _same(got[k], w, k)
+
+
+def test_all_gather_v_over_rccl_on_the_device(eng):
+    """configs[3]'s only collective on the backend an 8-GPU node uses: distributed.gather_skeletons over "nccl" (= RCCL on
+    ROCm) with device tensors, world_size 1 on this GPU -- the branch the gloo tests cannot reach."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import kimimaro_amd
+    from kimimaro_amd import distributed as D
+    from shapes import voronoi_labels
+    if dist.is_initialized():
+        pytest.skip("a process group exists already in this process")
+    an = (16, 16, 40)
+    lab = voronoi_labels((64, 64, 48), 10, seed=5, pts_per_label=5, step=10.0, anisotropy=an)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params["const"] = 64
+    local = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=200, fix_borders=True, progress=False, _engine=eng)
+    assert len(local) > 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        blobs = D.all_gather_v(D.pack_skeletons(local), device=dev)
+        assert len(blobs) == 1 and blobs[0] == D.pack_skeletons(local)
+        merged = D.gather_skeletons(local, device=dev)
+    finally:
+        dist.destroy_process_group()
+    assert sorted(merged) == sorted(local)
+    for k in local:
+        _same(merged[k], local[k], k)

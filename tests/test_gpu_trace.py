@@ -238,8 +238,7 @@ def test_skeletonize_sweep_and_heap_paths(sweep, slots):
     got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True,
                                    progress=False, _engine=eng2)
     want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True)
-    import kimimaro_amd.engine as E
-    tk = E.LAST_TASKS
+    tk = eng2.last_tasks
     if sweep:
         assert int(tk["stat_sweep_calls"].sum()) > 0
         assert int(tk["stat_sweep_calls"].sum() - tk["stat_sweep_bails"].sum()) > 0   # the sweep certified calls

@@ -225,3 +225,14 @@ def test_plan_launches_groups_labels_under_the_scratch_budget():
         assert len(g) == 1 or int(need[g].sum()) <= (30 << 20)
     assert groups[0] == [3]                                                       # 90000 voxels: 28 MB, alone under 30 MB
     assert plan_launches(counts, 1) == [[3], [5], [1], [4], [2], [0]]             # nothing fits: one label per launch
+
+
+def test_pow2_exponent_mirrors_the_reference_test():
+    """kimimaro/trace.py:310-313,343: integers that are powers of two below 2**16 take the squaring branch; an integral float
+    passes the reference's `int(num) != num` line and then fails in `num & (num - 1)` with TypeError."""
+    from kimimaro_amd._abi import is_pow2_exponent
+    assert [e for e in (1, 2, 4, 16, 2 ** 15, np.int64(8)) if is_pow2_exponent(e)] == [1, 2, 4, 16, 2 ** 15, np.int64(8)]
+    assert not any(is_pow2_exponent(e) for e in (0, 3, 5, 6, 2 ** 16, 2 ** 17, 2.5, np.float32(1.5), -4))
+    for e in (4.0, np.float64(16), np.float32(2)):
+        with pytest.raises(TypeError):
+            is_pow2_exponent(e)

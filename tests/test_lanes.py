@@ -86,6 +86,45 @@ def test_every_lane_failing_outside_its_job_raises_instead_of_hanging():
     assert time.perf_counter() - t0 < 5.0
 
 
+def test_all_lanes_failing_at_the_same_moment_still_raise():
+    """round-3 advisor finding: two lanes whose scopes fail together could both read "somebody else is still alive" and
+    leave the consumer waiting forever.  The lanes meet at a barrier and fail together, with the interpreter switching
+    threads as often as it can; `run` is driven from a watchdog thread so that a hang fails the test instead of the suite."""
+    import sys
+    import threading
+    old = sys.getswitchinterval()
+    sys.setswitchinterval(1e-6)
+    try:
+        for _ in range(150):
+            bar = threading.Barrier(4)
+
+            class BadScope:
+                def __enter__(self):
+                    bar.wait(timeout=5)
+                    raise OSError("no stream")
+
+                def __exit__(self, *a):
+                    return False
+
+            lanes = Lanes(4, engine_factory=_Eng, stream_factory=lambda e: BadScope())
+            res = []
+
+            def drive():
+                try:
+                    list(lanes.run(lambda e, k: k, 6))
+                    res.append("no error")
+                except RuntimeError as ex:
+                    res.append(str(ex))
+
+            th = threading.Thread(target=drive, daemon=True)
+            th.start()
+            th.join(10)
+            assert not th.is_alive(), "Lanes.run hangs when all lanes fail at once"
+            assert res and "every lane failed" in res[0]
+    finally:
+        sys.setswitchinterval(old)
+
+
 def test_one_failing_lane_is_covered_by_the_others():
     class Scope:
         def __init__(self, bad):

@@ -45,7 +45,7 @@ for name, ts in timings[1:]:
     print("  %-14s %.3f s" % (name, ts - prev)); prev = ts
 print("verts", sum(s.vertices.shape[0] for s in sk.values()), "arena MB", getattr(eng, "last_arena_bytes", 0) / 1e6)
 import kimimaro_amd.engine as E
-tk = E.LAST_TASKS
+tk = eng.last_tasks
 if tk is not None:
     print("kcyc target/rail/inval sums:", tk["cyc_target"].sum(), tk["cyc_rail"].sum(), tk["cyc_inval"].sum())
     i = np.argmax(tk["cyc_inval"].astype(np.int64) + tk["cyc_rail"])

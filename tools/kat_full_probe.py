@@ -8,7 +8,7 @@ eng = Engine()
 TP = {"scale": 1.5, "const": 300, "pdrf_scale": 100000, "pdrf_exponent": 4, "soma_acceptance_threshold": 3500,
       "soma_detection_threshold": 750, "soma_invalidation_const": 300, "soma_invalidation_scale": 2}
 def stats():
-    tk = E.LAST_TASKS
+    tk = eng.last_tasks
     return dict(calls=int(tk["stat_sweep_calls"].sum()), bails=int(tk["stat_sweep_bails"].sum()), why=int(np.bitwise_or.reduce(tk["stat_sweep_why"])), levels=int(tk["stat_sweep_levels"].sum()), nlev=tk["nlev"].tolist()[:4], pushes=int(tk["stat_heap_pushes"].sum()))
 which = sys.argv[1:] or ["square_main"]
 for w in which:

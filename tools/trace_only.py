@@ -18,7 +18,7 @@ eng = Engine()
 t0 = time.perf_counter()
 sk = kimimaro_amd.skeletonize(lab, anisotropy=an, dust_threshold=1000, fix_borders=True, progress=False, _engine=eng)
 eng.sync()
-tk = E.LAST_TASKS
+tk = eng.last_tasks
 nf = int(tk["count"].astype(np.int64).sum())
 settled = int(tk["stat_settled"].astype(np.int64).sum())
 print("TRACEONLY %s: %d skeletons, %.3f s, Nf %d, settled %d, algorithmic bytes of the path kernel (SURVEY 8d) %d" % (
