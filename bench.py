@@ -74,6 +74,11 @@ def make_volume(name):
     metric, label ids 1000 + perm(i).  Deterministic (np.random.default_rng(seed))."""
     from scipy.spatial import cKDTree
     shape, nchains, npts, seed, an = WORKLOADS[name]
+    cache = os.environ.get("KIMI_VOLUME_CACHE")     # developer knob: keep the generated volume between runs on one box
+    if cache:
+        path = os.path.join(cache, "%s_seed%d.npy" % (name, seed))
+        if os.path.exists(path):
+            return np.asfortranarray(np.load(path)), an
     rng = np.random.default_rng(seed)
     anf = np.asarray(an, dtype=np.float64)
     shp = np.asarray(shape, dtype=np.float64)
@@ -97,6 +102,9 @@ def make_volume(name):
         q = np.concatenate([base, np.full((base.shape[0], 1), z * anf[2])], axis=1)
         _, idx = tree.query(q, workers=-1)
         lab[:, :, z] = ids[owner[idx]].reshape(shape[0], shape[1], order="F")
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        np.save(path, lab)
     return lab, an
 
 

@@ -318,6 +318,8 @@ class Engine:
         d_cnt = t.zeros(1, dtype=t.int64, device=self.device)
         rank_ptr = P(ctx["d_rank"]) if ctx["d_rank"] is not None else C.c_void_p(0)
         rd = ctx["rdims"]
+        if ctx["d_sched"] is not None:
+            ctx["d_sched"].fill_(-1)      # the caller's mask may revive voxels an earlier call on this context killed
         _abi.check(self.lib.kh_invalidate_ball(P(ctx["d_task"]), P(ctx["d_lists"]), P(ctx["d_nbr"]), shape[0], shape[1], shape[2],
                                                float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(ctx["d_dbf"]),
                                                P(d_alive), P(ctx["d_queues"]), P(ctx["d_heap"]), P(d_path), int(d_path.numel()),
