@@ -167,6 +167,34 @@ def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate,
             os.remove(path)
 
 
+def volume_step(e, st):
+    """the whole step of one rank's share of the volume in `st` on engine e (current stream of the calling thread):
+    connected components -> EDT -> statistics -> border targets -> searches -> path loop -> host skeletons."""
+    from collections import defaultdict
+    from kimimaro_amd import intake
+    lab = st["lab"]
+    d_cc, nlabels, rep_ = e.ccl_device(st["d_lab"], lab.dtype.itemsize, lab.shape)
+    orig = st["flat"][rep_[1:].astype(np.int64)]
+    remapping = {i + 1: orig[i].item() for i in range(nlabels)}
+    cc = intake.LazyVolume(e, d_cc, lab.shape)
+    empty = defaultdict(list)
+    return intake.skeletonize_cc(e, cc, nlabels, remapping, st["params"], st["an"], st["dust"], True, st["fix_borders"],
+                                 empty, empty, black_border=False, rank=st["shard"][0], world=st["shard"][1], d_cc=d_cc)
+
+
+def _lane_setup(eng, index, path, an, params, dust, fix_borders, shard):
+    """a lane process of kimimaro_amd.lanes.ProcessLanes: its own copy of the label volume, resident in ITS HBM allocation"""
+    lab = np.asfortranarray(np.load(path, mmap_mode="r"))
+    st = {"lab": lab, "d_lab": eng.to_device(lab), "flat": lab.reshape(-1, order="F"), "an": np.asarray(an, dtype=np.float32),
+          "params": dict(params), "dust": dust, "fix_borders": fix_borders, "shard": tuple(shard)}
+    eng.sync()
+    return st
+
+
+def _lane_step(st, eng, payload):
+    return volume_step(eng, st)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +208,9 @@ def main():
                          "2 / 4 / 8 GPUs (a rank's share of a volume is smaller there, the chain of its largest component "
                          "is not).  1 = one step after the other (the latency "
                          "of a single volume, which is reported either way as single_volume_ms).")
+    ap.add_argument("--lanes", choices=["thread", "process"], default=os.environ.get("KIMI_BENCH_LANES", "thread"),
+                    help="what a lane is: a host thread of this process (kimimaro_amd.lanes.Lanes) or a process of its own "
+                         "(kimimaro_amd.lanes.ProcessLanes: no shared interpreter lock)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-borders", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("KIMI_BENCH_SCALING", "strong"),
@@ -262,7 +293,14 @@ def main():
         eng.sync()
         state["flat"] = lab.reshape(-1, order="F")
         state["shard"] = (rank, world) if mode == "strong" else (0, 1)
-        return time.perf_counter() - t
+        state.update(an=an, params=params, dust=dust, fix_borders=fix_borders)
+        dt = time.perf_counter() - t
+        if args.lanes == "process" and widths.get(mode, 1) > 1:
+            # the lane processes load the prepared volume from shared memory and keep their own copy in HBM
+            path = "/dev/shm/kimi_bench_%d_%d_%s.npy" % (os.getpid(), rank, mode)
+            np.save(path, lab)
+            state["shm"] = path
+        return dt
 
     def components():
         lab = state["lab"]
@@ -271,14 +309,7 @@ def main():
         return d_cc, n, {i + 1: orig[i].item() for i in range(n)}
 
     def local_step(e):
-        """the whole step of this rank's share on engine e (current stream of the calling thread); host skeletons."""
-        lab = state["lab"]
-        d_cc, nlabels, rep_ = e.ccl_device(state["d_lab"], lab.dtype.itemsize, lab.shape)
-        orig = state["flat"][rep_[1:].astype(np.int64)]
-        remapping = {i + 1: orig[i].item() for i in range(nlabels)}
-        cc = intake.LazyVolume(e, d_cc, lab.shape)
-        return intake.skeletonize_cc(e, cc, nlabels, remapping, params, an, dust, True, fix_borders,
-                                     empty, empty, black_border=False, rank=state["shard"][0], world=state["shard"][1], d_cc=d_cc)
+        return volume_step(e, state)
 
     def finish(local):
         if world > 1:
@@ -319,9 +350,33 @@ def main():
             wt = torch.tensor([widths[m_]], dtype=torch.int64, device=dev_w)
             dist.all_reduce(wt, op=dist.ReduceOp.MIN)
             widths[m_] = int(wt.item())
-    lanes = Lanes(max(widths.values()), device=eng.device) if max(widths.values()) > 1 else None
+    lanes = Lanes(max(widths.values()), device=eng.device) if max(widths.values()) > 1 and args.lanes == "thread" else None
+    plane = {"obj": None, "peak": 0}      # process lanes of the mode being measured (kimimaro_amd.lanes.ProcessLanes)
+
+    def open_process_lanes(width):
+        from kimimaro_amd.lanes import ProcessLanes
+        if args.lanes == "process" and width > 1:
+            plane["obj"] = ProcessLanes(width, setup=_lane_setup, device=eng.device.index,
+                                        setup_args=(state["shm"], [float(a) for a in an], params, dust, fix_borders, state["shard"]))
+
+    def close_process_lanes():
+        if plane["obj"] is not None:
+            plane["obj"].close()
+            plane["peak"] = max(plane["peak"], sum(s_["hbm_reserved_peak"] for s_ in plane["obj"].stats))
+            plane["obj"] = None
+        if state.get("shm"):
+            if os.path.exists(state["shm"]):
+                os.remove(state["shm"])
+            state["shm"] = None
 
     def run_steps(n, width):
+        if plane["obj"] is not None and width > 1:
+            want = os.environ.get("KIMI_BENCH_STAGGER")
+            on = (n >= 4 * width) if want is None else (want == "1" and n > width)
+            stagger = state.get("single_ms", 0.0) / 1e3 / width if on else 0.0
+            for _, local in plane["obj"].run(_lane_step, [None] * n, width=width, stagger=stagger):
+                finish(local)
+            return
         if lanes is None or width <= 1:
             for _ in range(n):
                 finish(local_step(lanes.engines[0] if lanes is not None else eng))
@@ -338,11 +393,15 @@ def main():
     def measure(mode, warmup, steps, latency=True):
         width = widths[mode]
         torch.cuda.empty_cache()           # scratch of the other mode / of the preparation goes back to the device
+        open_process_lanes(width)
         if width > 1:
             run_steps(width, width)        # every lane once: fills the scratch pool of its stream (not a warm-up step)
         if latency:
             t1 = time.perf_counter()
-            if lanes is not None:          # one volume alone on an otherwise idle GPU: its latency (also untimed)
+            if plane["obj"] is not None:   # one volume alone on an otherwise idle GPU: its latency (also untimed)
+                for _, local in plane["obj"].run(_lane_step, [None], width=1):
+                    finish(local)
+            elif lanes is not None:
                 for _, local in lanes.run(lambda e, k: local_step(e), 1, width=1):
                     finish(local)
             else:
@@ -380,9 +439,11 @@ def main():
         prepare(omode)
         osteps = max(1, min(args.steps, 4))
         oel = measure(omode, 1, osteps, latency=False)
+        close_process_lanes()
         other = {"mode": omode, "elapsed": oel, "steps": osteps, "skeletons": len(result["skels"])}
     preamble_s = prepare(args.scaling)
     elapsed = measure(args.scaling, args.warmup, args.steps)
+    close_process_lanes()                  # (their HBM goes back before the instrumented pass of this process)
     inflight = widths[args.scaling]
     # ---- instrumented pass (phase times, sweep statistics): one volume alone, on lane 0 while its scratch pool is warm
     import contextlib
@@ -528,7 +589,8 @@ def main():
         "value": round(value, 3), "unit": "labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
         "volumes_in_flight": inflight, "single_volume_ms": round(state.get("single_ms", float("nan")), 3),
-        "hbm_reserved_peak_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1),
+        "hbm_reserved_peak_gb": round((torch.cuda.max_memory_reserved() + plane["peak"]) / 1e9, 1),
+        "lanes": args.lanes if inflight > 1 else "none",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "
                                "default teasar_params, fix_branching=True, fix_borders=%s, dust_threshold=%d"

@@ -198,10 +198,11 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * up to 256 bytes, at the front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
  * sched (nullable) = one u32 per voxel, 0xFFFFFFFF on entry for every voxel that is alive (and again on exit): the sweep's
  * pending-deadline filter (csrc/sweep.h) -- with it a voxel is handed ~1.3 events per call instead of ~13; NULL = unfiltered.
- * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant).
+ * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant); KH_TRACE_HEAP_PRIO see below.
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.                                                  */
 #define KH_TRACE_PROFILE 1
+#define KH_TRACE_HEAP_PRIO 2   /* the wave running the heap emulation raises its issue priority (several volumes in flight) */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,

@@ -701,6 +701,7 @@ struct SweepGlobal {
   uint32_t* sched;              // one word per voxel (sweep.h, pending-deadline filter), SW_SCHED_NONE for live voxels; nullable
   unsigned char* arena;         // event arenas (per label: kh_label_t.ev_offset, in units of 256 bytes)
   uint32_t lds_levels;          // labels with more levels keep their level words in the arena instead of LDS
+  uint32_t heap_prio;           // != 0: the wave that runs the heap emulation raises its issue priority (s_setprio 3)
 };
 
 // One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
@@ -709,7 +710,7 @@ template <bool PROF, class H>
 __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                                const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                                float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
-                                               uint32_t* sweep_stats) {
+                                               uint32_t* sweep_stats, uint32_t heap_prio) {
   const int tid = threadIdx.x;
   bool ok = false;
   if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
@@ -734,8 +735,13 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   if (!ok) {
     __syncthreads();
     if (tid < 64) {
+      // The heap emulation is ONE sequential chain (a third of its time is instruction issue, the rest its own dependent
+      // loads) and it sets the wall clock of the label; the waves it shares its SIMD with -- other labels' sweeps and
+      // searches -- are throughput work.  With several volumes in flight they compete for issue slots all the time.
+      if (heap_prio) __builtin_amdgcn_s_setprio(3);
       const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
                                                   &ctl->status, &ctl->u3, ctl->cyc3);
+      if (heap_prio) __builtin_amdgcn_s_setprio(0);
       if (tid == 0) ctl->u1 = c;
     }
   }
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                          heap, list, nf, sweep_stats);   // trace.py:211 counts what is left
+                                          heap, list, nf, sweep_stats, sg.heap_prio);   // trace.py:211 counts what is left
   }
   const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
   if (nb + na >= max_paths) {                           // trace.py:217-218
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     t_rail += clock64() - t0; t0 = clock64();
     if (valid > 0)
       valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list, nf,
-                                            sweep_stats);
+                                            sweep_stats, sg.heap_prio);
     // ---- rails, trace.py:261-263
     t_inval += clock64() - t0;
     if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
@@ -1037,7 +1043,7 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
   }
   __syncthreads();
   const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                               lists + task->list_offset, nf, sweep_stats);
+                                               lists + task->list_offset, nf, sweep_stats, sg.heap_prio);
   if (tid == 0) {
     *invalidated = (long long)c;
     task->status |= ctl.status;
@@ -1232,7 +1238,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
-  if (flags & ~KH_TRACE_PROFILE) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
+  if (flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO)) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
   if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
                      ((uintptr_t)event_arena & 255) != 0)) {
     set_error("kh_trace_paths: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
@@ -1247,6 +1253,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   sg.sched = sched;
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
+  sg.heap_prio = (flags & KH_TRACE_HEAP_PRIO) ? 1u : 0u;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
@@ -1282,6 +1289,7 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
   sg.sched = sched;
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
+  sg.heap_prio = 0u;
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (level_rank && swl > lds) lds = swl;

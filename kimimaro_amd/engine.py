@@ -63,6 +63,7 @@ class Engine:
         self.split_min_voxels = 16384       # ... if they have at least this many voxels
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
+        self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
         # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
@@ -520,7 +521,7 @@ class Engine:
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
         # are consumed incrementally they go to a second stream and the others are collected while they still run
         n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
-        prof = 1 if self.profile else 0
+        prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0)      # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
 
         def launch(first, count, stream):

@@ -176,3 +176,181 @@ class _StreamScope:
 
     def synchronize(self):
         self.stream.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Lanes as PROCESSES.  The thread lanes above share one Python interpreter: a volume costs ~0.2 s of Python (border targets,
+# result collection, Skeleton assembly) and every kernel launch re-acquires the interpreter lock, so with four volumes in
+# flight the lanes wait for each other's Python as much as for the GPU.  The reference parallelises the same way
+# (kimimaro/intake.py:344-408: a pool of processes over the components); here a process owns a whole volume at a time.
+
+def _lane_main(conn, device, setup, setup_args, index, engine_factory):
+    """worker process: one Engine (own HIP context, own caching allocator), jobs one at a time over the pipe."""
+    import traceback
+    try:
+        if engine_factory is None:
+            from .engine import Engine
+            eng = Engine(device)
+        else:
+            eng = engine_factory()
+        ctx = setup(eng, index, *setup_args) if setup is not None else None
+        conn.send(("ready", None))
+    except BaseException:
+        conn.send(("failed", traceback.format_exc()))
+        return
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            return
+        if msg is None:
+            try:
+                conn.send(("stats", {"hbm_reserved_peak": int(eng.torch.cuda.max_memory_reserved()) if hasattr(eng, "torch") else 0}))
+            except Exception:
+                pass
+            return
+        k, work, payload = msg
+        try:
+            res = work(ctx, eng, payload)
+            if hasattr(eng, "sync"):
+                eng.sync()
+            conn.send((k, True, res))
+        except BaseException:
+            conn.send((k, False, traceback.format_exc()))
+
+
+class ProcessLanes:
+    """`width` worker processes on one GPU, each with an Engine of its own.
+
+        lanes = ProcessLanes(4, setup=load_my_state, setup_args=(...))      # setup(engine, lane_index, *setup_args) -> ctx
+        for k, result in lanes.run(work, payloads):                          # work(ctx, engine, payload) -> picklable result
+            ...
+        lanes.close()
+
+    `setup` and `work` are module-level functions (they travel by name to processes started with the "spawn" method: a
+    forked child could not use the HIP runtime its parent has initialised).  Results come back in order; an exception of
+    job k is raised when k is reached."""
+
+    def __init__(self, width, setup=None, setup_args=(), device=None, start_timeout=900.0, engine_factory=None):
+        """engine_factory (module-level callable, host-logic tests only): what a lane builds instead of Engine(device)."""
+        import multiprocessing as mp
+        if width < 1:
+            raise ValueError("ProcessLanes: width must be >= 1")
+        self.width = int(width)
+        self.stats = []
+        ctx = mp.get_context("spawn")
+        self._conns, self._procs = [], []
+        for i in range(self.width):
+            a, b = ctx.Pipe()
+            p = ctx.Process(target=_lane_main, args=(b, device, setup, tuple(setup_args), i, engine_factory), daemon=True)
+            p.start()
+            b.close()
+            self._conns.append(a)
+            self._procs.append(p)
+        t_end = time.time() + start_timeout
+        for i, c in enumerate(self._conns):
+            if not c.poll(max(0.0, t_end - time.time())):
+                self.close()
+                raise RuntimeError("kimimaro_amd.ProcessLanes: lane %d did not come up within %.0f s" % (i, start_timeout))
+            try:
+                tag, info = c.recv()
+            except EOFError:
+                tag, info = "failed", "the process died while starting"
+            if tag != "ready":
+                self.close()
+                raise RuntimeError("kimimaro_amd.ProcessLanes: lane %d failed to start:\n%s" % (i, info))
+
+    def run(self, work, payloads, width=None, stagger=0.0):
+        """Generator over (k, work(ctx, engine, payloads[k])), in order, at most one job per lane in flight (`width` lanes).
+        stagger: lane i gets its first job i * stagger seconds after lane 0 (see Lanes.run)."""
+        from multiprocessing.connection import wait
+        payloads = list(payloads)
+        n = len(payloads)
+        width = self.width if width is None else max(1, min(int(width), self.width))
+        if n <= 0:
+            return
+        out = [None] * n
+        ready = [threading.Event() for _ in range(n)]
+        stop = [False]
+
+        def pump():
+            conns = self._conns[:width]
+            busy = {}                      # connection -> job index
+            t0 = time.time()
+            first_at = {c: t0 + i * float(stagger) for i, c in enumerate(conns)}
+            nxt = 0
+            dead = set()
+            while True:
+                now = time.time()
+                for c in conns:
+                    if c not in busy and c not in dead and nxt < n and not stop[0] and now >= first_at[c]:
+                        try:
+                            c.send((nxt, work, payloads[nxt]))
+                            busy[c] = nxt
+                            nxt += 1
+                        except (BrokenPipeError, OSError):
+                            dead.add(c)
+                if not busy:
+                    if nxt >= n or stop[0]:
+                        return
+                    if len(dead) == len(conns):
+                        for k in range(nxt, n):
+                            out[k] = (False, "every lane process died")
+                            ready[k].set()
+                        return
+                    time.sleep(0.002)      # (only while lanes wait for their staggered start)
+                    continue
+                pending = [first_at[c] - now for c in conns if c not in busy and c not in dead and first_at[c] > now]
+                for c in wait(list(busy), timeout=min(pending) if pending and nxt < n else None):
+                    k = busy.pop(c)
+                    try:
+                        kk, ok, val = c.recv()
+                        out[kk] = (ok, val)
+                    except (EOFError, OSError):
+                        dead.add(c)
+                        out[k] = (False, "the lane process died during job %d" % k)
+                    ready[k].set()
+
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        try:
+            for k in range(n):
+                ready[k].wait()
+                ok, val = out[k]
+                out[k] = None
+                if not ok:
+                    raise RuntimeError("kimimaro_amd.ProcessLanes: job %d failed in its lane:\n%s" % (k, val))
+                yield k, val
+        finally:
+            stop[0] = True
+            th.join()
+
+    def close(self):
+        for c in self._conns:
+            try:
+                c.send(None)
+            except Exception:
+                pass
+        for c, p in zip(self._conns, self._procs):
+            try:
+                if c.poll(30.0):
+                    tag, info = c.recv()
+                    if tag == "stats":
+                        self.stats.append(info)
+            except Exception:
+                pass
+            p.join(30.0)
+            if p.is_alive():
+                p.terminate()
+            try:
+                c.close()
+            except Exception:
+                pass
+        self._conns, self._procs = [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -1,5 +1,6 @@
 """Host logic of kimimaro_amd.lanes (several volumes in flight): order of the results, bounded width, error hand-over.
 No GPU: the lanes get stand-in engines."""
+import os
 import threading
 import time
 
@@ -154,3 +155,37 @@ def test_hw_queue_guard(monkeypatch):
     L.ensure_hw_queues(6)          # HIP not started in the CPU suite: the variable is set for the runtime to read
     import os
     assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 7
+
+
+def test_process_lanes_order_overlap_and_errors():
+    """ProcessLanes without a GPU (engine_factory): results in order from several processes, a failing job raised at its
+    position, the lanes usable again afterwards, a failing setup reported at construction."""
+    import lane_helpers as H
+    from kimimaro_amd.lanes import ProcessLanes
+    with ProcessLanes(3, setup=H.setup, setup_args=(100,), engine_factory=H.make_engine, start_timeout=120) as lanes:
+        t0 = time.perf_counter()
+        got = list(lanes.run(H.work, list(range(9))))
+        dt = time.perf_counter() - t0
+        assert [k for k, _ in got] == list(range(9))
+        assert [v[0] for _, v in got] == [100 + i for i in range(9)]
+        assert len({v[2] for _, v in got}) == 3 and os.getpid() not in {v[2] for _, v in got}   # three other processes
+        assert dt < 9 * 0.05 * 0.9                                                               # ... working at the same time
+        seen = []
+        with pytest.raises(RuntimeError, match="job asked to fail"):
+            for k, v in lanes.run(H.work, [1, 2, "boom", 4, 5]):
+                seen.append(k)
+        assert seen == [0, 1]
+        assert [v[0] for _, v in lanes.run(H.work, [7, 8], width=1)] == [107, 108]              # still alive, one lane only
+    with pytest.raises(RuntimeError, match="failed to start"):
+        ProcessLanes(2, setup=H.bad_setup, engine_factory=H.make_engine, start_timeout=120)
+
+
+def test_process_lanes_survive_a_dead_lane():
+    import lane_helpers as H
+    from kimimaro_amd.lanes import ProcessLanes
+    with ProcessLanes(2, setup=H.setup, setup_args=(0,), engine_factory=H.make_engine, start_timeout=120) as lanes:
+        res = {}
+        with pytest.raises(RuntimeError, match="died"):
+            for k, v in lanes.run(H.work, [1, "die", 3, 4]):
+                res[k] = v
+        assert 0 in res
