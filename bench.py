@@ -564,6 +564,24 @@ def main():
                       "note": "latency bound: level-synchronous sweep per label; the wall clock is the largest label whose call "
                               "needed the exact heap emulation"}
 
+    # the labels whose chains set the wall clock of the path kernel (clock64 ticks / 1024 per phase, solo pass)
+    tot = tk["cyc_target"].astype(np.int64) + tk["cyc_rail"].astype(np.int64) + tk["cyc_inval"].astype(np.int64)
+    chains = []
+    for i in np.argsort(-tot)[:4]:
+        chains.append({"voxels": int(tk["count"][i]), "paths": int(tk["n_paths"][i]), "Mcyc_target": round(int(tk["cyc_target"][i]) * 1024 / 1e6, 1),
+                       "Mcyc_rail": round(int(tk["cyc_rail"][i]) * 1024 / 1e6, 1), "Mcyc_inval": round(int(tk["cyc_inval"][i]) * 1024 / 1e6, 1),
+                       "heap_pushes": int(tk["stat_heap_pushes"][i]), "sweep_calls": int(tk["stat_sweep_calls"][i]),
+                       "sweep_bails": int(tk["stat_sweep_bails"][i]), "sweep_levels": int(tk["stat_sweep_levels"][i]),
+                       "sweep_events": int(tk["stat_sweep_events"][i]), "bail_why": int(tk["stat_sweep_why"][i])})
+    nofb = tk["stat_sweep_bails"] == 0
+    chain_info = {"longest": chains,
+                  "sum_Mcyc": {"target": round(float(tk["cyc_target"].astype(np.int64).sum()) * 1024 / 1e6, 0),
+                               "rail": round(float(tk["cyc_rail"].astype(np.int64).sum()) * 1024 / 1e6, 0),
+                               "inval": round(float(tk["cyc_inval"].astype(np.int64).sum()) * 1024 / 1e6, 0),
+                               "inval_of_labels_without_fallback": round(float(tk["cyc_inval"][nofb].astype(np.int64).sum()) * 1024 / 1e6, 0)},
+                  "bail_reasons_or": int(np.bitwise_or.reduce(tk["stat_sweep_why"].astype(np.int64))) if len(tk) else 0,
+                  "labels_bailing_for_arena": int(np.count_nonzero(tk["stat_sweep_why"] & 4))}
+
     cpu = None
     cpu_all = None
     if not args.no_cpu_baseline and world == 1:
@@ -602,7 +620,7 @@ def main():
                                    "skeleton all-gather-v" % world),
                    "volumes_in_flight": inflight},
         "skeletons": nskel, "labels_per_s_by_label_count": round(nskel * (world if args.scaling == "weak" else 1) / (ms_per_step / 1e3), 3),
-        "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep,
+        "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep, "chains": chain_info,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
         "speedup_latency": speedup_latency, "speedup_throughput": speedup_throughput,

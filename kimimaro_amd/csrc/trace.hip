@@ -129,6 +129,10 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t
         const float wn = FIELD ? wfield[v] : g.w[k];
         const float nd = du + wn;
         const uint32_t nb = __float_as_uint(nd);
+        // a look before the atomic: distances only go down, so an edge that cannot lower dist[v] now never will.  Nine
+        // out of ten relaxations end here -- as a read; the atomic they replace is a read-modify-write that leaves its
+        // line dirty even when the minimum does not change (edf_batch_kernel wrote twice as many bytes as it read)
+        if (nb >= __float_as_uint(ld_f32_l2(&dist[v]))) continue;
         const uint32_t old = atomicMin(reinterpret_cast<uint32_t*>(&dist[v]), nb);
         if (nb < old) {
           if (RAIL && old == INF_BITS) {

@@ -47,6 +47,26 @@ def plan_launches(counts, budget):
     return groups
 
 
+SCHED_LEVELS = (1 << 17) - 1     # SW_SCHED_LEVELS (csrc/sweep.h): labels with more levels run the sweep unfiltered
+
+
+def plan_arena(cnt, nlev, filtered):
+    """(log2 slots per chunk, chunks) of the sweep's event arena per label (numpy arrays; csrc/sweep.h: fixed-size chunks of
+    8-byte events chained per level, every level that is ever used holds at least one partly filled chunk).
+    Unfiltered a voxel is handed ~13 events per call; with the pending-deadline filter ~2 (measured at c3: 1.72e9 -> 2.8e8
+    events per volume), and a level of a large call holds tens of events instead of hundreds -- smaller chunks, a quarter of
+    the event budget.  No label uses more levels than it can get events.  An arena that runs out makes the call fall back to
+    the heap emulation (SW_BAIL_ARENA in stat_sweep_why): a matter of speed, not of results."""
+    cnt = np.asarray(cnt, dtype=np.int64)
+    nlev = np.asarray(nlev, dtype=np.int64)
+    filt = np.asarray(filtered, dtype=bool) & (nlev <= SCHED_LEVELS)
+    shift = np.where(filt, np.where(cnt >= 65536, 6, 5), np.where(cnt >= 32768, 7, 6)).astype(np.int64)
+    per_voxel = np.where(filt, 4, 14)
+    levels = np.where(filt, np.minimum(nlev, 3 * cnt + 64), nlev)
+    chunks = np.minimum(levels + levels // 2 + ((per_voxel * cnt) >> shift) + 320, (1 << 22) - 2)
+    return shift, chunks
+
+
 class Engine:
     def __init__(self, device=None):
         self.lib = _abi.require_gpu()
@@ -293,8 +313,7 @@ class Engine:
             d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, rmax)
             nlev = int(np.searchsorted(keys, np.float32(rmax), side="left"))
             if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
-                shift = 7 if cnt >= 32768 else 6
-                chunks = min(nlev + nlev // 2 + ((14 * cnt) >> shift) + 320, (1 << 22) - 2)
+                shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter))
                 wunits = (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256 if nlev > self.sweep_lds_levels else 0
                 ev_units = wunits + ((chunks * 8) << shift) // 256
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
@@ -424,8 +443,7 @@ class Engine:
                 nlev = np.where(ok, nlev, 0)
                 # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
                 # ever used + about 12 events per voxel, with slack
-                shift = np.where(cnt >= 32768, 7, 6).astype(np.int64)
-                chunks = np.minimum(nlev + nlev // 2 + ((14 * cnt) >> shift) + 320, (1 << 22) - 2)
+                shift, chunks = plan_arena(cnt, nlev, self.sweep_filter)
                 wunits = np.where(nlev > self.sweep_lds_levels, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
                 units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
