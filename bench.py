@@ -64,6 +64,9 @@ WORKLOADS = {
     "c2": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
     "c3": ((512, 512, 512), 2124, 16, 3, (16, 16, 40)),
     "c5": ((1024, 1024, 1024), 8192, 24, 5, (8, 8, 40)),
+    # c2 with a soma in its middle: an ellipsoid of 1400 nm radius (~1.1e6 voxels, DBF max above soma_detection_threshold)
+    # with a small internal void, so that the label takes the soma branch of kimimaro/trace.py:108-134 (row f3)
+    "c2soma": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
     "mini": ((128, 128, 64), 40, 8, 4, (16, 16, 40)),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -102,6 +105,13 @@ def make_volume(name):
         q = np.concatenate([base, np.full((base.shape[0], 1), z * anf[2])], axis=1)
         _, idx = tree.query(q, workers=-1)
         lab[:, :, z] = ids[owner[idx]].reshape(shape[0], shape[1], order="F")
+    if name == "c2soma":
+        c = (shp - 1) / 2.0
+        gz = np.arange(shape[2])
+        d2 = (((gx - c[0]) * anf[0]) ** 2 + ((gy - c[1]) * anf[1]) ** 2)[:, :, None] + (((gz - c[2]) * anf[2]) ** 2)[None, None, :]
+        lab[d2 <= 1400.0 ** 2] = np.uint32(999999)
+        v = c + np.array([20.0, -12.0, 4.0])       # the void: a 5 x 5 x 3 box of background off the centre
+        lab[int(v[0]) - 2:int(v[0]) + 3, int(v[1]) - 2:int(v[1]) + 3, int(v[2]) - 1:int(v[2]) + 2] = 0
     if cache:
         os.makedirs(cache, exist_ok=True)
         np.save(path, lab)

@@ -44,7 +44,7 @@ static constexpr uint32_t SW_P = 1u << 16, SW_D = 1u << 17;     // event meta = 
 static constexpr uint32_t SW_CHAIN = 1024;                       // chunks per level the reader can take (LDS list)
 static constexpr uint32_t SW_NOCHUNK = 0x3FFFFFu;                // 22-bit chunk ids
 static constexpr uint32_t SW_SCHED_NONE = 0xFFFFFFFFu;           // sched word of a voxel without a pending deadline
-static constexpr uint32_t SW_SCHED_LEVELS = (1u << 17) - 1u;     // the filter packs the level into 17 bits
+static constexpr uint32_t SW_SCHED_LEVELS = (1u << 17) - 1u;     // with up to 32766 sources (15 bits) the filter holds this many levels
 // bail reasons (kh_label_t.stat_sweep_bail is the OR over the label's calls)
 static constexpr uint32_t SW_BAIL_M = 1, SW_BAIL_CAND = 2, SW_BAIL_ARENA = 4, SW_BAIL_LEVEL = 8, SW_BAIL_LIST = 16,
                           SW_BAIL_UNTOUCHED = 32;
@@ -65,7 +65,7 @@ struct Sweep {
   const uint32_t* nbrmask;
   uint8_t* alive;
   unsigned long long* cstate;
-  uint32_t* sched;                 // per voxel: earliest pending deadline (level << 15 | source + 1), SW_SCHED_NONE = none;
+  uint32_t* sched;                 // per voxel: earliest pending deadline (level << cb | source + 1), SW_SCHED_NONE = none;
                                    // nullptr = no filter (every event is pushed)
   const uint32_t* rank;            // [ra * rb * rc]
   int ra, rb;
@@ -248,29 +248,41 @@ __device__ __forceinline__ uint32_t sweep_nbr_rank(const Sweep& s, const uint4 s
 // test), and a second identical event is a no-op as well (the first adds the candidate / sets the dying bit, the second
 // returns at its first test).  A voxel is handed such events by every neighbour that dies before it does -- about a dozen
 // per voxel, nearly all of them the voxel's own key from the same source -- so unfiltered the sweep stores, reloads and
-// dismisses ~13 events per voxel.  sched[q] holds the smallest (level << 15 | code) over the deadline-carrying events
-// pushed to q so far (code = source + 1 for PD, 0 for a pure D).  A new event is pushed iff it lowers the word (an earlier
+// dismisses ~13 events per voxel.  sched[q] holds the smallest (level << cb | code) over the deadline-carrying events
+// pushed to q so far (code = source + 1 for PD, 0 for a pure D; cb = the bits the codes of THIS call need, so a call with few
+// sources -- a soma's single root, the plates of the reference's tests -- can have millions of levels).  A new event is pushed iff it lowers the word (an earlier
 // deadline) or ties its level under another code (two sources on the same key: the tie the certificate is about).
 // Skipped are only exact duplicates and events at a level above a pending deadline: the machine's states, bails and
 // result are those of the unfiltered sweep.  Every word that is ever set belongs to a voxel that is dead at the end of a
 // certified call (its deadline was processed) and dead voxels are never offered events, so the words of live voxels
 // read SW_SCHED_NONE at the start of every call; a bail resets the label's words together with cstate.
-__device__ __forceinline__ bool sweep_claim(const Sweep& s, uint32_t q, uint32_t tr, uint32_t code) {
-  if (s.sched == nullptr) return true;
-  const uint32_t val = (tr << 15) | code;
-  const uint32_t old = atomicMin(&s.sched[q], val);
-  return val < old || ((old >> 15) == tr && old != val);
+struct SweepFilter {
+  uint32_t* sched;   // nullptr: this call runs unfiltered
+  int cb;            // bits of the source code
+};
+// the filter of a call with npath sources on a label with nlev levels: every (level << cb | code) stays below SW_SCHED_NONE
+__device__ __forceinline__ SweepFilter sweep_filter(const Sweep& s, uint32_t npath) {
+  SweepFilter f;
+  f.cb = 32 - __clz((int)npath);                 // codes 1 .. npath
+  f.sched = (s.sched != nullptr && s.nlev <= (0xFFFFFFFFu >> f.cb)) ? s.sched : nullptr;
+  return f;
+}
+__device__ __forceinline__ bool sweep_claim(const SweepFilter f, uint32_t q, uint32_t tr, uint32_t code) {
+  if (f.sched == nullptr) return true;
+  const uint32_t val = (tr << f.cb) | code;
+  const uint32_t old = atomicMin(&f.sched[q], val);
+  return val < old || ((old >> f.cb) == tr && old != val);
 }
 // a pure P event of q at level tr is a no-op when a deadline of q is pending at an earlier level
-__device__ __forceinline__ bool sweep_moot(const Sweep& s, uint32_t q, uint32_t tr) {
-  return s.sched != nullptr && (sweep_ld(&s.sched[q]) >> 15) < tr;
+__device__ __forceinline__ bool sweep_moot(const SweepFilter f, uint32_t q, uint32_t tr) {
+  return f.sched != nullptr && (sweep_ld(&f.sched[q]) >> f.cb) < tr;
 }
 // the same for neighbours K0 .. K0+12 of v at once (`want`: bit k = neighbour k gets a PD event of source code - 1 at
 // level rk[k - K0]): all atomics are in flight before the first result is looked at.  Returns the events to push.
 // (sched, sx, sxy are handed over in registers: the Sweep record lives in LDS, and a flat atomic counts on the LDS
 // counter as well, so an LDS read between two atomics would wait for the first one to return)
 template <int K0>
-__device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, int sx, int sxy, uint32_t v, uint32_t want,
+__device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, int cb, int sx, int sxy, uint32_t v, uint32_t want,
                                                   const uint32_t (&rk)[13], uint32_t code) {
   uint32_t old[13];
 #pragma unroll
@@ -279,13 +291,13 @@ __device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, 
     int dx, dy, dz;
     dir_delta(k, dx, dy, dz);
     old[j] = 0u;
-    if ((want >> k) & 1u) old[j] = atomicMin(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)], (rk[j] << 15) | code);
+    if ((want >> k) & 1u) old[j] = atomicMin(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)], (rk[j] << cb) | code);
   }
   uint32_t keep = 0;
 #pragma unroll
   for (int j = 0; j < 13; j++) {
-    const uint32_t val = (rk[j] << 15) | code;
-    keep |= (uint32_t)(val < old[j] || ((old[j] >> 15) == rk[j] && old[j] != val)) << (K0 + j);
+    const uint32_t val = (rk[j] << cb) | code;
+    keep |= (uint32_t)(val < old[j] || ((old[j] >> cb) == rk[j] && old[j] != val)) << (K0 + j);
   }
   return keep & want;
 }
@@ -347,7 +359,8 @@ __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uin
 }
 
 // P events of the pair (v, c) to the levels above lvl (the pair was added by a pure P event and v survives the level)
-__device__ __forceinline__ void sweep_emit_possible(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v, uint32_t c) {
+__device__ __forceinline__ void sweep_emit_possible(const Sweep& s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
+                                                    uint32_t c) {
   const uint32_t nm = s.nbrmask[v];
   const uint4 src = s.srcs[c];
   const uint32_t am = sweep_alive_nbrs(s, v, nm);
@@ -359,21 +372,21 @@ __device__ __forceinline__ void sweep_emit_possible(const Sweep& s, uint32_t& sp
   for (uint32_t m = sweep_above(rk0, rk1, cov, lvl); m; m &= m - 1u) {
     uint32_t q;
     const uint32_t r = sweep_nbr_rank(s, src, v, x, y, z, __ffs((int)m) - 1, q);
-    if (!sweep_moot(s, q, r)) sweep_push(s, spare, r, q, c | SW_P);
+    if (!sweep_moot(flt, q, r)) sweep_push(s, spare, r, q, c | SW_P);
   }
 }
 
 // the neighbours of a dying voxel with a single candidate source: covered ones die with it (deadline at their own key)
-__device__ __forceinline__ void sweep_deadline_one(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v, uint32_t cid,
-                                                   const uint4 src, int x, int y, int z, uint32_t am) {
+__device__ __forceinline__ void sweep_deadline_one(const Sweep& s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
+                                                   uint32_t cid, const uint4 src, int x, int y, int z, uint32_t am) {
   uint32_t rk0[13], rk1[13];
   const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
   const uint32_t up = sweep_above(rk0, rk1, cov, lvl);   // covered neighbours whose own key lies above this level: a PD event there
   uint32_t push = up;
-  uint32_t* const sched = s.sched;
-  if (sched != nullptr) {
+  if (flt.sched != nullptr) {
     const int sx = s.g->sx, sxy = s.g->sxy;
-    push = sweep_claim13<0>(sched, sx, sxy, v, up, rk0, cid + 1u) | sweep_claim13<13>(sched, sx, sxy, v, up, rk1, cid + 1u);
+    push = sweep_claim13<0>(flt.sched, flt.cb, sx, sxy, v, up, rk0, cid + 1u) |
+           sweep_claim13<13>(flt.sched, flt.cb, sx, sxy, v, up, rk1, cid + 1u);
   }
   for (uint32_t m = cov & ~up; m; m &= m - 1u) {      // same level: the cascade of this level
     const uint32_t q = v + (uint32_t)s.g->off[__ffs((int)m) - 1];
@@ -389,7 +402,7 @@ __device__ __forceinline__ void sweep_deadline_one(const Sweep& s, uint32_t& spa
 }
 
 // a D event: v is dead once this level is complete
-__device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, uint32_t lvl, uint32_t v) {
+__device__ __forceinline__ void sweep_deadline(const Sweep& s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v) {
   const uint8_t live = s.alive[v];
   const uint32_t nm = s.nbrmask[v];
   if (!live) return;
@@ -421,7 +434,7 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
     uint4 s1 = src[0];
 #pragma unroll
     for (int i = 1; i < 4; i++) if (has[i]) { c1 = cid[i]; s1 = src[i]; }
-    sweep_deadline_one(s, spare, lvl, v, c1, s1, x, y, z, am);
+    sweep_deadline_one(s, flt, spare, lvl, v, c1, s1, x, y, z, am);
     return;
   }
   for (uint32_t m = am; m; m &= m - 1u) {
@@ -447,13 +460,13 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, uint32_t& spare, 
         if (s.cstate[q] & SW_DYING) continue;
         const uint32_t p = atomicAdd(&s.sh->nb, 1u);
         if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
-      } else if (sweep_claim(s, q, tr, 0u)) {
+      } else if (sweep_claim(flt, q, tr, 0u)) {
         sweep_push(s, spare, tr, q, SW_D);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      if (cov[i] && rk[i] > lvl && !sweep_moot(s, q, rk[i])) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
+      if (cov[i] && rk[i] > lvl && !sweep_moot(flt, q, rk[i])) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
   }
 }
 
@@ -473,6 +486,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
                                                      uint32_t* count) {
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   SweepShared* sh = s.sh;
+  const SweepFilter flt = sweep_filter(s, npath);
   uint32_t spare = SW_NONE;
   const uint32_t EMPTY = (SW_NOCHUNK << 10) | (1u << s.shift);
   const uint32_t nwords = (s.nlev >> 5) + 1u;
@@ -588,7 +602,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     // ---- B: deadlines (a voxel's candidates are complete now)
     for (uint32_t e = tid; e < nev; e += nthr) {
       const uint2 ev = sweep_event(s, e, newest);
-      if (ev.y & SW_D) sweep_deadline(s, spare, lvl, ev.x);
+      if (ev.y & SW_D) sweep_deadline(s, flt, spare, lvl, ev.x);
     }
     __syncthreads();
     SW_T(6)   // B
@@ -598,7 +612,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
       if (tid == 0) sh->snap = avail;
       __syncthreads();
       const uint32_t end = sh->snap;
-      for (uint32_t i = done + tid; i < end; i += nthr) sweep_deadline(s, spare, lvl, s.wb[i]);
+      for (uint32_t i = done + tid; i < end; i += nthr) sweep_deadline(s, flt, spare, lvl, s.wb[i]);
       done = end;
       __syncthreads();
     }
@@ -609,7 +623,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
       for (uint32_t i = tid; i < nnp; i += nthr) {
         const unsigned long long it = s.np[i];
         const uint32_t v = (uint32_t)(it >> 32);
-        if (!(s.cstate[v] & SW_DYING)) sweep_emit_possible(s, spare, lvl, v, (uint32_t)it);
+        if (!(s.cstate[v] & SW_DYING)) sweep_emit_possible(s, flt, spare, lvl, v, (uint32_t)it);
       }
     }
   }

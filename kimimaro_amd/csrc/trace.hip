@@ -764,7 +764,7 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.nbrmask = nbrmask;
   sw.alive = alive;
   sw.cstate = sg.cstate;
-  sw.sched = nlev <= SW_SCHED_LEVELS ? sg.sched : nullptr;
+  sw.sched = sg.sched;
   sw.rank = nlev ? sg.rank : nullptr;
   sw.ra = sg.ra; sw.rb = sg.rb;
   // the heap's HBM slice (>= 3 * nf + 256 nodes of 16 bytes) is free while the sweep runs: source records

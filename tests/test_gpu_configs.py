@@ -182,3 +182,19 @@ def test_all_gather_v_over_rccl_on_the_device(eng):
     assert sorted(merged) == sorted(local)
     for k in local:
         _same(merged[k], local[k], k)
+
+
+def test_soma_of_the_c2soma_workload_matches_oracle(eng):
+    """row f3 at a size that matters: the 1.1e6-voxel ellipsoid of bench.py's `c2soma` workload (DBF max 1400 nm above
+    soma_detection_threshold, a 5 x 5 x 3 void inside) takes the soma branch of kimimaro/trace.py:108-134 -- fill_voids, EDT of
+    the filled crop, soma root, the one-off soma invalidation, free_space_radius -- and must give the oracle's skeleton."""
+    import bench
+    import kimimaro_amd
+    from oracle import pipeline as P
+    lab, an = bench.make_volume("c2soma")
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    kw = dict(anisotropy=an, dust_threshold=1000, fix_borders=True, fix_branching=True, object_ids=[999999])
+    got = kimimaro_amd.skeletonize(lab, params, progress=False, _engine=eng, **kw)
+    want = P.skeletonize(lab, params, **kw)
+    assert sorted(got) == sorted(want) == [999999] and want[999999].vertices.shape[0] > 50
+    _same(got[999999], want[999999], 999999)
