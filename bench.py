@@ -454,6 +454,21 @@ def main():
     preamble_s = prepare(args.scaling)
     elapsed = measure(args.scaling, args.warmup, args.steps)
     close_process_lanes()                  # (their HBM goes back before the instrumented pass of this process)
+    # what the lanes' last volumes looked like UNDER LOAD (thread lanes: the engines are still there): the longest chain of
+    # each and the cycle sums, to be read against the solo pass below (`chains`)
+    loaded = None
+    if lanes is not None:
+        loaded = []
+        for e_ in lanes.engines:
+            lt = e_.last_tasks
+            if lt is None or not len(lt):
+                continue
+            tot_ = lt["cyc_target"].astype(np.int64) + lt["cyc_rail"].astype(np.int64) + lt["cyc_inval"].astype(np.int64)
+            j = int(np.argmax(tot_))
+            loaded.append({"longest_voxels": int(lt["count"][j]), "longest_Mcyc": round(int(tot_[j]) * 1024 / 1e6, 1),
+                           "longest_heap_pushes": int(lt["stat_heap_pushes"][j]),
+                           "sum_Mcyc_inval": round(float(lt["cyc_inval"].astype(np.int64).sum()) * 1024 / 1e6, 0),
+                           "sum_Mcyc_rail": round(float(lt["cyc_rail"].astype(np.int64).sum()) * 1024 / 1e6, 0)})
     inflight = widths[args.scaling]
     # ---- instrumented pass (phase times, sweep statistics): one volume alone, on lane 0 while its scratch pool is warm
     import contextlib
@@ -630,7 +645,7 @@ def main():
                                    "skeleton all-gather-v" % world),
                    "volumes_in_flight": inflight},
         "skeletons": nskel, "labels_per_s_by_label_count": round(nskel * (world if args.scaling == "weak" else 1) / (ms_per_step / 1e3), 3),
-        "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep, "chains": chain_info,
+        "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep, "chains": chain_info, "chains_under_load": loaded,
         "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
         "speedup_latency": speedup_latency, "speedup_throughput": speedup_throughput,
