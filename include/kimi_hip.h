@@ -142,6 +142,11 @@ typedef struct kh_label_t {
   uint32_t stat_sweep_levels; /* out: levels processed */
   uint32_t stat_sweep_events; /* out: events processed (low 32 bits) */
   uint32_t stat_sweep_why;    /* out: OR of the bail reasons (sweep.h SW_BAIL_*) */
+  uint32_t lev_window;   /* in: 0, or a power of two (>= 64) larger than the number of levels any event of this label can lie
+                            ahead of the level being processed (= distinct keys within one 26-neighbour step of any key below
+                            the label's radius, from the key table): the label then keeps lev_window level words, used round
+                            robin, instead of nlev.  A bound that turns out too small costs speed, not results (the event
+                            abandons the call to the heap emulation). */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
@@ -193,9 +198,10 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * std::priority_queue otherwise.  The sweep needs: level_rank = u32 [ra, rb, rc] table (x fastest) of the rank of
  * the key of offset (a, b, c) among the distinct keys (kh_level_keys + sort/unique by the caller), cstate = one
  * zeroed u64 per voxel (zero again on exit), event_arena = 256-byte aligned scratch addressed by ev_offset /
- * ev_chunks / ev_shift / nlev of each task; max_nlev = the largest task.nlev that is <= KH_SWEEP_LDS_LEVELS (sizes
- * the LDS of the launch); a task with more levels keeps its 4-byte level words and the bitmap (nlev / 8 bytes), rounded
- * up to 256 bytes, at the front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
+ * ev_chunks / ev_shift / nlev / lev_window of each task; max_nlev = the number of level words every workgroup of the launch
+ * gets in LDS (<= KH_SWEEP_LDS_LEVELS): a task keeps its words there when its lev_window (if non-zero) or else its nlev fits;
+ * any other task keeps 4-byte words for all its nlev levels and the bitmap (nlev / 8 bytes), rounded up to 256 bytes, at the
+ * front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
  * sched (nullable) = one u32 per voxel, 0xFFFFFFFF on entry for every voxel that is alive (and again on exit): the sweep's
  * pending-deadline filter (csrc/sweep.h) -- with it a voxel is handed ~1.3 events per call instead of ~13; NULL = unfiltered.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant); KH_TRACE_HEAP_PRIO see below.
@@ -203,6 +209,8 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * from the root, paths returned root -> target.                                                  */
 #define KH_TRACE_PROFILE 1
 #define KH_TRACE_HEAP_PRIO 2   /* the wave running the heap emulation raises its issue priority (several volumes in flight) */
+#define KH_TRACE_THREADS_64 4  /* workgroups of 64 threads (one wave per label, up to 12 labels per CU) instead of 256 */
+#define KH_TRACE_THREADS_128 8 /* workgroups of 128 threads */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,

@@ -29,7 +29,7 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 46 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 47 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
@@ -42,9 +42,9 @@ LABEL_T = np.dtype([
     ("soma_mode", "<u4"), ("fsr", "<f4"), ("soma_radius", "<f4"), ("soma_scale", "<f4"), ("soma_const", "<f4"),
     ("nlev", "<u4"), ("sweep_rmax", "<f4"), ("ev_offset", "<u4"), ("ev_chunks", "<u4"), ("ev_shift", "<u4"),
     ("stat_sweep_calls", "<u4"), ("stat_sweep_bails", "<u4"), ("stat_sweep_levels", "<u4"), ("stat_sweep_events", "<u4"),
-    ("stat_sweep_why", "<u4"),
+    ("stat_sweep_why", "<u4"), ("lev_window", "<u4"),
 ])
-assert LABEL_T.itemsize == 184
+assert LABEL_T.itemsize == 188
 SWEEP_LDS_LEVELS = 16384  # KH_SWEEP_LDS_LEVELS
 SWEEP_MAX_LEVELS = 1 << 22  # labels with more levels than this use the heap emulation only
 PDRF_BASE, PDRF_FINISH = -1, -2  # KH_PDRF_BASE / KH_PDRF_FINISH

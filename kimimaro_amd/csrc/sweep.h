@@ -41,7 +41,7 @@ namespace kh {
 static constexpr uint32_t SW_NONE = 0xFFFFFFFFu;
 static constexpr unsigned long long SW_DYING = 1ull << 63;
 static constexpr uint32_t SW_P = 1u << 16, SW_D = 1u << 17;     // event meta = source index (15 bits) | type
-static constexpr uint32_t SW_CHAIN = 1024;                       // chunks per level the reader can take (LDS list)
+static constexpr uint32_t SW_CHAIN = 512;                        // chunks per level the reader can take (LDS list)
 static constexpr uint32_t SW_NOCHUNK = 0x3FFFFFu;                // 22-bit chunk ids
 static constexpr uint32_t SW_SCHED_NONE = 0xFFFFFFFFu;           // sched word of a voxel without a pending deadline
 static constexpr uint32_t SW_SCHED_LEVELS = (1u << 17) - 1u;     // with up to 32766 sources (15 bits) the filter holds this many levels
@@ -76,8 +76,11 @@ struct Sweep {
   uint32_t* killed;                // HBM log of the voxels killed by this call
   uint32_t nlev;
   // LDS
-  uint32_t* words;                 // [nlev] (newest chunk << 10) | next free slot
-  uint32_t* lvbits;                // [nlev / 32 + 1] non-empty levels
+  uint32_t* words;                 // [nslots] (newest chunk << 10) | next free slot of level lv at words[lv & wmask]
+  uint32_t* lvbits;                // [nslots / 32 + 1] non-empty levels (bit lv & wmask)
+  uint32_t nslots, wmask;          // level window: nslots = a power of two and wmask = nslots - 1 when every pending event
+                                   // lies less than nslots levels ahead of the level being processed (the slots are then
+                                   // used round robin); nslots = nlev, wmask = all ones otherwise
   uint32_t* chain;                 // [SW_CHAIN] chunks of the level being processed, newest first
   SweepShared* sh;
   // HBM lists of the level being processed (label-private scratch)
@@ -122,8 +125,16 @@ __device__ __forceinline__ bool sweep_eval(const Sweep& s, const uint4 src, int 
 // installs a fresh chunk with a CAS on the overfull word and takes its slot 1; whoever loses that race just starts over,
 // and the chunk it had reserved stays with the thread (`spare`) for its next opening.  The fill field of a full chunk
 // keeps counting (at most one add per thread before the install: < 1024), readers clamp it to the chunk size.
-__device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint32_t lv, uint32_t vox, uint32_t meta) {
-  uint32_t* word = &s.words[lv];
+// Level window.  An event goes to a level ahead of the one being processed (`cur`), and never far ahead: its key is the
+// distance of a NEIGHBOUR of the processed voxel from a source whose key of that voxel is not above the current level, so
+// it exceeds the current key by one step at most -- a few hundred to a few thousand levels, which the host bounds from the
+// key table (kh_label_t.lev_window).  The level words are therefore kept for a window of nslots levels only, level lv in
+// slot lv & wmask: 4-8 KiB of LDS instead of 4 bytes for every level of the label.  The bound is checked, not trusted: an
+// event that would leave the window abandons the call (SW_BAIL_LEVEL -> heap emulation).
+__device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint32_t cur, uint32_t lv, uint32_t vox, uint32_t meta) {
+  if (lv - cur > s.wmask) { sweep_bail(s, SW_BAIL_LEVEL); return; }      // (wmask = all ones: never)
+  const uint32_t slot = lv & s.wmask;
+  uint32_t* word = &s.words[slot];
   const uint32_t CH = 1u << s.shift;
   for (;;) {
     const uint32_t w = atomicAdd(word, 1u);
@@ -146,7 +157,7 @@ __device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint
     if (!mine) continue;
     spare = SW_NONE;
     const uint32_t prev = cur >> 10;
-    if (prev == SW_NOCHUNK) atomicOr(&s.lvbits[lv >> 5], 1u << (lv & 31u));
+    if (prev == SW_NOCHUNK) atomicOr(&s.lvbits[slot >> 5], 1u << (slot & 31u));
     uint2* c = s.chunks + ((size_t)id << s.shift);
     c[0] = make_uint2(prev, 0u);
     c[1] = make_uint2(vox, meta);
@@ -372,7 +383,7 @@ __device__ __forceinline__ void sweep_emit_possible(const Sweep& s, const SweepF
   for (uint32_t m = sweep_above(rk0, rk1, cov, lvl); m; m &= m - 1u) {
     uint32_t q;
     const uint32_t r = sweep_nbr_rank(s, src, v, x, y, z, __ffs((int)m) - 1, q);
-    if (!sweep_moot(flt, q, r)) sweep_push(s, spare, r, q, c | SW_P);
+    if (!sweep_moot(flt, q, r)) sweep_push(s, spare, lvl, r, q, c | SW_P);
   }
 }
 
@@ -397,7 +408,7 @@ __device__ __forceinline__ void sweep_deadline_one(const Sweep& s, const SweepFi
   for (uint32_t m = push; m; m &= m - 1u) {
     uint32_t q;
     const uint32_t tr = sweep_nbr_rank(s, src, v, x, y, z, __ffs((int)m) - 1, q);
-    sweep_push(s, spare, tr, q, cid | SW_P | SW_D);
+    sweep_push(s, spare, lvl, tr, q, cid | SW_P | SW_D);
   }
 }
 
@@ -461,12 +472,12 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, const SweepFilter
         const uint32_t p = atomicAdd(&s.sh->nb, 1u);
         if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
       } else if (sweep_claim(flt, q, tr, 0u)) {
-        sweep_push(s, spare, tr, q, SW_D);
+        sweep_push(s, spare, lvl, tr, q, SW_D);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      if (cov[i] && rk[i] > lvl && !sweep_moot(flt, q, rk[i])) sweep_push(s, spare, rk[i], q, cid[i] | SW_P);
+      if (cov[i] && rk[i] > lvl && !sweep_moot(flt, q, rk[i])) sweep_push(s, spare, lvl, rk[i], q, cid[i] | SW_P);
   }
 }
 
@@ -489,8 +500,8 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
   const SweepFilter flt = sweep_filter(s, npath);
   uint32_t spare = SW_NONE;
   const uint32_t EMPTY = (SW_NOCHUNK << 10) | (1u << s.shift);
-  const uint32_t nwords = (s.nlev >> 5) + 1u;
-  for (uint32_t i = tid; i < s.nlev; i += nthr) s.words[i] = EMPTY;
+  const uint32_t nwords = (s.nslots >> 5) + 1u;
+  for (uint32_t i = tid; i < s.nslots; i += nthr) s.words[i] = EMPTY;
   for (uint32_t i = tid; i < nwords; i += nthr) s.lvbits[i] = 0u;
   if (tid == 0) {
     sh->na = sh->nb = sh->nnp = sh->bump = sh->nkill = sh->snap = sh->bail = 0u;
@@ -513,7 +524,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
   }
   __syncthreads();
   if (sh->bail) return false;
-  for (uint32_t i = tid; i < npath; i += nthr) if (s.alive[path[i]]) sweep_push(s, spare, 0u, path[i], i | SW_P | SW_D);
+  for (uint32_t i = tid; i < npath; i += nthr) if (s.alive[path[i]]) sweep_push(s, spare, 0u, 0u, path[i], i | SW_P | SW_D);
 #ifdef KH_SWEEP_PROBE
   long long tq = clock64();
 #define SW_T(i) if (tid == 0) { const long long n_ = clock64(); sh->cyc[i] += n_ - tq; tq = n_; }
@@ -534,25 +545,49 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     SW_T(0)   // commit
     if (wave == 0) {
       uint32_t found = SW_NONE;
-      const uint32_t w0 = next_from >> 5;
-      for (uint32_t base = w0; base < nwords; base += 64u) {
-        const uint32_t idx = base + (uint32_t)lane;
-        uint32_t v = idx < nwords ? sweep_ld(&s.lvbits[idx]) : 0u;
-        if (idx == w0) v &= ~((1u << (next_from & 31u)) - 1u);
-        const unsigned long long ball = __builtin_amdgcn_ballot_w64(v != 0u);
-        if (ball) {
-          const int l = __ffsll((long long)ball) - 1;
-          const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
-          found = ((base + (uint32_t)l) << 5) + (uint32_t)(__ffs((int)vv) - 1);
-          break;
+      if (s.wmask == 0xFFFFFFFFu) {
+        // one bit per level of the label: the first set bit at or above next_from
+        const uint32_t w0 = next_from >> 5;
+        for (uint32_t base = w0; base < nwords; base += 64u) {
+          const uint32_t idx = base + (uint32_t)lane;
+          uint32_t v = idx < nwords ? sweep_ld(&s.lvbits[idx]) : 0u;
+          if (idx == w0) v &= ~((1u << (next_from & 31u)) - 1u);
+          const unsigned long long ball = __builtin_amdgcn_ballot_w64(v != 0u);
+          if (ball) {
+            const int l = __ffsll((long long)ball) - 1;
+            const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+            found = ((base + (uint32_t)l) << 5) + (uint32_t)(__ffs((int)vv) - 1);
+            break;
+          }
+        }
+      } else {
+        // level window: the bits are used round robin; walk them from slot next_from & wmask once around (step j looks at
+        // bitmap word (w0 + j) mod nw; the first word is split: its bits from p0 up open the walk, those below p0 close it)
+        const uint32_t nw = s.nslots >> 5, p0 = next_from & s.wmask, w0 = p0 >> 5, lowbits = (1u << (p0 & 31u)) - 1u;
+        for (uint32_t base = 0; base <= nw; base += 64u) {
+          const uint32_t j = base + (uint32_t)lane;
+          const uint32_t wi = (w0 + j) & (nw - 1u);
+          uint32_t v = j <= nw ? sweep_ld(&s.lvbits[wi]) : 0u;
+          if (j == 0u) v &= ~lowbits;
+          if (j == nw) v &= lowbits;
+          const unsigned long long ball = __builtin_amdgcn_ballot_w64(v != 0u);
+          if (ball) {
+            const int l = __ffsll((long long)ball) - 1;
+            const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+            const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)wi, l);
+            const uint32_t slot = (wl << 5) + (uint32_t)(__ffs((int)vv) - 1);
+            found = next_from + ((slot - p0) & s.wmask);
+            break;
+          }
         }
       }
       if (lane == 0) {
         if (sh->bail) found = SW_NONE;   // the only place the loop's exit is decided: every thread reads sh->lvl
         sh->lvl = found;
         if (found != SW_NONE) {
-          const uint32_t w = atomicExch(&s.words[found], EMPTY);
-          atomicAnd(&s.lvbits[found >> 5], ~(1u << (found & 31u)));
+          const uint32_t fslot = found & s.wmask;
+          const uint32_t w = atomicExch(&s.words[fslot], EMPTY);
+          atomicAnd(&s.lvbits[fslot >> 5], ~(1u << (fslot & 31u)));
           // the level's chunks, newest first (a chain of dependent loads: one per chunk)
           uint32_t n = 0;
           for (uint32_t id = w >> 10; id != SW_NOCHUNK; id = s.chunks[(size_t)id << s.shift].x) {

@@ -778,7 +778,11 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   // level words + non-empty bitmap: LDS when they fit the launch's allotment, else the front of the arena (same
   // code path: the pointers are generic)
   const size_t wbytes = (((size_t)nlev * 4u + ((size_t)(nlev >> 5) + 2u) * 4u) + 255u) & ~(size_t)255u;
-  const bool in_lds = nlev <= sg.lds_levels;
+  const uint32_t win = task->lev_window;
+  const bool windowed = win >= 64u && (win & (win - 1u)) == 0u && win <= sg.lds_levels;   // round-robin words in LDS
+  const bool in_lds = windowed || nlev <= sg.lds_levels;
+  sw.nslots = windowed ? win : nlev;
+  sw.wmask = windowed ? win - 1u : 0xFFFFFFFFu;
   sw.chunks = reinterpret_cast<uint2*>(in_lds ? ar : ar + wbytes);
   sw.chcap = task->ev_chunks;
   sw.shift = (int)task->ev_shift;
@@ -786,7 +790,7 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.nlev = nlev;
   sw.chain = reinterpret_cast<uint32_t*>(lds);
   sw.words = in_lds ? sw.chain + SW_CHAIN : reinterpret_cast<uint32_t*>(ar);
-  sw.lvbits = sw.words + nlev;
+  sw.lvbits = sw.words + sw.nslots;
   sw.sh = swsh;
 }
 
@@ -1182,7 +1186,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
-                        int fix_branching, const SweepGlobal& sg, uint32_t max_nlev) {
+                        int fix_branching, const SweepGlobal& sg, uint32_t max_nlev, unsigned nthreads) {
   if (count <= 0) return KH_OK;
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
@@ -1195,8 +1199,6 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
     KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
-  const char* thr_env = getenv("KH_TRACE_THREADS");   // developer knob
-  const unsigned nthreads = thr_env ? (unsigned)atoi(thr_env) : 256u;
   hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
                      path_lengths, fix_branching, sg);
@@ -1242,7 +1244,12 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
-  if (flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO)) { set_error("kh_trace_paths: unknown flags"); return KH_EINVAL; }
+  if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128)) ||
+      ((flags & KH_TRACE_THREADS_64) && (flags & KH_TRACE_THREADS_128))) {
+    set_error("kh_trace_paths: unknown flags");
+    return KH_EINVAL;
+  }
+  const unsigned nthreads = (flags & KH_TRACE_THREADS_64) ? 64u : (flags & KH_TRACE_THREADS_128) ? 128u : 256u;
   if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
                      ((uintptr_t)event_arena & 255) != 0)) {
     set_error("kh_trace_paths: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
@@ -1262,10 +1269,10 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                    scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                   (uint32_t)max_nlev)
+                                   (uint32_t)max_nlev, nthreads)
               : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                     scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                    (uint32_t)max_nlev);
+                                    (uint32_t)max_nlev, nthreads);
 }
 
 extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,

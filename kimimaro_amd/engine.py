@@ -67,6 +67,24 @@ def plan_arena(cnt, nlev, filtered):
     return shift, chunks
 
 
+def level_windows(keys, anisotropy, nlev, lds_levels):
+    """kh_label_t.lev_window per label (numpy u32): a power of two above the number of levels an event can lie ahead of the
+    level being processed, or 0 when that does not fit `lds_levels` words.  An event's key is the distance of a 26-neighbour
+    of the processed voxel from a source whose key of that voxel is not above the current one, so it exceeds the current key
+    by one step (the longest neighbour offset) at most: the bound is the largest number of distinct keys in such an interval
+    over the label's levels, taken from the sorted key table itself (+ slack for the keys' own rounding)."""
+    keys = np.asarray(keys, dtype=np.float64)
+    nlev = np.asarray(nlev, dtype=np.int64)
+    if keys.size == 0:
+        return np.zeros(nlev.shape, dtype=np.uint32)
+    step = float(np.sqrt(sum(float(np.float32(a)) ** 2 for a in anisotropy)))
+    ahead = np.searchsorted(keys, (keys + step) * (1.0 + 1e-6) + 1e-6, side="right") - 1 - np.arange(keys.size)
+    worst = np.maximum.accumulate(ahead)                         # worst[i] = most levels ahead over levels 0..i
+    w = worst[np.clip(nlev - 1, 0, keys.size - 1)] + 2
+    win = np.maximum(64, 2 ** np.ceil(np.log2(np.maximum(w, 1))).astype(np.int64))
+    return np.where((nlev > 0) & (win <= int(lds_levels)), win, 0).astype(np.uint32)
+
+
 class Engine:
     def __init__(self, device=None):
         self.lib = _abi.require_gpu()
@@ -84,6 +102,8 @@ class Engine:
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
+        self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
+        self.trace_threads = int(os.environ.get("KH_TRACE_THREADS", "256"))  # threads per label in the path loop: 64, 128 or 256
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
         # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
@@ -314,10 +334,13 @@ class Engine:
             nlev = int(np.searchsorted(keys, np.float32(rmax), side="left"))
             if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
                 shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter))
-                wunits = (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256 if nlev > self.sweep_lds_levels else 0
+                win = int(level_windows(keys, anisotropy, [nlev], self.sweep_lds_levels)[0]) if self.sweep_window else 0
+                in_lds = win > 0 or nlev <= self.sweep_lds_levels
+                wunits = 0 if in_lds else (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256
                 ev_units = wunits + ((chunks * 8) << shift) // 256
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
-                max_nlev = nlev if nlev <= self.sweep_lds_levels else 0
+                task["lev_window"] = win
+                max_nlev = win if win > 0 else (nlev if in_lds else 0)
             else:
                 d_rank = None
         d_arena = self.empty(max(ev_units, 1) * 32 + 32, t.int64)
@@ -444,7 +467,10 @@ class Engine:
                 # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
                 # ever used + about 12 events per voxel, with slack
                 shift, chunks = plan_arena(cnt, nlev, self.sweep_filter)
-                wunits = np.where(nlev > self.sweep_lds_levels, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256, 0)  # level words in HBM
+                win = level_windows(keys, anisotropy, nlev, self.sweep_lds_levels).astype(np.int64) if self.sweep_window \
+                    else np.zeros(nl, dtype=np.int64)
+                in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)
+                wunits = np.where(in_lds, 0, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256)  # level words in HBM
                 units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
                 ev_total = int(units.sum())
@@ -458,8 +484,9 @@ class Engine:
                 tasks["ev_shift"] = shift
                 if int(nlev.max()) == 0:
                     d_rank = None
-                fits = nlev[nlev <= self.sweep_lds_levels]
-                max_nlev = int(fits.max()) if fits.size else 0
+                tasks["lev_window"] = win
+                in_words = np.where(win > 0, win, np.where(in_lds, nlev, 0))     # LDS words each label wants
+                max_nlev = int(in_words.max()) if in_words.size else 0
         tgt = []
         tgt_off = np.zeros(nl, dtype=np.int64)
         for s, o in enumerate(order):
@@ -539,7 +566,8 @@ class Engine:
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
         # are consumed incrementally they go to a second stream and the others are collected while they still run
         n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
-        prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0)      # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO
+        # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 / _128
+        prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0)
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
 
         def launch(first, count, stream):
