@@ -338,18 +338,19 @@ def main():
     def width_of(mode):
         if args.inflight > 0:
             return args.inflight
-        if args.workload == "c5":      # 40 B per voxel of whole-volume fields per lane: one volume at a time
-            return 1
-        if mode == "strong" and world > 1:
-            # a rank's share of a volume shrinks with N, the chain of its largest component does not: more volumes in
-            # flight.  Sized from the HBM that is free now and what a lane reserves (measured at c3 on one GPU: ~7 GB of
-            # whole-volume fields + ~37 GB of per-label scratch for ALL components, of which a rank holds 1 / N), 75 % of
-            # the free memory at most, 4 .. 12 lanes.
-            nvox_rel = float(np.prod(WORKLOADS[args.workload][0])) / 512.0 ** 3
-            per_lane = (7.0 + 37.0 / world) * nvox_rel * 1e9
-            free_b = torch.cuda.mem_get_info()[0]
-            return int(max(4, min(12, (0.75 * free_b) // per_lane)))
-        return 4
+        # A lane costs HBM: the whole-volume fields of its volume (~7.5 GB at 512^3) + the per-label scratch of the components
+        # it traces (~12 GB for all components of c3; a rank of the strong mode holds 1 / N of them).  As many lanes as 70 %
+        # of the memory that is free now pays for, 12 at most: the step time keeps falling up to there (one volume's chain
+        # of ~3 s is overlapped by the others' GPU-filling phases; measured at c3: 4 / 8 lanes = 1220 / 784 ms per step).
+        nvox_rel = float(np.prod(WORKLOADS[args.workload][0])) / 512.0 ** 3
+        share = world if (mode == "strong" and world > 1) else 1
+        per_lane = (7.5 + 12.0 / share) * nvox_rel * 1e9
+        free_b = torch.cuda.mem_get_info()[0]
+        most = int(max(1, min(12, (0.70 * free_b) // per_lane)))
+        # K equal volumes started together stay in lock step, so a run of K steps is ceil(K / lanes) rounds: the fewest
+        # rounds the memory allows, and no more lanes than fill them evenly (K = 20: 10 + 10 rather than 12 + 8)
+        rounds = -(-max(args.steps, 1) // most)
+        return int(-(-max(args.steps, 1) // rounds))
 
     widths = {m: width_of(m) for m in (("weak", "strong") if world > 1 else (args.scaling,))}
     if dist:
@@ -403,21 +404,19 @@ def main():
     def measure(mode, warmup, steps, latency=True):
         width = widths[mode]
         torch.cuda.empty_cache()           # scratch of the other mode / of the preparation goes back to the device
+        if latency:
+            # one volume alone on an otherwise idle GPU, the way kimimaro_amd.skeletonize() runs it (default engine: 256 threads
+            # per label, the largest labels on a second stream): its latency, untimed; twice, the first call fills the pool
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                state["single_ms"] = (time.perf_counter() - t1) * 1e3
+            torch.cuda.empty_cache()
         open_process_lanes(width)
         if width > 1:
             run_steps(width, width)        # every lane once: fills the scratch pool of its stream (not a warm-up step)
-        if latency:
-            t1 = time.perf_counter()
-            if plane["obj"] is not None:   # one volume alone on an otherwise idle GPU: its latency (also untimed)
-                for _, local in plane["obj"].run(_lane_step, [None], width=1):
-                    finish(local)
-            elif lanes is not None:
-                for _, local in lanes.run(lambda e, k: local_step(e), 1, width=1):
-                    finish(local)
-            else:
-                step()
-            torch.cuda.synchronize()
-            state["single_ms"] = (time.perf_counter() - t1) * 1e3
         run_steps(warmup, width)
         if dist:
             dist.barrier()
@@ -488,6 +487,7 @@ def main():
             intake.skeletonize_cc(ieng, intake.LazyVolume(ieng, i_cc, lab0.shape), i_n, {i + 1: i_orig[i].item() for i in range(i_n)},
                                   params, an, dust, True, fix_borders, empty, empty, black_border=False, d_cc=i_cc, timings=timings)
             tk = ieng.last_tasks
+            state["retries"] = getattr(ieng, "last_retries", 0)
             del i_cc
     lanes = None
     torch.cuda.empty_cache()
@@ -605,7 +605,9 @@ def main():
                                "inval": round(float(tk["cyc_inval"].astype(np.int64).sum()) * 1024 / 1e6, 0),
                                "inval_of_labels_without_fallback": round(float(tk["cyc_inval"][nofb].astype(np.int64).sum()) * 1024 / 1e6, 0)},
                   "bail_reasons_or": int(np.bitwise_or.reduce(tk["stat_sweep_why"].astype(np.int64))) if len(tk) else 0,
-                  "labels_bailing_for_arena": int(np.count_nonzero(tk["stat_sweep_why"] & 4))}
+                  "labels_bailing_for_arena": int(np.count_nonzero(tk["stat_sweep_why"] & 4)),
+                  "labels_bailing_for_lists_or_levels": int(np.count_nonzero(tk["stat_sweep_why"] & (8 | 16))),
+                  "labels_retraced_for_scratch": int(state.get("retries", 0))}
 
     cpu = None
     cpu_all = None

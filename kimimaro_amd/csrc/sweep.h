@@ -53,6 +53,8 @@ struct SweepShared {
   uint32_t lvl, nev, ord, openid;
   uint32_t na, nb, nnp, bump, nkill, snap, bail;
   int32_t nM;
+  int32_t nfree;       // chunks on the free stack (transiently negative while lanes that found it empty put their claim back)
+  uint32_t nprev;      // chunks of the level being processed: they go to the free stack when the next level is looked for
   uint32_t levels, events, maxnev;
 #ifdef KH_SWEEP_PROBE
   unsigned long long cyc[8];   // developer probe: cycles per phase of the level loop (thread 0's clock)
@@ -71,6 +73,7 @@ struct Sweep {
   int ra, rb;
   const uint4* srcs;               // per path vertex {x, y, z, radius bits} (HBM)
   uint2* chunks;                   // arena: chunk c = slots [c << shift, (c + 1) << shift); slot 0 = {previous chunk of the level, -}
+  uint32_t* fs;                    // [chcap] free stack: ids of chunks whose level has been processed (HBM, front of the arena)
   uint32_t chcap;                  // chunks available
   int shift;                       // log2(slots per chunk), <= 7
   uint32_t* killed;                // HBM log of the voxels killed by this call
@@ -143,20 +146,26 @@ __device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint
       s.chunks[((size_t)(w >> 10) << s.shift) + fill] = make_uint2(vox, meta);
       return;
     }
-    if (spare == SW_NONE) spare = atomicAdd(&s.sh->bump, 1u);
+    if (spare == SW_NONE) {
+      // a chunk of a level that is done, if there is one (the stack is only filled between the levels, by wave 0, when
+      // nobody takes from it), a fresh one otherwise
+      const int have = atomicSub(&s.sh->nfree, 1);
+      if (have > 0) spare = s.fs[have - 1];
+      else { atomicAdd(&s.sh->nfree, 1); spare = atomicAdd(&s.sh->bump, 1u); }
+    }
     const uint32_t id = spare;
     if (id >= s.chcap || id >= SW_NOCHUNK) { sweep_bail(s, SW_BAIL_ARENA); return; }   // the call is abandoned
     bool mine = false;
-    uint32_t cur = w + 1u;
+    uint32_t seen = w + 1u;
     for (;;) {
-      if ((cur & 1023u) < CH) break;                       // somebody installed a chunk: take a slot of it
-      const uint32_t old = atomicCAS(word, cur, (id << 10) | 2u);
-      if (old == cur) { mine = true; break; }
-      cur = old;
+      if ((seen & 1023u) < CH) break;                      // somebody installed a chunk: take a slot of it
+      const uint32_t old = atomicCAS(word, seen, (id << 10) | 2u);
+      if (old == seen) { mine = true; break; }
+      seen = old;
     }
     if (!mine) continue;
     spare = SW_NONE;
-    const uint32_t prev = cur >> 10;
+    const uint32_t prev = seen >> 10;
     if (prev == SW_NOCHUNK) atomicOr(&s.lvbits[slot >> 5], 1u << (slot & 31u));
     uint2* c = s.chunks + ((size_t)id << s.shift);
     c[0] = make_uint2(prev, 0u);
@@ -506,6 +515,9 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
   if (tid == 0) {
     sh->na = sh->nb = sh->nnp = sh->bump = sh->nkill = sh->snap = sh->bail = 0u;
     sh->nM = 0;
+    sh->nfree = 0;
+    sh->nprev = 0u;
+    sh->lvl = 0u;
     sh->levels = sh->events = sh->maxnev = 0u;
 #ifdef KH_SWEEP_PROBE
     for (int i = 0; i < 8; i++) sh->cyc[i] = 0;
@@ -544,6 +556,10 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     }
     SW_T(0)   // commit
     if (wave == 0) {
+      // the chunks of the level that has just been processed are free again (their ids are still in the chain list)
+      const uint32_t nprev = sh->nprev;
+      const int nfree0 = sh->nfree;          // >= 0: every lane that found the stack empty has put its claim back
+      for (uint32_t i = (uint32_t)lane; i < nprev; i += 64u) s.fs[(uint32_t)nfree0 + i] = s.chain[i];
       uint32_t found = SW_NONE;
       if (s.wmask == 0xFFFFFFFFu) {
         // one bit per level of the label: the first set bit at or above next_from
@@ -600,6 +616,8 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
           sh->levels++;
           sh->events += sh->nev;
           if (sh->nev > sh->maxnev) sh->maxnev = sh->nev;
+          sh->nfree = nfree0 + (int32_t)nprev;
+          sh->nprev = n;
         }
         sh->nM -= (int32_t)(k1 - committed);
         sh->na = sh->nb = sh->nnp = 0u;

@@ -767,10 +767,11 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.sched = sg.sched;
   sw.rank = nlev ? sg.rank : nullptr;
   sw.ra = sg.ra; sw.rb = sg.rb;
-  // the heap's HBM slice (>= 3 * nf + 256 nodes of 16 bytes) is free while the sweep runs: source records
-  // (<= nf), then the three lists of the current level (nf + 64 entries each)
+  // the heap's HBM slice (>= 11 * nf / 8 + 256 nodes of 16 bytes) is free while the sweep runs: source records
+  // (<= nf), then the three lists of the level being processed (nf / 4 + 64 entries each; a list that runs over
+  // abandons the call, SW_BAIL_LIST)
   sw.srcs = reinterpret_cast<const uint4*>(heap_node);
-  sw.ncap = nf + 64u;
+  sw.ncap = nf / 4u + 64u;
   sw.wa = reinterpret_cast<unsigned long long*>(heap_node + nf);
   sw.np = sw.wa + sw.ncap;
   sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);
@@ -783,7 +784,10 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   const bool in_lds = windowed || nlev <= sg.lds_levels;
   sw.nslots = windowed ? win : nlev;
   sw.wmask = windowed ? win - 1u : 0xFFFFFFFFu;
-  sw.chunks = reinterpret_cast<uint2*>(in_lds ? ar : ar + wbytes);
+  // [level words when they are not in LDS][free stack: one u32 per chunk][chunks]
+  unsigned char* fsp = in_lds ? ar : ar + wbytes;
+  sw.fs = reinterpret_cast<uint32_t*>(fsp);
+  sw.chunks = reinterpret_cast<uint2*>(fsp + ((((size_t)task->ev_chunks * 4u) + 255u) & ~(size_t)255u));
   sw.chcap = task->ev_chunks;
   sw.shift = (int)task->ev_shift;
   sw.killed = killed;                                      // the search work lists are free during an invalidation

@@ -50,19 +50,24 @@ def plan_launches(counts, budget):
 SCHED_LEVELS = (1 << 17) - 1     # SW_SCHED_LEVELS (csrc/sweep.h): labels with more levels run the sweep unfiltered
 
 
-def plan_arena(cnt, nlev, filtered):
+def plan_arena(cnt, nlev, filtered, window=None):
     """(log2 slots per chunk, chunks) of the sweep's event arena per label (numpy arrays; csrc/sweep.h: fixed-size chunks of
-    8-byte events chained per level, every level that is ever used holds at least one partly filled chunk).
+    8-byte events chained per level; the chunks of a level go back to a free stack when the level has been processed).
     Unfiltered a voxel is handed ~13 events per call; with the pending-deadline filter ~2 (measured at c3: 1.72e9 -> 2.8e8
-    events per volume), and a level of a large call holds tens of events instead of hundreds -- smaller chunks, a quarter of
-    the event budget.  No label uses more levels than it can get events.  An arena that runs out makes the call fall back to
-    the heap emulation (SW_BAIL_ARENA in stat_sweep_why): a matter of speed, not of results."""
+    events per volume), and a level of a large call holds tens of events instead of hundreds -- smaller chunks, a fraction of
+    the event budget.  What has to fit is what is PENDING at one time: one partly filled chunk per level that has events
+    (at most `window` levels when the label has a level window, never more levels than the label can get events) plus the
+    pending events themselves.  An arena that runs out makes the call fall back to the heap emulation (SW_BAIL_ARENA in
+    stat_sweep_why): a matter of speed, not of results."""
     cnt = np.asarray(cnt, dtype=np.int64)
     nlev = np.asarray(nlev, dtype=np.int64)
     filt = np.asarray(filtered, dtype=bool) & (nlev <= SCHED_LEVELS)
     shift = np.where(filt, np.where(cnt >= 65536, 6, 5), np.where(cnt >= 32768, 7, 6)).astype(np.int64)
-    per_voxel = np.where(filt, 4, 14)
+    per_voxel = np.where(filt, 3, 14)
     levels = np.where(filt, np.minimum(nlev, 3 * cnt + 64), nlev)
+    if window is not None:
+        window = np.asarray(window, dtype=np.int64)
+        levels = np.where(window > 0, np.minimum(levels, window), levels)
     chunks = np.minimum(levels + levels // 2 + ((per_voxel * cnt) >> shift) + 320, (1 << 22) - 2)
     return shift, chunks
 
@@ -103,7 +108,11 @@ class Engine:
         self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
-        self.trace_threads = int(os.environ.get("KH_TRACE_THREADS", "256"))  # threads per label in the path loop: 64, 128 or 256
+        # threads per label in the path loop (64, 128 or 256).  256 serves one volume best (its searches are 4 x as wide);
+        # with volumes in flight 64 does: a label whose call runs on the heap emulation -- one wave for seconds -- then holds a
+        # twelfth of a CU instead of a third, and the sweep's levels hold tens of events, not hundreds (kimimaro_amd.lanes
+        # sets it for its engines; measured at c3, 8 lanes: 784 vs 1134 ms per step)
+        self.trace_threads = int(os.environ.get("KH_TRACE_THREADS", "256"))
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
         # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
@@ -313,7 +322,7 @@ class Engine:
         task["source"] = first[1]
         task["root"] = NONE32
         task["q_capacity"] = cnt + 64
-        hcap = 27 * cnt + 4096          # every push of the flood fits: a voxel is pushed by at most 26 neighbours
+        hcap = 27 * cnt + 4096          # every push of the flood fits: a voxel is pushed by at most 26 neighbours (and the sweep's lists)
         task["heap_capacity"] = hcap
         task["path_capacity"] = 4 * cnt + 1024
         ctx = {"shape": shape, "nvox": nvox, "count": cnt, "d_cc": d_cc, "d_dbf": d_dbf, "dbf_max": float(dbf_max[1])}
@@ -333,11 +342,11 @@ class Engine:
             d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, rmax)
             nlev = int(np.searchsorted(keys, np.float32(rmax), side="left"))
             if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
-                shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter))
                 win = int(level_windows(keys, anisotropy, [nlev], self.sweep_lds_levels)[0]) if self.sweep_window else 0
+                shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter, win))
                 in_lds = win > 0 or nlev <= self.sweep_lds_levels
                 wunits = 0 if in_lds else (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256
-                ev_units = wunits + ((chunks * 8) << shift) // 256
+                ev_units = wunits + (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256   # words, free stack, chunks
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
                 task["lev_window"] = win
                 max_nlev = win if win > 0 else (nlev if in_lds else 0)
@@ -424,7 +433,10 @@ class Engine:
         q_off = np.concatenate([[0], np.cumsum(qcap)[:-1]]).astype(np.int64)
         # heap / path scratch are sized for the common case; a label that overflows them is traced again on its own
         # with `scratch_scale` times as much (below) -- the reference has no such limits
-        hcap = np.maximum((3 * cnt + 1024) * scratch_scale // self.scratch_divisor, 3 * cnt + 256)  # (the sweep's lists live here too)
+        # heap: 3 nodes per voxel for small labels, 1.5 per voxel + 4096 for the others (the deepest heap of c3's largest
+        # label holds 0.7 nodes per voxel); never less than the sweep's lists need (11 / 8 nodes per voxel + 256)
+        hbase = np.maximum((3 * cnt) // 2 + 4096, np.minimum(3 * cnt + 1024, 32768))
+        hcap = np.maximum(hbase * scratch_scale // self.scratch_divisor, (11 * cnt) // 8 + 256)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
         pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
@@ -466,12 +478,13 @@ class Engine:
                 nlev = np.where(ok, nlev, 0)
                 # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
                 # ever used + about 12 events per voxel, with slack
-                shift, chunks = plan_arena(cnt, nlev, self.sweep_filter)
                 win = level_windows(keys, anisotropy, nlev, self.sweep_lds_levels).astype(np.int64) if self.sweep_window \
                     else np.zeros(nl, dtype=np.int64)
+                shift, chunks = plan_arena(cnt, nlev, self.sweep_filter, win)
                 in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)
                 wunits = np.where(in_lds, 0, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256)  # level words in HBM
-                units = np.where(nlev > 0, wunits + ((chunks * 8) << shift) // 256, 0)
+                # [level words when not in LDS][free stack, 4 B per chunk][chunks]
+                units = np.where(nlev > 0, wunits + (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
                 ev_total = int(units.sum())
                 self.last_arena_bytes = ev_total * 256
@@ -615,20 +628,24 @@ class Engine:
                     "voff": np.concatenate([[0], np.cumsum(nverts)]), "loff": np.concatenate([[0], np.cumsum(npaths)])}
 
         retry = []   # positions (caller order) of the labels whose scratch overflowed
+        self.last_retries = 0
 
         def run_retry(sink):
             """re-trace the overflowed labels with 8x the scratch.  sink = None: returns the nested call's own (already
             spliced) result, whose `order` indexes `retry`; else the groups go to `sink` like every other result."""
             if not retry:
                 return None
+            nretry = len(retry)
             pick = np.asarray(retry, dtype=np.int64)
             sub = lambda a: [a[i] for i in pick] if a is not None else None
             subsoma = None if soma is None else {k: np.asarray(v)[pick] for k, v in soma.items()}
-            return self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[pick], counts[pick],
-                                   np.asarray(dbf_max)[pick], np.asarray(first_index)[pick], np.asarray(xmin)[pick],
-                                   np.asarray(xmax)[pick], np.asarray(roots, dtype=np.uint32)[pick], sub(targets_before),
-                                   sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
-                                   consume=sink, scratch_scale=scratch_scale * 8)
+            got = self.run_labels(d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids[pick], counts[pick],
+                                  np.asarray(dbf_max)[pick], np.asarray(first_index)[pick], np.asarray(xmin)[pick],
+                                  np.asarray(xmax)[pick], np.asarray(roots, dtype=np.uint32)[pick], sub(targets_before),
+                                  sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
+                                  consume=sink, scratch_scale=scratch_scale * 8)
+            self.last_retries = nretry + self.last_retries      # (the nested call counted its own)
+            return got
 
         def splice_retried(records):
             """consume paths: re-trace the overflowed labels (their groups go to `consume`) and put the nested call's records

@@ -20,6 +20,9 @@ import threading
 import time
 
 
+LANE_THREADS = 64     # threads per label of a lane's path loop (Engine.trace_threads): one wave, twelve labels per CU
+
+
 def ensure_hw_queues(width):
     """Every lane stream needs a hardware queue of its own: with fewer queues than streams a lane's kernels wait behind
     another lane's seconds-long path kernel (profiles/r02b_inflight_timeline.txt).  The HIP runtime reads
@@ -65,7 +68,10 @@ class Lanes:
             import torch
 
             def engine_factory():
-                return Engine(device)
+                e = Engine(device)
+                if "KH_TRACE_THREADS" not in os.environ:
+                    e.trace_threads = LANE_THREADS
+                return e
 
             def stream_factory(eng):
                 return _StreamScope(torch, eng)
@@ -191,6 +197,9 @@ def _lane_main(conn, device, setup, setup_args, index, engine_factory):
         if engine_factory is None:
             from .engine import Engine
             eng = Engine(device)
+            if "KH_TRACE_THREADS" not in os.environ:
+                eng.trace_threads = LANE_THREADS
+            eng.split_slots = 0       # the other lanes are what overlaps the tail of this lane's largest components
         else:
             eng = engine_factory()
         ctx = setup(eng, index, *setup_args) if setup is not None else None
