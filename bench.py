@@ -538,7 +538,8 @@ def main():
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     # runs, gfx950 x2 FETCH correction calibrated on the x pass): profiles/r02_c3_edt_pmc.json.  Only valid for c3.
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_c3_edt_pmc.json")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
+                if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(pmc):
         kern = json.load(open(pmc))["kernels"]
         lts = {2: "unsigned short", 4: "unsigned int"}[L]
@@ -548,7 +549,7 @@ def main():
             traffic = hit[0]["hbm_bytes_corrected"]
     roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r02_c3_edt_pmc.json (PMC pass, not live)" if traffic else None,
+                "traffic_source": "profiles/%s (PMC pass, not live)" % os.path.basename(pmc) if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
@@ -576,12 +577,13 @@ def main():
     # HBM traffic of that kernel from the committed counter passes (tools/pmc_trace_r3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs over one c3 volume, FETCH x 2 on gfx950): only valid for c3
     tr_traffic, tr_src = None, None
-    tpmc = os.path.join(ROOT, "profiles", "r03_c3_trace_pmc.json")
+    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_c3_trace_pmc.json", "r03_c3_trace_pmc.json"))
+                 if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(tpmc):
         for name, v in json.load(open(tpmc))["kernels"].items():
             if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected_per_volume"):
                 tr_traffic = v["hbm_bytes_corrected_per_volume"]
-                tr_src = "profiles/r03_c3_trace_pmc.json (PMC passes over one volume, not live; all path-kernel launches of the volume)"
+                tr_src = "profiles/%s (PMC passes over one volume, not live; all path-kernel launches of the volume)" % os.path.basename(tpmc)
     roofline_trace = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / tr_s / 1e9, 3),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / tr_s / 1e9 / HBM_PEAK_GBS, 6),
                       "traffic": tr_traffic, "traffic_source": tr_src, "bytes_per_launch": int(trace_bytes),

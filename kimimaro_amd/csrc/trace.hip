@@ -767,11 +767,11 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.sched = sg.sched;
   sw.rank = nlev ? sg.rank : nullptr;
   sw.ra = sg.ra; sw.rb = sg.rb;
-  // the heap's HBM slice (>= 11 * nf / 8 + 256 nodes of 16 bytes) is free while the sweep runs: source records
-  // (<= nf), then the three lists of the level being processed (nf / 4 + 64 entries each; a list that runs over
+  // the heap's HBM slice (>= 11 * nf / 8 + 1536 nodes of 16 bytes) is free while the sweep runs: source records
+  // (<= nf), then the three lists of the level being processed (nf / 4 + 1024 entries each; a list that runs over
   // abandons the call, SW_BAIL_LIST)
   sw.srcs = reinterpret_cast<const uint4*>(heap_node);
-  sw.ncap = nf / 4u + 64u;
+  sw.ncap = nf / 4u + 1024u;
   sw.wa = reinterpret_cast<unsigned long long*>(heap_node + nf);
   sw.np = sw.wa + sw.ncap;
   sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);

@@ -434,9 +434,9 @@ class Engine:
         # heap / path scratch are sized for the common case; a label that overflows them is traced again on its own
         # with `scratch_scale` times as much (below) -- the reference has no such limits
         # heap: 3 nodes per voxel for small labels, 1.5 per voxel + 4096 for the others (the deepest heap of c3's largest
-        # label holds 0.7 nodes per voxel); never less than the sweep's lists need (11 / 8 nodes per voxel + 256)
-        hbase = np.maximum((3 * cnt) // 2 + 4096, np.minimum(3 * cnt + 1024, 32768))
-        hcap = np.maximum(hbase * scratch_scale // self.scratch_divisor, (11 * cnt) // 8 + 256)
+        # label holds 0.7 nodes per voxel); never less than the sweep's lists need (11 / 8 nodes per voxel + 1536)
+        hbase = np.maximum((3 * cnt) // 2 + 4096, np.minimum(3 * cnt + 2048, 32768))
+        hcap = np.maximum(hbase * scratch_scale // self.scratch_divisor, (11 * cnt) // 8 + 1536)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
         pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
@@ -565,6 +565,8 @@ class Engine:
             d_pdrf.index_copy_(0, idx, t.from_numpy(base).to(self.device))
             pdrf_call(_abi.PDRF_FINISH)
         mark("pdrf")
+        if not return_fields:
+            del d_field          # the DAF lives on in list order (d_ldaf); its volume goes back to the pool
         d_dist = self.empty(nvox, t.float32)
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
