@@ -85,30 +85,57 @@ __device__ __forceinline__ void flag_clear(uint8_t* base, uint32_t v, uint32_t b
   atomicAnd(w, ~(bit << sh));
 }
 
+// Address spaces by type inside the searches: the pointers arrive through a function boundary as generic ones, and a
+// generic (flat) access counts on the LDS counter as well as on the vector-memory one -- an LDS read between two of them
+// would wait for the first to return.  With the address space in the type the loads are global_load / ds_read and the
+// stages below really overlap.
+#define KH_AS_GLOBAL __attribute__((address_space(1)))
+#define KH_AS_LDS __attribute__((address_space(3)))
+typedef KH_AS_GLOBAL uint32_t gu32_t;
+typedef KH_AS_GLOBAL float gf32_t;
+__device__ __forceinline__ uint32_t gld_l2(const gu32_t* p) {       // agent-scope load: the word is modified by L2 atomics
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t gflag_or(gu32_t* qs, uint32_t v, uint32_t bit) {
+  const int sh = (int)(v & 3u) * 8;
+  return (__hip_atomic_fetch_or(qs + (v >> 2), bit << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 0xFFu;
+}
+__device__ __forceinline__ void gflag_clear(gu32_t* qs, uint32_t v, uint32_t bit) {
+  const int sh = (int)(v & 3u) * 8;
+  __hip_atomic_fetch_and(qs + (v >> 2), ~(bit << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // MODE 0: EDF (edge length by direction).  MODE 1: railroad (cost = pdrf of the entered voxel, rails
 // absorb, stops once everything at or below the nearest rail is final).  MODE 2: parental field
 // (trace.py:155, fix_branching=False): field costs, no rails, runs to completion.
 // On return distances below the final threshold are exact (ctl->best_rail set for MODE 1).
 template <int MODE>
-__device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t* __restrict__ nbrmask, const float* __restrict__ wfield,
-                     float* dist, uint8_t* qstate, uint32_t source, Queues q, Ctl* ctl, float delta_floor,
+__device__ __attribute__((noinline)) void sssp(const Geometry& g_, const uint32_t* __restrict__ nbrmask_, const float* __restrict__ wfield_,
+                     float* dist_, uint8_t* qstate_, uint32_t source, Queues q, Ctl* ctl_, float delta_floor,
                      uint32_t preseeded_far = 0) {
   constexpr bool RAIL = MODE == 1;
   constexpr bool FIELD = MODE != 0;  // MODE 2: dijkstra3d.parental_field -- field weights, no rails, runs to completion
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
-  uint32_t* cur = q.a;
-  uint32_t* next = q.b;
-  uint32_t* far = q.c;
+  const KH_AS_LDS Geometry* g = (const KH_AS_LDS Geometry*)&g_;      // the kernels keep their Geometry in LDS (Ctl::g)
+  KH_AS_LDS Ctl* ctl = (KH_AS_LDS Ctl*)ctl_;
+  const gu32_t* nbrmask = (const gu32_t*)nbrmask_;
+  const gf32_t* wfield = (const gf32_t*)wfield_;
+  gu32_t* dist = (gu32_t*)dist_;                                     // float bit patterns (non-negative: ordered like unsigned)
+  gu32_t* qstate = (gu32_t*)qstate_;                                 // 4-byte aligned (checked by the entry points)
+  gu32_t* cur = (gu32_t*)q.a;
+  gu32_t* next = (gu32_t*)q.b;
+  gu32_t* far = (gu32_t*)q.c;
+  gu32_t* touched = (gu32_t*)q.touched;
   float T = RAIL ? 1e-45f : delta_floor;
   if (tid == 0) {
     ctl->n_cur = 1; ctl->n_next = 0; ctl->n_far = preseeded_far; ctl->n_far2 = 0;  // far list q.c may hold seeds
     ctl->n_touched = 0;
     ctl->best_rail = NONE64;
     cur[0] = source;
-    st_f32_l2(&dist[source], 0.0f);
-    if (RAIL) { q.touched[0] = source; ctl->n_touched = 1; }
+    __hip_atomic_store(dist + source, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (RAIL) { touched[0] = source; ctl->n_touched = 1; }
   }
   __syncthreads();
   for (;;) {
@@ -116,42 +143,72 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t
     for (;;) {
       const uint32_t n = ctl->n_cur;
       if (n == 0) break;
-      for (uint32_t i = tid; i < n; i += nthr) flag_clear(qstate, cur[i], 1u);
+      for (uint32_t i = tid; i < n; i += nthr) gflag_clear(qstate, cur[i], 1u);
       __syncthreads();
       const uint64_t items = (uint64_t)n << 5;
-      for (uint64_t w = tid; w < items; w += nthr) {
-        const int k = (int)(w & 31);
-        if (k >= 26) continue;
-        const uint32_t u = cur[w >> 5];
-        if (!((nbrmask[u] >> k) & 1u)) continue;
-        const float du = ld_f32_l2(&dist[u]);
-        const uint32_t v = u + (uint32_t)g.off[k];
-        const float wn = FIELD ? wfield[v] : g.w[k];
-        const float nd = du + wn;
-        const uint32_t nb = __float_as_uint(nd);
+      // A relaxation is a chain of dependent round trips (work list -> neighbour mask and distance of u -> weight and
+      // distance of v -> atomic), and a thread has many of them per pass when the label runs on one wave: SB of them
+      // travel together, stage by stage, so that the loads of a stage are all in flight before the first is needed.
+      constexpr int SB = 4;
+      for (uint64_t w0 = tid; w0 < items; w0 += (uint64_t)nthr * SB) {
+        uint32_t uu[SB], vv[SB], nbv[SB], oldv[SB], nmv[SB], duv[SB];
+        float wnv[SB];
+        int kk[SB];
+        bool act[SB];
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          const uint64_t w = w0 + (uint64_t)j * nthr;
+          kk[j] = (int)(w & 31);
+          act[j] = w < items && kk[j] < 26;
+          if (!act[j]) kk[j] = 0;
+          uu[j] = act[j] ? cur[w >> 5] : source;
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          nmv[j] = nbrmask[uu[j]];
+          duv[j] = gld_l2(dist + uu[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          act[j] = act[j] && ((nmv[j] >> kk[j]) & 1u);
+          vv[j] = act[j] ? uu[j] + (uint32_t)g->off[kk[j]] : source;
+        }
         // a look before the atomic: distances only go down, so an edge that cannot lower dist[v] now never will.  Nine
         // out of ten relaxations end here -- as a read; the atomic they replace is a read-modify-write that leaves its
         // line dirty even when the minimum does not change (edf_batch_kernel wrote twice as many bytes as it read)
-        if (nb >= __float_as_uint(ld_f32_l2(&dist[v]))) continue;
-        const uint32_t old = atomicMin(reinterpret_cast<uint32_t*>(&dist[v]), nb);
-        if (nb < old) {
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          wnv[j] = FIELD ? wfield[vv[j]] : g->w[kk[j]];
+          oldv[j] = gld_l2(dist + vv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          nbv[j] = __float_as_uint(__uint_as_float(duv[j]) + wnv[j]);
+          act[j] = act[j] && nbv[j] < oldv[j];
+          if (act[j]) oldv[j] = __hip_atomic_fetch_min(dist + vv[j], nbv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          if (!act[j] || !(nbv[j] < oldv[j])) continue;
+          const uint32_t v = vv[j], nb = nbv[j], old = oldv[j];
+          const float nd = __uint_as_float(nb), wn = wnv[j];
           if (RAIL && old == INF_BITS) {
-            const uint32_t t = atomicAdd(&ctl->n_touched, 1u);
-            if (t < q.cap) q.touched[t] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            const uint32_t t = __hip_atomic_fetch_add(&ctl->n_touched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (t < q.cap) touched[t] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (RAIL && wn == 0.0f) {  // a rail: absorbing
-            atomicMin(&ctl->best_rail, pack(nd, v));
+            __hip_atomic_fetch_min(&ctl->best_rail, pack(nd, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             continue;
           }
           if (nd < T) {
-            if (!(flag_or(qstate, v, 1u) & 1u)) {
-              const uint32_t p = atomicAdd(&ctl->n_next, 1u);
-              if (p < q.cap) next[p] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            if (!(gflag_or(qstate, v, 1u) & 1u)) {
+              const uint32_t p = __hip_atomic_fetch_add(&ctl->n_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (p < q.cap) next[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           } else {
-            if (!(flag_or(qstate, v, 2u) & 2u)) {
-              const uint32_t p = atomicAdd(&ctl->n_far, 1u);
-              if (p < q.cap) far[p] = v; else atomicOr(&ctl->status, KH_ST_QUEUE_OVERFLOW);
+            if (!(gflag_or(qstate, v, 2u) & 2u)) {
+              const uint32_t p = __hip_atomic_fetch_add(&ctl->n_far, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (p < q.cap) far[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }
@@ -162,7 +219,7 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t
         ctl->n_next = 0;
         if (ctl->n_far > q.cap) ctl->n_far = q.cap;
       }
-      uint32_t* t = cur; cur = next; next = t;
+      gu32_t* t = cur; cur = next; next = t;
       __syncthreads();
     }
     // ---- every voxel with d < T is final now
@@ -181,7 +238,7 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t
     float mn = KH_INF, sm = 0.0f;
     uint32_t cnt = 0;
     for (uint32_t i = tid; i < nfar; i += nthr) {
-      const float d = ld_f32_l2(&dist[far[i]]);
+      const float d = __uint_as_float(gld_l2(dist + far[i]));
       mn = fminf(mn, d); sm += d; cnt++;
     }
 #pragma unroll
@@ -206,22 +263,22 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g, const uint32_t
     // pass 2: split far -> cur (d < T) + compacted far (into the free `next` buffer)
     for (uint32_t i = tid; i < nfar; i += nthr) {
       const uint32_t v = far[i];
-      flag_clear(qstate, v, 2u);
-      const float d = ld_f32_l2(&dist[v]);
+      gflag_clear(qstate, v, 2u);
+      const float d = __uint_as_float(gld_l2(dist + v));
       if (d < T) {
-        if (!(flag_or(qstate, v, 1u) & 1u)) {
-          const uint32_t p = atomicAdd(&ctl->n_cur, 1u);
+        if (!(gflag_or(qstate, v, 1u) & 1u)) {
+          const uint32_t p = __hip_atomic_fetch_add(&ctl->n_cur, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           cur[p] = v;  // p < nfar <= cap
         }
       } else {
-        flag_or(qstate, v, 2u);
-        const uint32_t p = atomicAdd(&ctl->n_far2, 1u);
+        gflag_or(qstate, v, 2u);
+        const uint32_t p = __hip_atomic_fetch_add(&ctl->n_far2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         next[p] = v;
       }
     }
     __syncthreads();
     if (tid == 0) { ctl->n_far = ctl->n_far2; ctl->n_far2 = 0; }
-    uint32_t* t = far; far = next; next = t;
+    gu32_t* t = far; far = next; next = t;
     __syncthreads();
   }
   __syncthreads();
