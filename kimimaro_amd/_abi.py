@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkimi_hip.so")
+# KIMI_HIP_LIB: developer knob -- another build of the same sources (e.g. -DKH_SWEEP_PROBE, kimimaro_amd/build.py)
+LIB_PATH = os.environ.get("KIMI_HIP_LIB") or os.path.join(HERE, "libkimi_hip.so")
 
 # every symbol include/kimi_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

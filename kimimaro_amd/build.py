@@ -21,19 +21,22 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None):
+    """out: another file name for a developer build (KH_HIPCC_DEFINES=-DKH_SWEEP_PROBE ...; load it with KIMI_HIP_LIB)"""
+    if out is not None:
+        force = True
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     extra = os.environ.get("KH_HIPCC_DEFINES", "").split()   # developer probes, e.g. -DKH_SWEEP_PROBE (csrc/sweep.h)
     cmd[1:1] = extra
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -782,8 +782,8 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
       sweep_stats[2] += sw->sh->levels;
       sweep_stats[3] += sw->sh->events;
 #ifdef KH_SWEEP_PROBE
-      if (blockIdx.x == 0)
-        printf("SWCYC ok=%d lev=%u ev=%u commit=%llu next=%llu A=%llu cascA=%llu B=%llu cascB=%llu pairs=%llu\n", (int)ok,
+      if (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 1000 || blockIdx.x == 2500)
+        printf("SWCYC blk=%u nf=%u ok=%d lev=%u ev=%u commit=%llu next=%llu A=%llu cascA=%llu B=%llu cascB=%llu pairs=%llu\n", blockIdx.x, nf, (int)ok,
                sw->sh->levels, sw->sh->events, sw->sh->cyc[0], sw->sh->cyc[1], sw->sh->cyc[2], sw->sh->cyc[3], sw->sh->cyc[6],
                sw->sh->cyc[4], sw->sh->cyc[5]);
 #endif
