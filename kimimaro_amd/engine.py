@@ -120,6 +120,8 @@ class Engine:
         self.sweep_lds_levels = min(int(os.environ.get("KH_SWEEP_LDS_LEVELS", 8192)), _abi.SWEEP_LDS_LEVELS)
         self._level_tables = {}
         self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
+        self.arena_divisor = 1              # tests: shrink the sweep's event arena (a call that runs out falls back to the heap)
+        self.window_cap = 0                 # tests: cap the level window (an event beyond it abandons the call to the heap)
         # Per-label scratch (heap, work lists, event arena, path buffers: ~300 B per voxel of a label) of ONE path-loop
         # launch.  Labels beyond it go to further launches of the same call, largest labels first (callers that consume
         # results incrementally only); the whole-volume fields (~40 B per voxel of the volume) are not counted.
@@ -480,7 +482,10 @@ class Engine:
                 # ever used + about 12 events per voxel, with slack
                 win = level_windows(keys, anisotropy, nlev, self.sweep_lds_levels).astype(np.int64) if self.sweep_window \
                     else np.zeros(nl, dtype=np.int64)
+                if self.window_cap:
+                    win = np.where(win > 0, np.minimum(win, int(self.window_cap)), win)
                 shift, chunks = plan_arena(cnt, nlev, self.sweep_filter, win)
+                chunks = np.maximum(chunks // int(self.arena_divisor), 8)
                 in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)
                 wunits = np.where(in_lds, 0, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256)  # level words in HBM
                 # [level words when not in LDS][free stack, 4 B per chunk][chunks]

@@ -252,6 +252,50 @@ def test_skeletonize_sweep_and_heap_paths(sweep, slots):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
+@pytest.mark.parametrize("variant", ["threads64", "threads128", "unfiltered", "no_window", "tiny_arena", "narrow_window"])
+def test_sweep_storage_variants_and_their_bails(variant):
+    """Round-4 storage of the sweep (pending-deadline filter, level window, recycled chunks) and its knobs: one wave / two
+    waves per label, the filter off, the window off, an arena a 64th of its size (calls run out of chunks: SW_BAIL_ARENA) and a
+    window of 64 levels (events land beyond it: SW_BAIL_LEVEL).  A bail is a matter of speed: the skeletons are the oracle's."""
+    import kimimaro_amd
+    from kimimaro_amd.engine import Engine
+    from oracle import pipeline as P
+    eng2 = Engine()
+    if variant == "threads64":
+        eng2.trace_threads = 64
+    elif variant == "threads128":
+        eng2.trace_threads = 128
+    elif variant == "unfiltered":
+        eng2.sweep_filter = False
+    elif variant == "no_window":
+        eng2.sweep_window = False
+    elif variant == "tiny_arena":
+        eng2.arena_divisor = 64
+    elif variant == "narrow_window":
+        eng2.window_cap = 64
+    an = (16, 16, 40)
+    lab = voronoi_labels((96, 96, 40), 7, seed=5, pts_per_label=3, step=12.0, anisotropy=an)
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True,
+                                   progress=False, _engine=eng2)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=100, fix_borders=True)
+    tk = eng2.last_tasks
+    calls, bails = int(tk["stat_sweep_calls"].sum()), int(tk["stat_sweep_bails"].sum())
+    why = int(np.bitwise_or.reduce(tk["stat_sweep_why"].astype(np.int64)))
+    assert calls > 0
+    if variant == "tiny_arena":
+        assert why & 4 and bails > 0          # SW_BAIL_ARENA happened and the heap emulation took those calls
+    elif variant == "narrow_window":
+        assert why & 8 and bails > 0          # SW_BAIL_LEVEL (an event beyond the window)
+    else:
+        assert calls - bails > 0
+    assert sorted(got.keys()) == sorted(want.keys()) and len(got) >= 4
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+
+
 def test_scratch_overflow_is_retried():
     """a label whose heap / path scratch overflows is traced again on its own with more room (the reference has no
     such limits); the others keep their results.  Scratch shrunk 64-fold, heap path only."""
