@@ -200,8 +200,8 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * zeroed u64 per voxel (zero again on exit), event_arena = 256-byte aligned scratch addressed by ev_offset /
  * ev_chunks / ev_shift / nlev / lev_window of each task; max_nlev = the number of level words every workgroup of the launch
  * gets in LDS (<= KH_SWEEP_LDS_LEVELS): a task keeps its words there when its lev_window (if non-zero) or else its nlev fits;
- * any other task keeps 4-byte words for all its nlev levels and the bitmap (nlev / 8 bytes), rounded up to 256 bytes, at the
- * front of its arena, before the chunks.  level_rank == NULL switches the sweep off.
+ * a task for which neither does runs all its invalidations as the heap emulation.  A task's arena = a free stack of ev_chunks u32,
+ * rounded up to 256 bytes, followed by the chunks.  level_rank == NULL switches the sweep off.
  * sched (nullable) = one u32 per voxel, 0xFFFFFFFF on entry for every voxel that is alive (and again on exit): the sweep's
  * pending-deadline filter (csrc/sweep.h) -- with it a voxel is handed ~1.3 events per call instead of ~13; NULL = unfiltered.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant); KH_TRACE_HEAP_PRIO see below.

@@ -33,6 +33,16 @@ int require_device();  // KH_OK or KH_ENODEVICE (+message); cached after the fir
 
 static constexpr float KH_INF = __builtin_huge_valf();
 
+// Address spaces in pointer TYPES.  A pointer that reaches a kernel's inner code through a struct in LDS or a function boundary is
+// a generic one, and a generic (flat) access counts on the LDS counter as well as on the vector-memory one: every LDS read after
+// it -- a field of an LDS-resident record, an entry of the geometry table -- waits for it to RETURN (s_waitcnt vmcnt(0)
+// lgkmcnt(0)), which turns loads that could travel together into a chain of round trips.  With the address space in the type the
+// ISA shows global_load / global_atomic / ds_* and only real dependences wait.
+#define KH_AS_GLOBAL __attribute__((address_space(1)))
+#define KH_AS_LDS __attribute__((address_space(3)))
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));   // (HIP's uint2 / uint4 are structs: no copies across address spaces)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 // 26-neighbourhood in the order of dijkstra_invalidation.hpp:60-124
 __host__ __device__ constexpr inline void dir_delta(int i, int& dx, int& dy, int& dz) {
   // packed table: 2 bits per component (0 -> -1, 1 -> 0, 2 -> +1)

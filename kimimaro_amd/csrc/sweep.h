@@ -62,47 +62,67 @@ struct SweepShared {
 };
 
 struct Sweep {
-  // uniform over the workgroup
-  const Geometry* g;               // LDS copy
-  const uint32_t* nbrmask;
-  uint8_t* alive;
-  unsigned long long* cstate;
-  uint32_t* sched;                 // per voxel: earliest pending deadline (level << cb | source + 1), SW_SCHED_NONE = none;
+  // uniform over the workgroup.  The record itself lives in LDS; its pointers carry their address space (common.h)
+  const KH_AS_LDS Geometry* g;     // LDS copy
+  const KH_AS_GLOBAL uint32_t* nbrmask;
+  KH_AS_GLOBAL uint8_t* alive;
+  KH_AS_GLOBAL unsigned long long* cstate;
+  KH_AS_GLOBAL uint32_t* sched;    // per voxel: earliest pending deadline (level << cb | source + 1), SW_SCHED_NONE = none;
                                    // nullptr = no filter (every event is pushed)
-  const uint32_t* rank;            // [ra * rb * rc]
+  const KH_AS_GLOBAL uint32_t* rank;   // [ra * rb * rc]
   int ra, rb;
-  const uint4* srcs;               // per path vertex {x, y, z, radius bits} (HBM)
-  uint2* chunks;                   // arena: chunk c = slots [c << shift, (c + 1) << shift); slot 0 = {previous chunk of the level, -}
-  uint32_t* fs;                    // [chcap] free stack: ids of chunks whose level has been processed (HBM, front of the arena)
+  KH_AS_GLOBAL u32x4_t* srcs;      // per path vertex {x, y, z, radius bits} (HBM)
+  KH_AS_GLOBAL u32x2_t* chunks;    // arena: chunk c = slots [c << shift, (c + 1) << shift); slot 0 = {previous chunk of the level, -}
+  KH_AS_GLOBAL uint32_t* fs;       // [chcap] free stack: ids of chunks whose level has been processed (HBM, front of the arena)
   uint32_t chcap;                  // chunks available
   int shift;                       // log2(slots per chunk), <= 7
-  uint32_t* killed;                // HBM log of the voxels killed by this call
+  KH_AS_GLOBAL uint32_t* killed;   // HBM log of the voxels killed by this call
   uint32_t nlev;
-  // LDS
-  uint32_t* words;                 // [nslots] (newest chunk << 10) | next free slot of level lv at words[lv & wmask]
-  uint32_t* lvbits;                // [nslots / 32 + 1] non-empty levels (bit lv & wmask)
+  // LDS (a label whose level words do not fit the launch's allotment runs without the sweep)
+  KH_AS_LDS uint32_t* words;       // [nslots] (newest chunk << 10) | next free slot of level lv at words[lv & wmask]
+  KH_AS_LDS uint32_t* lvbits;      // [nslots / 32 + 1] non-empty levels (bit lv & wmask)
   uint32_t nslots, wmask;          // level window: nslots = a power of two and wmask = nslots - 1 when every pending event
                                    // lies less than nslots levels ahead of the level being processed (the slots are then
                                    // used round robin); nslots = nlev, wmask = all ones otherwise
-  uint32_t* chain;                 // [SW_CHAIN] chunks of the level being processed, newest first
-  SweepShared* sh;
+  KH_AS_LDS uint32_t* chain;       // [SW_CHAIN] chunks of the level being processed, newest first
+  KH_AS_LDS SweepShared* sh;
   // HBM lists of the level being processed (label-private scratch)
-  unsigned long long* wa;          // [ncap] candidate cascade (voxel << 32 | source)
-  unsigned long long* np;          // [ncap] pairs added by pure P events (their voxel may survive the level)
-  uint32_t* wb;                    // [ncap] deadline cascade
+  KH_AS_GLOBAL unsigned long long* wa;   // [ncap] candidate cascade (voxel << 32 | source)
+  KH_AS_GLOBAL unsigned long long* np;   // [ncap] pairs added by pure P events (their voxel may survive the level)
+  KH_AS_GLOBAL uint32_t* wb;             // [ncap] deadline cascade
   uint32_t ncap;
 };
+typedef const KH_AS_LDS Sweep& SweepRef;   // the workgroup's record (LDS)
 
+// atomics on address-space-qualified pointers (HIP's atomicAdd & co take generic ones); relaxed, like those
+#define SW_L_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define SW_L_OR(p, v) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define SW_G_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SW_G_OR(p, v) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SW_G_AND(p, v) __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SW_G_MIN(p, v) __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+template <class T>
+__device__ __forceinline__ T sw_g_cas(KH_AS_GLOBAL T* p, T expect, T want) {      // returns the old value like atomicCAS
+  __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expect;
+}
 
-__device__ __forceinline__ void sweep_bail(const Sweep& s, uint32_t why) { atomicOr(&s.sh->bail, why); }
+__device__ __forceinline__ void sweep_bail(SweepRef s, uint32_t why) { SW_L_OR(&s.sh->bail, why); }
 // The level words and the bitmap are updated with atomics (LDS, or L2 when they live in HBM): read them the same way,
 // a plain load could be served from a stale line of the CU's vector cache.
 __device__ __forceinline__ uint32_t sweep_ld(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ uint32_t sweep_ld(const KH_AS_LDS uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t sweep_ld(const KH_AS_GLOBAL uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // distance of voxel (qx, qy, qz) from the source, with the float operation order of dijkstra_invalidation.hpp:310-316
-__device__ __forceinline__ bool sweep_eval(const Sweep& s, const uint4 src, int qx, int qy, int qz, uint32_t& rk) {
+__device__ __forceinline__ bool sweep_eval(SweepRef s, const u32x4_t src, int qx, int qy, int qz, uint32_t& rk) {
   const int ex = qx - (int)src.x, ey = qy - (int)src.y, ez = qz - (int)src.z;
   const float a = s.g->wx * (float)ex;
   const float b = s.g->wy * (float)ey;
@@ -134,24 +154,24 @@ __device__ __forceinline__ bool sweep_eval(const Sweep& s, const uint4 src, int 
 // key table (kh_label_t.lev_window).  The level words are therefore kept for a window of nslots levels only, level lv in
 // slot lv & wmask: 4-8 KiB of LDS instead of 4 bytes for every level of the label.  The bound is checked, not trusted: an
 // event that would leave the window abandons the call (SW_BAIL_LEVEL -> heap emulation).
-__device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint32_t cur, uint32_t lv, uint32_t vox, uint32_t meta) {
+__device__ __forceinline__ void sweep_push(SweepRef s, uint32_t& spare, uint32_t cur, uint32_t lv, uint32_t vox, uint32_t meta) {
   if (lv - cur > s.wmask) { sweep_bail(s, SW_BAIL_LEVEL); return; }      // (wmask = all ones: never)
   const uint32_t slot = lv & s.wmask;
-  uint32_t* word = &s.words[slot];
+  KH_AS_LDS uint32_t* word = &s.words[slot];
   const uint32_t CH = 1u << s.shift;
   for (;;) {
-    const uint32_t w = atomicAdd(word, 1u);
+    const uint32_t w = SW_L_ADD(word, 1u);
     const uint32_t fill = w & 1023u;
     if (fill < CH) {
-      s.chunks[((size_t)(w >> 10) << s.shift) + fill] = make_uint2(vox, meta);
+      s.chunks[((size_t)(w >> 10) << s.shift) + fill] = u32x2_t{vox, meta};
       return;
     }
     if (spare == SW_NONE) {
       // a chunk of a level that is done, if there is one (the stack is only filled between the levels, by wave 0, when
       // nobody takes from it), a fresh one otherwise
-      const int have = atomicSub(&s.sh->nfree, 1);
+      const int have = SW_L_ADD(&s.sh->nfree, -1);
       if (have > 0) spare = s.fs[have - 1];
-      else { atomicAdd(&s.sh->nfree, 1); spare = atomicAdd(&s.sh->bump, 1u); }
+      else { SW_L_ADD(&s.sh->nfree, 1); spare = SW_L_ADD(&s.sh->bump, 1u); }
     }
     const uint32_t id = spare;
     if (id >= s.chcap || id >= SW_NOCHUNK) { sweep_bail(s, SW_BAIL_ARENA); return; }   // the call is abandoned
@@ -159,22 +179,23 @@ __device__ __forceinline__ void sweep_push(const Sweep& s, uint32_t& spare, uint
     uint32_t seen = w + 1u;
     for (;;) {
       if ((seen & 1023u) < CH) break;                      // somebody installed a chunk: take a slot of it
-      const uint32_t old = atomicCAS(word, seen, (id << 10) | 2u);
+      uint32_t old = seen;
+      __hip_atomic_compare_exchange_strong(word, &old, (id << 10) | 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (old == seen) { mine = true; break; }
       seen = old;
     }
     if (!mine) continue;
     spare = SW_NONE;
     const uint32_t prev = seen >> 10;
-    if (prev == SW_NOCHUNK) atomicOr(&s.lvbits[slot >> 5], 1u << (slot & 31u));
-    uint2* c = s.chunks + ((size_t)id << s.shift);
-    c[0] = make_uint2(prev, 0u);
-    c[1] = make_uint2(vox, meta);
+    if (prev == SW_NOCHUNK) SW_L_OR(&s.lvbits[slot >> 5], 1u << (slot & 31u));
+    KH_AS_GLOBAL u32x2_t* c = s.chunks + ((size_t)id << s.shift);
+    c[0] = u32x2_t{prev, 0u};
+    c[1] = u32x2_t{vox, meta};
     return;
   }
 }
 
-__device__ __forceinline__ void sweep_coords(const Sweep& s, uint32_t v, int& x, int& y, int& z) {
+__device__ __forceinline__ void sweep_coords(SweepRef s, uint32_t v, int& x, int& y, int& z) {
   const uint32_t sx = (uint32_t)s.g->sx, sxy = (uint32_t)s.g->sxy;
   const uint32_t zz = v / sxy, r = v - zz * sxy, yy = r / sx;
   z = (int)zz; y = (int)yy; x = (int)(r - yy * sx);
@@ -184,7 +205,7 @@ __device__ __forceinline__ void sweep_coords(const Sweep& s, uint32_t v, int& x,
 // dependent L2 round trips per event (alive byte, then rank word, per neighbour) and the sweep is nothing but such
 // chains.  The helpers below issue the loads of all neighbours before any is consumed (full unrolling, addresses made
 // valid by predication instead of branches), so an event costs a handful of round trips.
-__device__ __forceinline__ uint32_t sweep_alive_nbrs(const Sweep& s, uint32_t v, uint32_t nm) {
+__device__ __forceinline__ uint32_t sweep_alive_nbrs(SweepRef s, uint32_t v, uint32_t nm) {
   const int sx = s.g->sx, sxy = s.g->sxy;
   uint32_t am = 0;
 #pragma unroll
@@ -198,7 +219,7 @@ __device__ __forceinline__ uint32_t sweep_alive_nbrs(const Sweep& s, uint32_t v,
 }
 // neighbours K0 .. K0+12 of (x, y, z) that are in `am` and inside the ball of src: coverage mask (bit k) + their ranks
 template <int K0>
-__device__ __forceinline__ uint32_t sweep_eval13(const Sweep& s, const uint4 src, int x, int y, int z, uint32_t am,
+__device__ __forceinline__ uint32_t sweep_eval13(SweepRef s, const u32x4_t src, int x, int y, int z, uint32_t am,
                                                  uint32_t (&rk)[13]) {
   const float r = __uint_as_float(src.w);
   const float wx = s.g->wx, wy = s.g->wy, wz = s.g->wz;
@@ -253,7 +274,7 @@ __device__ __forceinline__ void sweep_dir(int k, int& dx, int& dy, int& dz) {
   dz = (int)((WZ >> (2 * k)) & 3ull) - 1;
 }
 // neighbour k (run-time index) of v = (x, y, z), known to be covered by src: its voxel index and the rank of its key
-__device__ __forceinline__ uint32_t sweep_nbr_rank(const Sweep& s, const uint4 src, uint32_t v, int x, int y, int z, int k,
+__device__ __forceinline__ uint32_t sweep_nbr_rank(SweepRef s, const u32x4_t src, uint32_t v, int x, int y, int z, int k,
                                                    uint32_t& q) {
   int dx, dy, dz;
   sweep_dir(k, dx, dy, dz);
@@ -277,11 +298,11 @@ __device__ __forceinline__ uint32_t sweep_nbr_rank(const Sweep& s, const uint4 s
 // certified call (its deadline was processed) and dead voxels are never offered events, so the words of live voxels
 // read SW_SCHED_NONE at the start of every call; a bail resets the label's words together with cstate.
 struct SweepFilter {
-  uint32_t* sched;   // nullptr: this call runs unfiltered
+  KH_AS_GLOBAL uint32_t* sched;   // nullptr: this call runs unfiltered
   int cb;            // bits of the source code
 };
 // the filter of a call with npath sources on a label with nlev levels: every (level << cb | code) stays below SW_SCHED_NONE
-__device__ __forceinline__ SweepFilter sweep_filter(const Sweep& s, uint32_t npath) {
+__device__ __forceinline__ SweepFilter sweep_filter(SweepRef s, uint32_t npath) {
   SweepFilter f;
   f.cb = 32 - __clz((int)npath);                 // codes 1 .. npath
   f.sched = (s.sched != nullptr && s.nlev <= (0xFFFFFFFFu >> f.cb)) ? s.sched : nullptr;
@@ -290,7 +311,7 @@ __device__ __forceinline__ SweepFilter sweep_filter(const Sweep& s, uint32_t npa
 __device__ __forceinline__ bool sweep_claim(const SweepFilter f, uint32_t q, uint32_t tr, uint32_t code) {
   if (f.sched == nullptr) return true;
   const uint32_t val = (tr << f.cb) | code;
-  const uint32_t old = atomicMin(&f.sched[q], val);
+  const uint32_t old = SW_G_MIN(&f.sched[q], val);
   return val < old || ((old >> f.cb) == tr && old != val);
 }
 // a pure P event of q at level tr is a no-op when a deadline of q is pending at an earlier level
@@ -302,7 +323,7 @@ __device__ __forceinline__ bool sweep_moot(const SweepFilter f, uint32_t q, uint
 // (sched, sx, sxy are handed over in registers: the Sweep record lives in LDS, and a flat atomic counts on the LDS
 // counter as well, so an LDS read between two atomics would wait for the first one to return)
 template <int K0>
-__device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, int cb, int sx, int sxy, uint32_t v, uint32_t want,
+__device__ __forceinline__ uint32_t sweep_claim13(KH_AS_GLOBAL uint32_t* sched, int cb, int sx, int sxy, uint32_t v, uint32_t want,
                                                   const uint32_t (&rk)[13], uint32_t code) {
   uint32_t old[13];
 #pragma unroll
@@ -311,7 +332,7 @@ __device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, 
     int dx, dy, dz;
     dir_delta(k, dx, dy, dz);
     old[j] = 0u;
-    if ((want >> k) & 1u) old[j] = atomicMin(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)], (rk[j] << cb) | code);
+    if ((want >> k) & 1u) old[j] = SW_G_MIN(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)], (rk[j] << cb) | code);
   }
   uint32_t keep = 0;
 #pragma unroll
@@ -323,12 +344,15 @@ __device__ __forceinline__ uint32_t sweep_claim13(uint32_t* __restrict__ sched, 
 }
 
 // a P event (c may own v from this level on)
-__device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uint32_t v, uint32_t c, bool has_deadline) {
+__device__ __forceinline__ void sweep_possible(SweepRef s, uint32_t lvl, uint32_t v, uint32_t c, bool has_deadline) {
   const uint8_t live = s.alive[v];
   unsigned long long cs = s.cstate[v];
   const uint32_t nm = s.nbrmask[v];
-  const uint4 src = s.srcs[c];
+  const u32x4_t src = s.srcs[c];
   if (!live) return;
+  // the neighbours' alive bytes are asked for before the CAS below, so that the two round trips overlap (an event that
+  // turns out to be a duplicate has loaded them in vain: rare since the pending-deadline filter)
+  const uint32_t am = sweep_alive_nbrs(s, v, nm);
   unsigned long long want;
   for (;;) {
     int freeslot = -1;
@@ -340,17 +364,16 @@ __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uin
     }
     if (freeslot < 0) { sweep_bail(s, SW_BAIL_CAND); return; }
     want = cs | ((unsigned long long)(c + 1u) << (16 * freeslot));
-    const unsigned long long old = atomicCAS(&s.cstate[v], cs, want);
+    const unsigned long long old = sw_g_cas(&s.cstate[v], cs, want);
     if (old == cs) break;
     cs = old;
   }
-  if ((cs & ~SW_DYING) == 0ull) atomicAdd(&s.sh->nM, 1);
+  if ((cs & ~SW_DYING) == 0ull) SW_L_ADD(&s.sh->nM, 1);
   if (!has_deadline) {
-    const uint32_t p = atomicAdd(&s.sh->nnp, 1u);
+    const uint32_t p = SW_L_ADD(&s.sh->nnp, 1u);
     if (p < s.ncap) s.np[p] = ((unsigned long long)v << 32) | c; else sweep_bail(s, SW_BAIL_LIST);
   }
   // cascade: neighbours whose key from c is not above this level may be owned by c inside this level
-  const uint32_t am = sweep_alive_nbrs(s, v, nm);
   if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
@@ -373,16 +396,16 @@ __device__ __forceinline__ void sweep_possible(const Sweep& s, uint32_t lvl, uin
 #pragma unroll
     for (int i = 0; i < 4; i++) have = have || ((uint32_t)(qs >> (16 * i)) & 0x7fffu) == c + 1u;
     if (have) continue;
-    const uint32_t p = atomicAdd(&s.sh->na, 1u);
+    const uint32_t p = SW_L_ADD(&s.sh->na, 1u);
     if (p < s.ncap) s.wa[p] = ((unsigned long long)q << 32) | c; else sweep_bail(s, SW_BAIL_LIST);
   }
 }
 
 // P events of the pair (v, c) to the levels above lvl (the pair was added by a pure P event and v survives the level)
-__device__ __forceinline__ void sweep_emit_possible(const Sweep& s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
+__device__ __forceinline__ void sweep_emit_possible(SweepRef s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
                                                     uint32_t c) {
   const uint32_t nm = s.nbrmask[v];
-  const uint4 src = s.srcs[c];
+  const u32x4_t src = s.srcs[c];
   const uint32_t am = sweep_alive_nbrs(s, v, nm);
   if (!am) return;
   int x, y, z;
@@ -397,8 +420,8 @@ __device__ __forceinline__ void sweep_emit_possible(const Sweep& s, const SweepF
 }
 
 // the neighbours of a dying voxel with a single candidate source: covered ones die with it (deadline at their own key)
-__device__ __forceinline__ void sweep_deadline_one(const Sweep& s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
-                                                   uint32_t cid, const uint4 src, int x, int y, int z, uint32_t am) {
+__device__ __forceinline__ void sweep_deadline_one(SweepRef s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
+                                                   uint32_t cid, const u32x4_t src, int x, int y, int z, uint32_t am) {
   uint32_t rk0[13], rk1[13];
   const uint32_t cov = sweep_eval13<0>(s, src, x, y, z, am, rk0) | sweep_eval13<13>(s, src, x, y, z, am, rk1);
   const uint32_t up = sweep_above(rk0, rk1, cov, lvl);   // covered neighbours whose own key lies above this level: a PD event there
@@ -411,7 +434,7 @@ __device__ __forceinline__ void sweep_deadline_one(const Sweep& s, const SweepFi
   for (uint32_t m = cov & ~up; m; m &= m - 1u) {      // same level: the cascade of this level
     const uint32_t q = v + (uint32_t)s.g->off[__ffs((int)m) - 1];
     if (s.cstate[q] & SW_DYING) continue;
-    const uint32_t p = atomicAdd(&s.sh->nb, 1u);
+    const uint32_t p = SW_L_ADD(&s.sh->nb, 1u);
     if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
   }
   for (uint32_t m = push; m; m &= m - 1u) {
@@ -422,14 +445,25 @@ __device__ __forceinline__ void sweep_deadline_one(const Sweep& s, const SweepFi
 }
 
 // a D event: v is dead once this level is complete
-__device__ __forceinline__ void sweep_deadline(const Sweep& s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v) {
+// `hint`: the source of the event when it is a PD event (the usual single candidate of its voxel), SW_NONE otherwise.
+// The first round trip carries everything that does not depend on anything else: the voxel's alive byte and neighbour mask,
+// the hinted source record, and the dying bit itself -- set before the alive byte is known and taken back when the voxel
+// turns out to be dead (a dead voxel's word is zero and nobody looks at it: dead voxels are not in anybody's neighbour set);
+// the neighbours' alive bytes follow as soon as the mask is there, while the atomic is still on its way.
+__device__ __forceinline__ void sweep_deadline(SweepRef s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
+                                               uint32_t hint) {
   const uint8_t live = s.alive[v];
   const uint32_t nm = s.nbrmask[v];
-  if (!live) return;
-  const unsigned long long old = atomicOr(&s.cstate[v], SW_DYING);
+  const u32x4_t hsrc = s.srcs[hint != SW_NONE ? hint : 0u];
+  const unsigned long long old = SW_G_OR(&s.cstate[v], SW_DYING);
+  const uint32_t am = sweep_alive_nbrs(s, v, nm);
+  if (!live) {
+    if (!(old & SW_DYING)) SW_G_AND(&s.cstate[v], ~SW_DYING);
+    return;
+  }
   if (old & SW_DYING) return;
   if (old == 0ull) { sweep_bail(s, SW_BAIL_UNTOUCHED); return; }
-  s.killed[atomicAdd(&s.sh->nkill, 1u)] = v;
+  s.killed[SW_L_ADD(&s.sh->nkill, 1u)] = v;
   // the candidate slots stay where they are in the word (no compaction: every array below is indexed by constants only,
   // so nothing of this lives in scratch memory)
   uint32_t cid[4];
@@ -442,21 +476,20 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, const SweepFilter
     cid[i] = sl - 1u;
     nc += has[i] ? 1 : 0;
   }
-  uint4 src[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) src[i] = s.srcs[has[i] ? cid[i] : 0u];
-  const uint32_t am = sweep_alive_nbrs(s, v, nm);
   if (!am) return;
   int x, y, z;
   sweep_coords(s, v, x, y, z);
   if (nc == 1) {
     uint32_t c1 = cid[0];
-    uint4 s1 = src[0];
 #pragma unroll
-    for (int i = 1; i < 4; i++) if (has[i]) { c1 = cid[i]; s1 = src[i]; }
+    for (int i = 1; i < 4; i++) if (has[i]) c1 = cid[i];
+    const u32x4_t s1 = c1 == hint ? hsrc : s.srcs[c1];       // (the hinted record is here already)
     sweep_deadline_one(s, flt, spare, lvl, v, c1, s1, x, y, z, am);
     return;
   }
+  u32x4_t src[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) src[i] = s.srcs[has[i] ? cid[i] : 0u];
   for (uint32_t m = am; m; m &= m - 1u) {
     const int k = __ffs((int)m) - 1;
     const uint32_t q = v + (uint32_t)s.g->off[k];
@@ -478,7 +511,7 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, const SweepFilter
     if (all) {
       if (tr <= lvl) {
         if (s.cstate[q] & SW_DYING) continue;
-        const uint32_t p = atomicAdd(&s.sh->nb, 1u);
+        const uint32_t p = SW_L_ADD(&s.sh->nb, 1u);
         if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
       } else if (sweep_claim(flt, q, tr, 0u)) {
         sweep_push(s, spare, lvl, tr, q, SW_D);
@@ -491,7 +524,7 @@ __device__ __forceinline__ void sweep_deadline(const Sweep& s, const SweepFilter
 }
 
 // event e of the level being processed: the newest chunk (chain[0]) holds `newest` events, the others are full
-__device__ __forceinline__ uint2 sweep_event(const Sweep& s, uint32_t e, uint32_t newest) {
+__device__ __forceinline__ u32x2_t sweep_event(SweepRef s, uint32_t e, uint32_t newest) {
   const uint32_t per = (1u << s.shift) - 1u;
   uint32_t c = 0, slot = e + 1u;
   if (e >= newest) { const uint32_t r = e - newest; c = 1u + r / per; slot = r - (c - 1u) * per + 1u; }
@@ -501,11 +534,11 @@ __device__ __forceinline__ uint2 sweep_event(const Sweep& s, uint32_t e, uint32_
 // Whole workgroup.  path / npath: the vertices of the new path; srcs has room for npath records.
 // Returns true when certified (alive updated, *count = voxels invalidated); false when the call has to be redone by
 // the heap emulation (alive and cstate are as they were on entry).
-__device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path, uint32_t npath, const float* __restrict__ dbf,
+__device__ __forceinline__ bool sweep_ball(SweepRef s, const uint32_t* path, uint32_t npath, const float* __restrict__ dbf,
                                                      float scale, float constant, float rmax, const uint32_t* list, uint32_t nf,
                                                      uint32_t* count) {
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
-  SweepShared* sh = s.sh;
+  KH_AS_LDS SweepShared* sh = s.sh;
   const SweepFilter flt = sweep_filter(s, npath);
   uint32_t spare = SW_NONE;
   const uint32_t EMPTY = (SW_NOCHUNK << 10) | (1u << s.shift);
@@ -524,7 +557,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
 #endif
   }
   __syncthreads();
-  uint4* srcs = const_cast<uint4*>(s.srcs);
+  KH_AS_GLOBAL u32x4_t* srcs = s.srcs;
   for (uint32_t i = tid; i < npath; i += nthr) {
     const uint32_t v = path[i];
     float r = scale * dbf[v];        // skeletontricks.pyx:393-395: numpy float32 scalar arithmetic
@@ -532,7 +565,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     if (!(r <= rmax)) sweep_bail(s, SW_BAIL_LEVEL);
     int x, y, z;
     sweep_coords(s, v, x, y, z);
-    srcs[i] = make_uint4((uint32_t)x, (uint32_t)y, (uint32_t)z, __float_as_uint(r));
+    srcs[i] = u32x4_t{(uint32_t)x, (uint32_t)y, (uint32_t)z, __float_as_uint(r)};
   }
   __syncthreads();
   if (sh->bail) return false;
@@ -602,8 +635,8 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
         sh->lvl = found;
         if (found != SW_NONE) {
           const uint32_t fslot = found & s.wmask;
-          const uint32_t w = atomicExch(&s.words[fslot], EMPTY);
-          atomicAnd(&s.lvbits[fslot >> 5], ~(1u << (fslot & 31u)));
+          const uint32_t w = __hip_atomic_exchange(&s.words[fslot], EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_and(&s.lvbits[fslot >> 5], ~(1u << (fslot & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           // the level's chunks, newest first (a chain of dependent loads: one per chunk)
           uint32_t n = 0;
           for (uint32_t id = w >> 10; id != SW_NOCHUNK; id = s.chunks[(size_t)id << s.shift].x) {
@@ -632,7 +665,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     const uint32_t nev = sh->nev, newest = sh->ord;
     // ---- A: candidates
     for (uint32_t e = tid; e < nev; e += nthr) {
-      const uint2 ev = sweep_event(s, e, newest);
+      const u32x2_t ev = sweep_event(s, e, newest);
       if (ev.y & SW_P) sweep_possible(s, lvl, ev.x, ev.y & 0x7fffu, (ev.y & SW_D) != 0u);
     }
     __syncthreads();
@@ -654,8 +687,8 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
     SW_T(3)   // cascade of A
     // ---- B: deadlines (a voxel's candidates are complete now)
     for (uint32_t e = tid; e < nev; e += nthr) {
-      const uint2 ev = sweep_event(s, e, newest);
-      if (ev.y & SW_D) sweep_deadline(s, flt, spare, lvl, ev.x);
+      const u32x2_t ev = sweep_event(s, e, newest);
+      if (ev.y & SW_D) sweep_deadline(s, flt, spare, lvl, ev.x, (ev.y & SW_P) ? (ev.y & 0x7fffu) : SW_NONE);
     }
     __syncthreads();
     SW_T(6)   // B
@@ -665,7 +698,7 @@ __device__ __forceinline__ bool sweep_ball(const Sweep& s, const uint32_t* path,
       if (tid == 0) sh->snap = avail;
       __syncthreads();
       const uint32_t end = sh->snap;
-      for (uint32_t i = done + tid; i < end; i += nthr) sweep_deadline(s, flt, spare, lvl, s.wb[i]);
+      for (uint32_t i = done + tid; i < end; i += nthr) sweep_deadline(s, flt, spare, lvl, s.wb[i], SW_NONE);
       done = end;
       __syncthreads();
     }

@@ -776,7 +776,7 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   bool ok = false;
   if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
     uint32_t cnt = 0;
-    ok = sweep_ball(*sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt);
+    ok = sweep_ball(*(const KH_AS_LDS Sweep*)sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt);
     if (tid == 0) {
       sweep_stats[0]++;
       sweep_stats[2] += sw->sh->levels;
@@ -812,47 +812,48 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   return c;
 }
 
-// thread 0: fill the workgroup's Sweep record for `task` (LDS carve-out `lds` = the dynamic shared memory)
+// thread 0: fill the workgroup's Sweep record for `task` (LDS carve-out `lds` = the dynamic shared memory).  The kernel's
+// pointers get their address spaces here (sweep.h works on typed pointers only).
 __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* ctl, const SweepGlobal& sg, const kh_label_t* task,
                                             const uint32_t* nbrmask, uint8_t* alive, hnode_t* heap_node, uint32_t* killed,
                                             uint32_t nf, unsigned char* lds) {
+  typedef KH_AS_GLOBAL unsigned char gbyte_t;
   const uint32_t nlev = task->nlev;
-  sw.g = &ctl->g;
-  sw.nbrmask = nbrmask;
-  sw.alive = alive;
-  sw.cstate = sg.cstate;
-  sw.sched = sg.sched;
-  sw.rank = nlev ? sg.rank : nullptr;
+  sw.g = (const KH_AS_LDS Geometry*)&ctl->g;
+  sw.nbrmask = (const KH_AS_GLOBAL uint32_t*)nbrmask;
+  sw.alive = (KH_AS_GLOBAL uint8_t*)alive;
+  sw.cstate = (KH_AS_GLOBAL unsigned long long*)sg.cstate;
+  sw.sched = (KH_AS_GLOBAL uint32_t*)sg.sched;
+  sw.rank = nlev ? (const KH_AS_GLOBAL uint32_t*)sg.rank : nullptr;
   sw.ra = sg.ra; sw.rb = sg.rb;
   // the heap's HBM slice (>= 11 * nf / 8 + 1536 nodes of 16 bytes) is free while the sweep runs: source records
   // (<= nf), then the three lists of the level being processed (nf / 4 + 1024 entries each; a list that runs over
   // abandons the call, SW_BAIL_LIST)
-  sw.srcs = reinterpret_cast<const uint4*>(heap_node);
+  gbyte_t* hp = (gbyte_t*)heap_node;
+  sw.srcs = (KH_AS_GLOBAL u32x4_t*)hp;
   sw.ncap = nf / 4u + 1024u;
-  sw.wa = reinterpret_cast<unsigned long long*>(heap_node + nf);
+  sw.wa = (KH_AS_GLOBAL unsigned long long*)(hp + (size_t)nf * 16u);
   sw.np = sw.wa + sw.ncap;
-  sw.wb = reinterpret_cast<uint32_t*>(sw.np + sw.ncap);
-  unsigned char* ar = sg.arena + (size_t)task->ev_offset * 256u;
-  // level words + non-empty bitmap: LDS when they fit the launch's allotment, else the front of the arena (same
-  // code path: the pointers are generic)
-  const size_t wbytes = (((size_t)nlev * 4u + ((size_t)(nlev >> 5) + 2u) * 4u) + 255u) & ~(size_t)255u;
+  sw.wb = (KH_AS_GLOBAL uint32_t*)(sw.np + sw.ncap);
+  // level words + non-empty bitmap live in LDS: a window of them (kh_label_t.lev_window), or one per level when that fits the
+  // launch's allotment; a label for which neither does runs without the sweep (heap emulation only)
   const uint32_t win = task->lev_window;
-  const bool windowed = win >= 64u && (win & (win - 1u)) == 0u && win <= sg.lds_levels;   // round-robin words in LDS
-  const bool in_lds = windowed || nlev <= sg.lds_levels;
+  const bool windowed = win >= 64u && (win & (win - 1u)) == 0u && win <= sg.lds_levels;   // round-robin words
+  if (!windowed && nlev > sg.lds_levels) sw.rank = nullptr;
   sw.nslots = windowed ? win : nlev;
   sw.wmask = windowed ? win - 1u : 0xFFFFFFFFu;
-  // [level words when they are not in LDS][free stack: one u32 per chunk][chunks]
-  unsigned char* fsp = in_lds ? ar : ar + wbytes;
-  sw.fs = reinterpret_cast<uint32_t*>(fsp);
-  sw.chunks = reinterpret_cast<uint2*>(fsp + ((((size_t)task->ev_chunks * 4u) + 255u) & ~(size_t)255u));
+  // arena: [free stack: one u32 per chunk][chunks]
+  gbyte_t* fsp = (gbyte_t*)(sg.arena + (size_t)task->ev_offset * 256u);
+  sw.fs = (KH_AS_GLOBAL uint32_t*)fsp;
+  sw.chunks = (KH_AS_GLOBAL u32x2_t*)(fsp + ((((size_t)task->ev_chunks * 4u) + 255u) & ~(size_t)255u));
   sw.chcap = task->ev_chunks;
   sw.shift = (int)task->ev_shift;
-  sw.killed = killed;                                      // the search work lists are free during an invalidation
+  sw.killed = (KH_AS_GLOBAL uint32_t*)killed;              // the search work lists are free during an invalidation
   sw.nlev = nlev;
-  sw.chain = reinterpret_cast<uint32_t*>(lds);
-  sw.words = in_lds ? sw.chain + SW_CHAIN : reinterpret_cast<uint32_t*>(ar);
+  sw.chain = (KH_AS_LDS uint32_t*)lds;
+  sw.words = sw.chain + SW_CHAIN;
   sw.lvbits = sw.words + sw.nslots;
-  sw.sh = swsh;
+  sw.sh = (KH_AS_LDS SweepShared*)swsh;
 }
 
 template <bool PROF, int TOPL>

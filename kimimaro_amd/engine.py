@@ -346,9 +346,8 @@ class Engine:
             if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
                 win = int(level_windows(keys, anisotropy, [nlev], self.sweep_lds_levels)[0]) if self.sweep_window else 0
                 shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter, win))
-                in_lds = win > 0 or nlev <= self.sweep_lds_levels
-                wunits = 0 if in_lds else (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256
-                ev_units = wunits + (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256   # words, free stack, chunks
+                in_lds = win > 0 or nlev <= self.sweep_lds_levels       # else: heap emulation only (the kernel decides the same)
+                ev_units = (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256   # free stack, chunks
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
                 task["lev_window"] = win
                 max_nlev = win if win > 0 else (nlev if in_lds else 0)
@@ -486,10 +485,9 @@ class Engine:
                     win = np.where(win > 0, np.minimum(win, int(self.window_cap)), win)
                 shift, chunks = plan_arena(cnt, nlev, self.sweep_filter, win)
                 chunks = np.maximum(chunks // int(self.arena_divisor), 8)
-                in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)
-                wunits = np.where(in_lds, 0, (nlev * 4 + (nlev // 32 + 2) * 4 + 255) // 256)  # level words in HBM
-                # [level words when not in LDS][free stack, 4 B per chunk][chunks]
-                units = np.where(nlev > 0, wunits + (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256, 0)
+                in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)   # the others: heap emulation only (the kernel decides the same)
+                # [free stack, 4 B per chunk][chunks]
+                units = np.where((nlev > 0) & in_lds, (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256, 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
                 ev_total = int(units.sum())
                 self.last_arena_bytes = ev_total * 256
