@@ -119,7 +119,6 @@ class Engine:
         # instead of LDS (2 per CU at 16384) -- +20 % labels/s with several volumes in flight, nothing for a single one.
         self.sweep_lds_levels = min(int(os.environ.get("KH_SWEEP_LDS_LEVELS", 8192)), _abi.SWEEP_LDS_LEVELS)
         self._level_tables = {}
-        self.edf_gate = None                # a lock shared by the engines of kimimaro_amd.lanes.Lanes: their EDF launches take turns
         self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
         self.arena_divisor = 1              # tests: shrink the sweep's event arena (a call that runs out falls back to the heap)
         self.window_cap = 0                 # tests: cap the level window (an event beyond it abandons the call to the heap)
@@ -540,23 +539,11 @@ class Engine:
         _abi.check(lib.kh_scatter_lists(P(d_cc), label_bytes, nvox, P(d_slot), nl, P(d_off), P(d_cur), P(d_lists), st))
         _abi.check(lib.kh_neighbor_mask(P(d_cc), label_bytes, sx, sy, sz, P(d_nbr), st))
         mark("lists+nbrmask")
-        # find_root (trace.py:291-308) then DAF (trace.py:139-145).  With several volumes in flight (kimimaro_amd.lanes) the
-        # lanes reach this point together, and distance-field searches of several volumes at once thrash each other's working
-        # set (measured: four pairs of launches together 0.73 s, one after the other 4 x 0.076 s): the lanes take turns.
-        gate = self.edf_gate
-        if gate is not None:
-            t.cuda.current_stream(self.device).synchronize()        # only the searches themselves are held under the gate
-            gate.acquire()
-        try:
-            _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
-            mark("edf_root")
-            _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
-            mark("edf_daf")
-            if gate is not None:
-                t.cuda.current_stream(self.device).synchronize()
-        finally:
-            if gate is not None:
-                gate.release()
+        # find_root (trace.py:291-308) then DAF (trace.py:139-145)
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
+        mark("edf_root")
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
+        mark("edf_daf")
         d_ldaf = self.empty(max(total, 1), t.float32)
         _abi.check(lib.kh_gather_f32(P(d_field), P(d_lists), total, P(d_ldaf), st))
         # PDRF (trace.py:148)

@@ -77,11 +77,6 @@ class Lanes:
                 return _StreamScope(torch, eng)
         self.engines = [engine_factory() for _ in range(self.width)]
         self._scopes = [stream_factory(e) if stream_factory is not None else None for e in self.engines]
-        if os.environ.get("KIMI_LANES_EDF_GATE", "1") != "0":
-            gate = threading.Lock()          # the lanes' distance-field searches take turns (Engine.run_labels)
-            for e in self.engines:
-                if hasattr(e, "edf_gate"):
-                    e.edf_gate = gate
 
     def run(self, job, n, width=None, stagger=0.0):
         """Generator over (k, job(engine, k)) for k = 0..n-1, in order, with at most `width` jobs in flight.  An exception
