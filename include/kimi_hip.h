@@ -164,6 +164,14 @@ int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint32_t* lists,
                  int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                  float* field, uint8_t* qstate, uint32_t* queues, void* stream);
 
+/* ---- voxel_graph of dijkstra3d.* / roll_invalidation_ball_inside_component (kimimaro/trace.py:139-145,155,167,240-242,257;
+ * dijkstra_invalidation.hpp:126-191): nbrmask[v] &= the directions the caller's connectivity word graph[v] allows (cc3d's bit layout,
+ * read at the CURRENT voxel like the reference does).  Every search and the invalidation take their neighbourhoods from nbrmask, so
+ * after this call they honour the graph.  corner_gate (nullable, u8 per voxel): bit j = the yz diagonal that corner entry 18 + j
+ * degenerates into at an x face of the array exists AND the corner's own bit is set (dijkstra_invalidation.hpp:116-123 + :182-190);
+ * kh_invalidate_ball takes it so that the heap emulation pushes the same duplicates as the reference there.                    */
+int kh_apply_voxel_graph(uint32_t* nbrmask, const uint32_t* graph, int64_t nvox, uint8_t* corner_gate, void* stream);
+
 /* ---- a3+a5: zero2inf / inf2zero / compute_pdrf fused, whole volume ------------------
  * replaces kimimaro/trace.py:138,146,148 (skeletontricks.pyx:177-224, trace.py:315-356).
  * For every voxel of a selected label: daf *= 1/max_daf (max_daf = task.max_val, skipped
@@ -232,13 +240,15 @@ int kh_level_keys(int64_t ra, int64_t rb, int64_t rc, float wx, float wy, float 
  * q_offset / q_capacity, heap_offset / heap_capacity and the sweep fields as for kh_trace_paths); alive: u8 per voxel,
  * 1 for the object's voxels that are still valid (mutated in place like the reference's `labels`); path: u32 linear
  * indices of the path vertices; *invalidated (device int64) = number of voxels invalidated by the call.
- * The ball radius of vertex v is f32(f32(scale * dbf[v]) + constant).  Sweep arguments as for kh_trace_paths.      */
+ * The ball radius of vertex v is f32(f32(scale * dbf[v]) + constant).  Sweep arguments as for kh_trace_paths.
+ * corner_gate: NULL, or the array kh_apply_voxel_graph filled (voxel_connectivity_graph=, skeletontricks.pyx:380,405-416).      */
 int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask,
                        int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                        const float* dbf, uint8_t* alive, uint32_t* queues, void* heap_nodes,
                        const uint32_t* path, int64_t npath, float scale, float constant,
                        const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                       uint64_t* cstate, uint32_t* sched, void* event_arena, int64_t* invalidated, void* stream);
+                       uint64_t* cstate, uint32_t* sched, void* event_arena, const uint8_t* corner_gate, int64_t* invalidated,
+                       void* stream);
 
 /* ---- a7 / a8 on their own: one search on one object (the path loop has them inside kh_trace_paths).
  * field: the weight volume (PDRF; +inf outside the object); dist: f32 volume, +inf on entry; qstate / queues as for

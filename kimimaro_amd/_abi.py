@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("KIMI_HIP_LIB") or os.path.join(HERE, "libkimi_hip.so"
 # every symbol include/kimi_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_nd", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
-    "kh_neighbor_mask", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
+    "kh_neighbor_mask", "kh_apply_voxel_graph", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
     "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_invalidate_ball", "kh_path_search", "kh_zero2inf", "kh_inf2zero", "kh_pdrf_field", "kh_target_max", "kh_find_target", "kh_first_label", "kh_ccl26", "kh_fill_voids", "kh_host_ccl26", "kh_host_find_border_targets",
 ]
 
@@ -106,7 +106,8 @@ def lib():
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
                                  f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, ci, ci, vp]
     L.kh_invalidate_ball.argtypes = [vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, i64, f32, f32,
-                                     vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+                                     vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.kh_apply_voxel_graph.argtypes = [vp, vp, i64, vp, vp]
     L.kh_path_search.argtypes = [vp, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, i64, vp, vp]
     L.kh_zero2inf.argtypes = [vp, i64, vp]
     L.kh_inf2zero.argtypes = [vp, i64, vp]

@@ -334,6 +334,51 @@ extern "C" int kh_neighbor_mask(const void* labels, int label_bytes, int64_t sx,
   return KH_OK;
 }
 
+namespace kh {
+// voxel_connectivity_graph bit of direction i (directions in the order of dijkstra_invalidation.hpp:60-124, bits as the reference
+// reads them at dijkstra_invalidation.hpp:152-190 -- cc3d's layout): -x 1, +x 0, -y 3, +y 2, -z 5, +z 4, xy diagonals 9 7 8 6,
+// yz diagonals 17 13 16 12, xz diagonals 15 11 14 10, corners 25 24 23 21 22 20 19 18.
+__device__ __forceinline__ uint32_t graph_to_directions(uint32_t gw) {
+  constexpr int BIT[26] = {1, 0, 3, 2, 5, 4, 9, 7, 8, 6, 17, 13, 16, 12, 15, 11, 14, 10, 25, 24, 23, 21, 22, 20, 19, 18};
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 26; i++) m |= ((gw >> BIT[i]) & 1u) << i;
+  return m;
+}
+__global__ __launch_bounds__(256) void apply_voxel_graph_kernel(uint32_t* nbrmask, const uint32_t* __restrict__ graph, int64_t nvox,
+                                                                uint8_t* corner_gate) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t geo = nbrmask[v];
+  const uint32_t allowed = graph_to_directions(graph[v]);
+  nbrmask[v] = geo & allowed;
+  if (corner_gate) {
+    // a corner entry (18..25) of a voxel on an x face of its array degenerates into the yz diagonal with the corner's y / z steps
+    // (dijkstra_invalidation.hpp:116-123), and the graph gates it by the CORNER's bit (:182-190): bit j = that diagonal exists
+    // (same label, in bounds) and corner 18 + j is allowed.  Only the heap emulation's tie order can see it.
+    uint32_t cg = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int dx, dy, dz;
+      dir_delta(18 + j, dx, dy, dz);
+      const int kd = 10 + (dy > 0 ? 2 : 0) + (dz > 0 ? 1 : 0);
+      cg |= (((geo >> kd) & 1u) & ((allowed >> (18 + j)) & 1u)) << j;
+    }
+    corner_gate[v] = (uint8_t)cg;
+  }
+}
+}  // namespace kh
+
+extern "C" int kh_apply_voxel_graph(uint32_t* nbrmask, const uint32_t* graph, int64_t nvox, uint8_t* corner_gate, void* stream) {
+  if (int rc = kh::require_device()) return rc;
+  if (!nbrmask || !graph || nvox < 0) { kh::set_error("kh_apply_voxel_graph: bad arguments"); return KH_EINVAL; }
+  if (nvox == 0) return KH_OK;
+  hipLaunchKernelGGL(kh::apply_voxel_graph_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nbrmask, graph,
+                     nvox, corner_gate);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
 extern "C" int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
                        const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale, float* pdrf,
                        void* stream) {

@@ -539,7 +539,7 @@ template <bool PROF, class H>
 __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                     float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
-                                    unsigned long long* cyc3) {
+                                    unsigned long long* cyc3, const uint8_t* __restrict__ corner_gate = nullptr) {
   const int lane = threadIdx.x & 63;
   unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt = 0;
   h.n = 0;
@@ -584,7 +584,11 @@ __device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, c
         if (lane >= 18) { ex = 0; k = 10 + (dy > 0 ? 2 : 0) + (dz > 0 ? 1 : 0); }
         else k = -1;
       }
-      if (k >= 0 && ((nbrmask[vox] >> k) & 1u)) {
+      // with a voxel_connectivity_graph a degenerate corner entry is gated by the corner's bit, not the diagonal's
+      const bool open = k < 0 ? false
+                      : (xout && lane >= 18 && corner_gate != nullptr) ? ((corner_gate[vox] >> (lane - 18)) & 1u) != 0u
+                                                                       : ((nbrmask[vox] >> k) & 1u) != 0u;
+      if (open) {
         q = vox + (uint32_t)(ex + (int)sx * dy + (int)sxy * dz);
         if (alive[q]) {
           const int qx = (int)x + ex, qy = (int)y + dy, qz = (int)z + dz;
@@ -771,7 +775,8 @@ template <bool PROF, class H>
 __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                                const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                                float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
-                                               uint32_t* sweep_stats, uint32_t heap_prio) {
+                                               uint32_t* sweep_stats, uint32_t heap_prio,
+                                               const uint8_t* __restrict__ corner_gate = nullptr) {
   const int tid = threadIdx.x;
   bool ok = false;
   if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
@@ -801,7 +806,7 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
       // searches -- are throughput work.  With several volumes in flight they compete for issue slots all the time.
       if (heap_prio) __builtin_amdgcn_s_setprio(3);
       const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                                  &ctl->status, &ctl->u3, ctl->cyc3);
+                                                  &ctl->status, &ctl->u3, ctl->cyc3, corner_gate);
       if (heap_prio) __builtin_amdgcn_s_setprio(0);
       if (tid == 0) ctl->u1 = c;
     }
@@ -1092,7 +1097,8 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
                                                               const uint32_t* __restrict__ nbrmask, Geometry g,
                                                               const float* __restrict__ dbf, uint8_t* alive, uint32_t* queues,
                                                               hnode_t* heap_nodes, const uint32_t* __restrict__ path, uint32_t npath,
-                                                              float scale, float constant, SweepGlobal sg, long long* invalidated) {
+                                                              float scale, float constant, SweepGlobal sg, long long* invalidated,
+                                                              const uint8_t* __restrict__ corner_gate) {
   __shared__ Ctl ctl;
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
@@ -1113,7 +1119,7 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
   }
   __syncthreads();
   const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                               lists + task->list_offset, nf, sweep_stats, sg.heap_prio);
+                                               lists + task->list_offset, nf, sweep_stats, sg.heap_prio, corner_gate);
   if (tid == 0) {
     *invalidated = (long long)c;
     task->status |= ctl.status;
@@ -1341,7 +1347,8 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
                                   int64_t sz, float wx, float wy, float wz, const float* dbf, uint8_t* alive, uint32_t* queues,
                                   void* heap_nodes, const uint32_t* path, int64_t npath, float scale, float constant,
                                   const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                                  uint64_t* cstate, uint32_t* sched, void* event_arena, int64_t* invalidated, void* stream) {
+                                  uint64_t* cstate, uint32_t* sched, void* event_arena, const uint8_t* corner_gate,
+                                  int64_t* invalidated, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (!task || !lists || !nbrmask || !dbf || !alive || !queues || !heap_nodes || !path || !invalidated || npath < 0 ||
       npath >= (1ll << 32) || sx * sy * sz >= (1ll << 32) || ((uintptr_t)heap_nodes & 15) != 0) {
@@ -1373,7 +1380,7 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
   hipLaunchKernelGGL(invalidate_ball_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, task, lists, nbrmask, g, dbf, alive, queues,
-                     (hnode_t*)heap_nodes, path, (uint32_t)npath, scale, constant, sg, (long long*)invalidated);
+                     (hnode_t*)heap_nodes, path, (uint32_t)npath, scale, constant, sg, (long long*)invalidated, corner_gate);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -297,7 +297,7 @@ class Engine:
         return hit[0], hit[1], hit[2], covered
 
     # -- one binary object on its own (the function-level mirrors of ops.py) ---------------
-    def single_object(self, mask, anisotropy, rmax=0.0, dbf=None):
+    def single_object(self, mask, anisotropy, rmax=0.0, dbf=None, voxel_graph=None):
         """Device context of ONE binary object given as a host mask (x, y, z; Fortran order): component volume (0 / 1),
         voxel list, neighbour masks, per-label scratch and -- for ball radii up to `rmax` -- the level table and the
         event arena of the invalidation sweep.  Returns a dict of device tensors + the kh_label_t record."""
@@ -336,6 +336,19 @@ class Engine:
         st = self.stream()
         _abi.check(lib.kh_scatter_lists(P(d_cc), 4, nvox, P(d_slot), 1, P(d_off), P(d_cur), P(d_lists), st))
         _abi.check(lib.kh_neighbor_mask(P(d_cc), 4, shape[0], shape[1], shape[2], P(d_nbr), st))
+        d_gate = None
+        if voxel_graph is not None:
+            # voxel_graph= / voxel_connectivity_graph= of the reference's calls: directions the caller's words do not allow
+            # leave the neighbour masks every search and the invalidation work from (kh_apply_voxel_graph)
+            vg = np.asarray(voxel_graph)
+            while vg.ndim < 3:
+                vg = vg[..., np.newaxis]
+            if tuple(int(v) for v in vg.shape) != shape:
+                raise ValueError("voxel_graph must have the shape of the labels")
+            d_graph = self.to_device(np.asfortranarray(vg.astype(np.uint32)))
+            d_gate = t.zeros(nvox + 4, dtype=t.uint8, device=self.device)
+            _abi.check(lib.kh_apply_voxel_graph(P(d_nbr), P(d_graph), nvox, P(d_gate), st))
+        ctx["d_gate"] = d_gate
         ctx.update(d_slot=d_slot, d_lists=d_lists, d_nbr=d_nbr, d_queues=self.empty(4 * (cnt + 64), t.int32),
                    d_heap=self.empty(2 * hcap, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
         d_rank, rdims, max_nlev, ev_units = None, (0, 0, 0), 0, 0
@@ -377,8 +390,8 @@ class Engine:
                                                float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(ctx["d_dbf"]),
                                                P(d_alive), P(ctx["d_queues"]), P(ctx["d_heap"]), P(d_path), int(d_path.numel()),
                                                np.float32(scale), np.float32(const), rank_ptr, rd[0], rd[1], rd[2], ctx["max_nlev"],
-                                               P(ctx["d_cstate"]), self.optr(ctx["d_sched"]), ctx["arena_ptr"], P(d_cnt),
-                                               self.stream()))
+                                               P(ctx["d_cstate"]), self.optr(ctx["d_sched"]), ctx["arena_ptr"],
+                                               self.optr(ctx.get("d_gate")), P(d_cnt), self.stream()))
         task = ctx["d_task"].cpu().numpy().view(_abi.LABEL_T).copy()
         if int(task["status"][0]):
             raise _abi.KimiHipError("kh_invalidate_ball: %s" % _abi.describe_status(int(task["status"][0])))

@@ -80,9 +80,9 @@ def roll_invalidation_cube(labels, DBF, path, scale, const, anisotropy=(1, 1, 1)
 def roll_invalidation_ball_inside_component(labels, DBF, scale, const, anisotropy=(1, 1, 1), path=(), voxel_connectivity_graph=None):
     """kimimaro.skeletontricks.roll_invalidation_ball_inside_component (skeletontricks.pyx:373-418), call site
     kimimaro/trace.py:253-259: `labels` (uint8 / bool, Fortran order) is the mask of ONE object and is zeroed in place
-    inside the rolling ball of every path vertex (radius scale * DBF[v] + const); returns (invalidated, labels)."""
-    if voxel_connectivity_graph is not None:
-        raise NotImplementedError("voxel_connectivity_graph")
+    inside the rolling ball of every path vertex (radius scale * DBF[v] + const); returns (invalidated, labels).
+    voxel_connectivity_graph (uint32, the labels' shape, cc3d's bit layout; skeletontricks.pyx:380,405-416 ->
+    dijkstra_invalidation.hpp:126-191): a direction whose bit is clear in the word of the voxel being expanded is not followed."""
     if not labels.flags.f_contiguous:
         raise ValueError("roll_invalidation_ball_inside_component: labels must be Fortran ordered (skeletontricks.pyx:398)")
     eng = engine()
@@ -95,7 +95,7 @@ def roll_invalidation_ball_inside_component(labels, DBF, scale, const, anisotrop
     locs = pts[:, 0] + sx * (pts[:, 1] + sy * pts[:, 2])
     f = np.float32
     radii = (f(scale) * dbf.reshape(-1, order="F")[locs]).astype(np.float32) + f(const)     # f32 ops, pyx:393-395
-    ctx = eng.single_object(lab, anisotropy, rmax=float(radii.max()), dbf=dbf)
+    ctx = eng.single_object(lab, anisotropy, rmax=float(radii.max()), dbf=dbf, voxel_graph=voxel_connectivity_graph)
     d_alive = eng.torch.from_numpy(np.ascontiguousarray(lab.reshape(-1, order="F"))).to(eng.device)
     cnt, _ = eng.invalidate_ball(ctx, d_alive, locs, scale, const, anisotropy)
     lab.reshape(-1, order="F")[...] = d_alive.cpu().numpy()

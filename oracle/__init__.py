@@ -42,6 +42,7 @@ def lib():
         L.ko_field_distances.argtypes = [vp, i64, i64, i64, u64, vp]
         L.ko_path_to_source.argtypes = [vp, vp, i64, i64, i64, u64, u64, vp, vp]
         L.ko_invalidate_ball.argtypes = [vp, i64, i64, i64, f32, f32, f32, vp, vp, i64, vp, vp]
+        L.ko_invalidate_ball_graph.argtypes = [vp, i64, i64, i64, f32, f32, f32, vp, vp, i64, vp, vp, vp]
         L.ko_ball_radii.argtypes = [vp, vp, i64, f32, f32, vp]
         L.ko_invalidate_cube.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, vp, i64, f32, f32, vp]
         L.ko_zero2inf.argtypes = [vp, i64]
@@ -218,8 +219,9 @@ def path_from_parents(parents, target):
 
 
 def roll_invalidation_ball_inside_component(labels, DBF, scale, const, anisotropy, path,
-                                            return_stats=False):
-    """skeletontricks.pyx:373-418.  labels (uint8/bool, F order) is mutated in place."""
+                                            return_stats=False, voxel_connectivity_graph=None):
+    """skeletontricks.pyx:373-418.  labels (uint8/bool, F order) is mutated in place.
+    voxel_connectivity_graph: optional uint32 array of the labels' shape (F order), cc3d's bit layout."""
     assert labels.flags.f_contiguous and DBF.flags.f_contiguous
     lab = labels.view(np.uint8)
     path = np.asarray(path, dtype=np.int64).reshape(-1, 3)
@@ -229,9 +231,16 @@ def roll_invalidation_ball_inside_component(labels, DBF, scale, const, anisotrop
     lib().ko_ball_radii(_p(DBF), _p(locs), locs.size, np.float32(scale), np.float32(const), _p(radii))
     cnt = C.c_int64(0)
     ops = C.c_int64(0)
-    _check(lib().ko_invalidate_ball(_p(lab), sx, sy, sz, float(anisotropy[0]), float(anisotropy[1]),
-                                    float(anisotropy[2]), _p(locs), _p(radii), locs.size,
-                                    C.byref(cnt), C.byref(ops)))
+    if voxel_connectivity_graph is not None:
+        vcg = np.asfortranarray(voxel_connectivity_graph, dtype=np.uint32)
+        assert vcg.shape == lab.shape
+        _check(lib().ko_invalidate_ball_graph(_p(lab), sx, sy, sz, float(anisotropy[0]), float(anisotropy[1]),
+                                              float(anisotropy[2]), _p(locs), _p(radii), locs.size, _p(vcg),
+                                              C.byref(cnt), C.byref(ops)))
+    else:
+        _check(lib().ko_invalidate_ball(_p(lab), sx, sy, sz, float(anisotropy[0]), float(anisotropy[1]),
+                                        float(anisotropy[2]), _p(locs), _p(radii), locs.size,
+                                        C.byref(cnt), C.byref(ops)))
     if return_stats:
         return cnt.value, labels, ops.value
     return cnt.value, labels

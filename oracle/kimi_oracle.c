@@ -636,10 +636,29 @@ static void ko_nhood26(int64_t* nb, int64_t x, int64_t y, int64_t z, int64_t sx,
 int64_t ko_last_heap_peak = 0;
 int64_t ko_get_last_heap_peak(void) { return ko_last_heap_peak; }
 
+/* voxel_connectivity_graph bit of neighbourhood entry i (dijkstra_invalidation.hpp:152-190; the layout is cc3d's):
+ * an entry whose bit is clear in the graph word of the CURRENT voxel is dropped -- after the neighbourhood helper has
+ * produced it, so a corner entry that degenerated into a yz diagonal at an x face is gated by the corner's bit. */
+static const int ko_graph_bit[26] = {1, 0, 3, 2, 5, 4,   9, 7, 8, 6,   17, 13, 16, 12,   15, 11, 14, 10,
+                                     25, 24, 23, 21, 22, 20, 19, 18};
+
+int ko_invalidate_ball_graph(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
+                             float wx, float wy, float wz,
+                             const uint64_t* sources, const float* max_distances, int64_t nsrc,
+                             const uint32_t* graph, int64_t* invalidated, int64_t* heap_ops);
+
 int ko_invalidate_ball(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
                        float wx, float wy, float wz,
                        const uint64_t* sources, const float* max_distances, int64_t nsrc,
                        int64_t* invalidated, int64_t* heap_ops) {
+  return ko_invalidate_ball_graph(field, sx, sy, sz, wx, wy, wz, sources, max_distances, nsrc, NULL, invalidated, heap_ops);
+}
+
+/* skeletontricks.pyx:373-418 with voxel_connectivity_graph (nullable) -> dijkstra_invalidation.hpp:239-332 */
+int ko_invalidate_ball_graph(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
+                             float wx, float wy, float wz,
+                             const uint64_t* sources, const float* max_distances, int64_t nsrc,
+                             const uint32_t* graph, int64_t* invalidated, int64_t* heap_ops) {
   const int64_t sxy = sx * sy;
   ko_iheap h = {0, 0, 0};
   int64_t ops = 0;
@@ -663,6 +682,10 @@ int ko_invalidate_ball(uint8_t* field, int64_t sx, int64_t sy, int64_t sz,
     int64_t z = (int64_t)(loc / (uint64_t)sxy), r = (int64_t)(loc % (uint64_t)sxy), y = r / sx, x = r % sx;
     int64_t oz = (int64_t)(src / (uint64_t)sxy), orr = (int64_t)(src % (uint64_t)sxy), oy = orr / sx, ox = orr % sx;
     ko_nhood26(nb, x, y, z, sx, sy, sz);
+    if (graph) {
+      const uint32_t gw = graph[loc];
+      for (int i = 0; i < 26; i++) if (!((gw >> ko_graph_bit[i]) & 1u)) nb[i] = 0;
+    }
     for (int i = 0; i < 26; i++) {
       if (nb[i] == 0) continue;
       uint64_t q = (uint64_t)((int64_t)loc + nb[i]);

@@ -548,7 +548,62 @@ def gen_post(st):
     print("post:", n, "cases")
 
 
-if __name__ == "__main__" and "post" in sys.argv[1:]:
+def gen_ball_graph(st):
+    """roll_invalidation_ball_inside_component(..., voxel_connectivity_graph=) of the COMPILED reference
+    (skeletontricks.pyx:373-418 -> dijkstra_invalidation.hpp:126-191) on 40 tubes / blobs with random connectivity graphs:
+    a fraction of the 26 bits of every voxel cleared at random (asymmetrically, as the reference reads only the CURRENT voxel's
+    word), plus planes of walls; some objects touch the x faces of their array (the degenerate corner entries there are gated by
+    the corner's bit)."""
+    rng = np.random.default_rng(20260927)
+    cases = {}
+    n = 0
+    for t in range(40):
+        shape = (int(rng.integers(8, 22)), int(rng.integers(10, 24)), int(rng.integers(8, 20)))
+        an = [(1, 1, 1), (16, 16, 40), (4, 4, 40), (1, 2, 3), (40, 32, 20)][t % 5]
+        if t % 4 == 3:
+            m = np.ones(shape, np.uint8, order="F")          # a solid block: every x face voxel has degenerate corners
+        else:
+            m = random_walk_tube(shape, 900 + t, steps=30, step=2.5, radius=(1.5, 4.0))
+        dbf = edt_like(m, an, rng)
+        vcg = np.full(shape, (1 << 26) - 1, dtype=np.uint32, order="F")
+        drop = [0.0, 0.05, 0.2, 0.5][t % 4]
+        for b in range(26):
+            vcg &= ~(np.asfortranarray(rng.random(shape) < drop).astype(np.uint32) << np.uint32(b))
+        if t % 3 == 0:                                       # a wall: nobody steps in +z across the middle plane
+            zc = shape[2] // 2
+            plus_z = sum(1 << b for b in (4, 13, 12, 11, 10, 21, 20, 19, 18))   # the bits of the entries with dz = +1
+            vcg[:, :, zc] &= np.uint32(~plus_z & 0xFFFFFFFF)
+        idx = np.flatnonzero(m.ravel(order="F"))
+        k = int(rng.integers(1, 10))
+        start = int(rng.integers(0, max(1, idx.size - k)))
+        sel = idx[start:start + k] if t % 2 == 0 else rng.choice(idx, min(k, idx.size), replace=False)
+        sx, sy = shape[0], shape[1]
+        path = np.stack([sel % sx, (sel // sx) % sy, sel // (sx * sy)], axis=1)
+        scale = [1.5, 4.0, 0.5, 2.0][t % 4]
+        const = [0.0, 3.0 * an[0], 30.0, 0.7][(t // 4) % 4]
+        before = m.copy(order="F")
+        cnt, _ = st.roll_invalidation_ball_inside_component(
+            m, dbf, scale, const, an, [tuple(int(v) for v in p) for p in path], voxel_connectivity_graph=vcg)
+        cases["shape_%d" % n] = np.array(shape)
+        cases["an_%d" % n] = np.array(an, np.float32)
+        cases["mask_%d" % n] = np.packbits(before.ravel(order="F"))
+        cases["graph_%d" % n] = vcg.ravel(order="F").copy()
+        cases["path_%d" % n] = path.astype(np.int32)
+        cases["dbfpath_%d" % n] = dbf[path[:, 0], path[:, 1], path[:, 2]].astype(np.float32)
+        cases["sc_%d" % n] = np.array([scale, const], np.float32)
+        cases["count_%d" % n] = np.array(cnt)
+        cases["after_%d" % n] = np.packbits(m.ravel(order="F"))
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "invalidation_ball_graph.npz"), **cases)
+    print("invalidation_ball_graph:", n)
+
+
+if __name__ == "__main__" and "ball_graph" in sys.argv[1:]:
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    gen_ball_graph(st)
+elif __name__ == "__main__" and "post" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
     gen_post(st)
@@ -569,6 +624,7 @@ elif __name__ == "__main__":
     assert st is not None, "needs /root/reference"
     trace = load_reference_trace(st)
     gen_ball(st)
+    gen_ball_graph(st)
     gen_cube(st)
     gen_finder(st)
     gen_legacy(st)

@@ -434,6 +434,38 @@ def test_invalidate_ball_reference_goldens(sweep):
         ops._engine = None
 
 
+@pytest.mark.parametrize("sweep", [True, False])
+def test_invalidate_ball_voxel_graph_reference_goldens(sweep):
+    """roll_invalidation_ball_inside_component(..., voxel_connectivity_graph=) (skeletontricks.pyx:380,405-416 ->
+    dijkstra_invalidation.hpp:126-191) on the 40 vectors of the COMPILED REFERENCE with random connectivity graphs
+    (tests/golden/invalidation_ball_graph.npz): kh_apply_voxel_graph + kh_invalidate_ball, counts and masks bit exact through
+    the sweep (with its fall-back) and through the heap emulation alone, incl. the corner entries at the x faces."""
+    import os
+    from kimimaro_amd import ops
+    from kimimaro_amd.engine import Engine
+    eng2 = Engine()
+    eng2.sweep = sweep
+    ops._engine = eng2
+    try:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "invalidation_ball_graph.npz"))
+        unpack = lambda b, shape: np.unpackbits(b)[: int(np.prod(shape))].reshape(shape, order="F").astype(np.uint8)
+        for i in range(int(z["n"])):
+            shape = tuple(int(v) for v in z["shape_%d" % i])
+            m = np.asfortranarray(unpack(z["mask_%d" % i], shape))
+            path = z["path_%d" % i]
+            dbf = np.zeros(shape, np.float32, order="F")
+            dbf[path[:, 0], path[:, 1], path[:, 2]] = z["dbfpath_%d" % i]
+            scale, const = z["sc_%d" % i]
+            vcg = np.asfortranarray(z["graph_%d" % i].reshape(shape, order="F"))
+            cnt, out = ops.roll_invalidation_ball_inside_component(m, dbf, scale, const, z["an_%d" % i], path,
+                                                                   voxel_connectivity_graph=vcg)
+            assert out is m
+            assert cnt == int(z["count_%d" % i]), i
+            np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
+    finally:
+        ops._engine = None
+
+
 def _unpack(b, shape):
     return np.unpackbits(b)[: int(np.prod(shape))].reshape(shape, order="F").astype(np.uint8)
 

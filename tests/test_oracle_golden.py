@@ -30,6 +30,32 @@ def test_invalidation_ball_golden():
         np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
 
 
+def test_invalidation_ball_with_voxel_graph_golden():
+    """roll_invalidation_ball_inside_component(..., voxel_connectivity_graph=) of the compiled reference on 40 objects with random
+    connectivity graphs (tests/golden/make_golden.py ball_graph): the oracle's bit table (dijkstra_invalidation.hpp:152-190) and
+    its place in the flood (after the neighbourhood helper, so degenerate corner entries are gated by the corner's bit)."""
+    z = np.load(os.path.join(G, "invalidation_ball_graph.npz"))
+    blocked = 0
+    for i in range(int(z["n"])):
+        shape = tuple(z["shape_%d" % i])
+        m = unpack(z["mask_%d" % i], shape)
+        before = int(m.sum())
+        path = z["path_%d" % i]
+        dbf = np.zeros(shape, np.float32, order="F")
+        dbf[path[:, 0], path[:, 1], path[:, 2]] = z["dbfpath_%d" % i]
+        scale, const = z["sc_%d" % i]
+        vcg = np.asfortranarray(z["graph_%d" % i].reshape(shape, order="F"))
+        m2 = m.copy(order="F")
+        cnt, out = K.roll_invalidation_ball_inside_component(m, dbf, scale, const, z["an_%d" % i], path,
+                                                             voxel_connectivity_graph=vcg)
+        assert cnt == int(z["count_%d" % i]), i
+        np.testing.assert_array_equal(out, unpack(z["after_%d" % i], shape), err_msg="case %d" % i)
+        free, _ = K.roll_invalidation_ball_inside_component(m2, dbf, scale, const, z["an_%d" % i], path)
+        blocked += int(free != cnt)
+        assert before >= free >= cnt
+    assert blocked >= 3           # the graphs really change some of the floods (26-connectivity is very redundant)
+
+
 def test_invalidation_ball_shadowing():
     """SURVEY B-8: the flood is NOT the union of balls (99 voxels, not 153)."""
     m = np.zeros((40, 5, 5), np.uint8, order="F")
