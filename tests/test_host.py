@@ -236,3 +236,63 @@ def test_pow2_exponent_mirrors_the_reference_test():
     for e in (4.0, np.float64(16), np.float32(2)):
         with pytest.raises(TypeError):
             is_pow2_exponent(e)
+
+
+def _key_table(an, rmax):
+    """the flood's keys of all offsets up to rmax, with its float operation order (dijkstra_invalidation.hpp:310-316), and their
+    ranks -- what Engine.level_table gets from kh_level_keys + torch.unique"""
+    w = [np.float32(a) for a in an]
+    dims = [int(rmax / float(w[i])) + 2 for i in range(3)]
+    a = (np.arange(dims[0], dtype=np.float32) * w[0]) ** 2
+    b = (np.arange(dims[1], dtype=np.float32) * w[1]) ** 2
+    c = (np.arange(dims[2], dtype=np.float32) * w[2]) ** 2
+    s = ((a[:, None, None] + b[None, :, None]).astype(np.float32) + c[None, None, :]).astype(np.float32)
+    keys3 = np.sqrt(s).astype(np.float32)
+    uniq, inv = np.unique(keys3, return_inverse=True)
+    return uniq, inv.reshape(keys3.shape), dims
+
+
+@pytest.mark.parametrize("an,rmax", [((16, 16, 40), 700.0), ((1, 1, 1), 40.0), ((8, 8, 40), 500.0), ((4, 3, 2), 90.0), ((40, 32, 20), 900.0)])
+def test_level_window_bounds_every_neighbour_step(an, rmax):
+    """kh_label_t.lev_window (engine.level_windows): an event goes from a voxel processed at a level >= rank(v, c) to a neighbour q at
+    rank(q, c); the window must exceed rank(q, c) - rank(v, c) for EVERY offset of v inside the radius and every one of the 26 steps --
+    checked here by brute force on the key table itself (the kernel checks every push as well and falls back to the heap when a bound is
+    ever exceeded: this test is why that never happens)."""
+    from kimimaro_amd.engine import level_windows
+    uniq, rank, dims = _key_table(an, rmax)
+    nlev = int(np.searchsorted(uniq, np.float32(rmax), side="left"))
+    win = int(level_windows(uniq, an, [nlev], 1 << 20)[0])
+    assert win >= 64 and win & (win - 1) == 0
+    inside = rank < nlev                                         # offsets whose key is below the radius
+    worst = 0
+    A, B, C = dims
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if dx == dy == dz == 0:
+                    continue
+                # neighbour offset (|a + dx|, |b + dy|, |c + dz|): the table holds absolute offsets
+                ia = np.abs(np.arange(A)[:, None, None] + dx)
+                ib = np.abs(np.arange(B)[None, :, None] + dy)
+                ic = np.abs(np.arange(C)[None, None, :] + dz)
+                ok = inside & (ia < A) & (ib < B) & (ic < C)
+                rq = rank[np.minimum(ia, A - 1), np.minimum(ib, B - 1), np.minimum(ic, C - 1)]
+                ok &= rq < nlev                                  # the neighbour is inside the radius too (else no event)
+                if ok.any():
+                    worst = max(worst, int((rq - rank)[ok].max()))
+    assert 0 < worst < win, (worst, win)
+    assert win <= 4 * (worst + 2)                                # and the bound is not wildly loose (LDS is what it costs)
+
+
+def test_plan_arena_shapes():
+    """engine.plan_arena: filtered labels get small chunks and an arena for what is pending (window + a few events per voxel), labels
+    with more levels than the filter can pack keep the unfiltered budget, nothing exceeds the 22-bit chunk ids."""
+    from kimimaro_amd.engine import plan_arena, SCHED_LEVELS
+    cnt = np.array([1200, 40000, 177129, 10 ** 6, 5 * 10 ** 7])
+    nlev = np.array([6000, 9000, 8142, SCHED_LEVELS + 5, 9000])
+    win = np.array([1024, 1024, 1024, 1024, 0])
+    shift, chunks = plan_arena(cnt, nlev, True, win)
+    assert shift.tolist() == [5, 5, 6, 7, 6] and (chunks <= (1 << 22) - 2).all() and (chunks > 0).all()
+    s0, c0 = plan_arena(cnt, nlev, False, win)
+    assert (s0 >= shift).all() and ((c0 << s0) >= (chunks << shift)).all()          # the unfiltered arena is never smaller
+    assert int(chunks[0]) < 2500 and int(chunks[2]) < 12000                              # bounded by the window, not by nlev
