@@ -23,12 +23,13 @@ Engine.scratch_budget asks for).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
-Steps in flight (--inflight F; default 4, and 7 / 10 / 12 for the strong mode on 2 / 4 / 8 GPUs): the wall clock of ONE volume is the chain of its largest component -- a
-handful of workgroups for seconds while the rest of the GPU idles.  The K timed steps are therefore
-issued from F host threads, each with a HIP stream, an Engine and scratch of its own, so that the tail of one volume
-overlaps the next ones; every step still does all of its work inside the timed region and ms_per_step = wall / K.  The
-latency of a single volume on an otherwise idle GPU is measured in the same run (untimed) and printed as
-single_volume_ms; --inflight 1 times the steps one after the other.
+Steps in flight (--inflight F; default: as many as 80 % of the free HBM pays for -- 17.9 GB per 512^3 volume -- 12 at most, and no
+more than fill the rounds of the run evenly): the wall clock of ONE volume is the chain of its largest component -- a handful of waves
+for seconds while the rest of the GPU idles.  The K timed steps are therefore issued from F lanes (host threads by
+default, --lanes process for processes), each with a HIP stream, an Engine and scratch of its own and one wave per label in its path
+loop, so that the tail of one volume overlaps the next ones; every step still does all of its work inside the timed region and
+ms_per_step = wall / K.  The latency of a single volume on an otherwise idle GPU is measured in the same run (untimed, on the default
+engine: what kimimaro_amd.skeletonize() does) and printed as single_volume_ms; --inflight 1 times the steps one after the other.
 
 Extra objects on the JSON line:
   roofline      EDT pass kernel (the kernel BASELINE.json's metric names): algorithmic bytes / the
@@ -37,7 +38,10 @@ Extra objects on the JSON line:
   cpu_baseline  the oracle (CPU restatement, 1 core) on a bounded sample of the same labels.
   cpu_baseline_all_cores  the same work on a process pool over every USABLE host core (affinity and cgroup quota are
                 printed: the pool's 256-core boxes grant 16), components largest first, in two legs -- `latency`: one
-                volume's components; `throughput`: as many volumes' components at once as the GPU run has in flight.
+                volume's components; `throughput`: several volumes' components at once (as many as the GPU run has in
+                flight, four at most: the pool is throughput bound from one volume on).
+  chains / chains_under_load  the labels whose chains set the wall clock of the path kernel (cycles per phase, heap pushes,
+                why their call left the sweep), alone and -- thread lanes -- in the lanes' last volumes.
   speedup_latency / speedup_throughput  the like-for-like ratios: one volume alone on the GPU vs the latency leg, the
                 pipelined `value` vs the throughput leg.  Never mixed.
   rank_times    (N > 1) every rank's own seconds per step and the seconds it spent in the skeleton gather.
