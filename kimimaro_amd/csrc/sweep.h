@@ -29,10 +29,12 @@
 //   common case: unique owner).  Path vertices start with a PD event at level 0.
 // Certified iff no voxel is left in state M and no capacity was exceeded; then the dead set is D.
 //
-// Machine mapping: one workgroup per label (the caller's), one thread per event of the current level; per-voxel
-// state = one 64-bit word in HBM (4 x 15-bit candidates + the "dying in this level" bit), events = 8-byte records
-// in per-level chunk lists (HBM, label-private arena), the per-level list heads, a non-empty-level bitmap and the
-// cascade lists in LDS.  No float atomics, no MFMA: irregular integer/f32 work bound by HBM/L2 latency.
+// Machine mapping: one workgroup per label (the caller's: one to four waves), one thread per event of the current level;
+// per-voxel state = one 64-bit word in HBM (4 x 15-bit candidates + the "dying in this level" bit) + one 32-bit word (the
+// earliest pending deadline: the filter below), events = 8-byte records in per-level chunk lists (HBM, label-private arena,
+// chunks recycled level by level), the list heads of a WINDOW of levels and a non-empty-level bitmap in LDS, the cascade
+// lists in HBM.  Every pointer carries its address space in its type (common.h).  No float atomics, no MFMA: irregular
+// integer/f32 work bound by dependent round trips to L2 / HBM (about ten per level).
 #pragma once
 #include "common.h"
 
