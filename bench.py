@@ -346,11 +346,9 @@ def main():
         # it traces (~11 GB for all components of c3; a rank of the strong mode holds 1 / N of them).  As many lanes as 80 %
         # of the memory that is free now pays for, 12 at most: the step time keeps falling up to there (one volume's chain
         # of ~3 s is overlapped by the others' GPU-filling phases; measured at c3: 4 / 8 lanes = 1220 / 784 ms per step).
-        nvox_rel = float(np.prod(WORKLOADS[args.workload][0])) / 512.0 ** 3
-        share = world if (mode == "strong" and world > 1) else 1
-        per_lane = (7.5 + 11.0 / share) * nvox_rel * 1e9
-        free_b = torch.cuda.mem_get_info()[0]
-        most = int(max(1, min(12, (0.80 * free_b) // per_lane)))
+        from kimimaro_amd.lanes import lanes_for
+        share = 1.0 / world if (mode == "strong" and world > 1) else 1.0
+        most = lanes_for(WORKLOADS[args.workload][0], torch.cuda.mem_get_info()[0], most=12, share=share)
         # K equal volumes started together stay in lock step, so a run of K steps is ceil(K / lanes) rounds: the fewest
         # rounds the memory allows, and no more lanes than fill them evenly (K = 20: 10 + 10 rather than 12 + 8)
         rounds = -(-max(args.steps, 1) // most)

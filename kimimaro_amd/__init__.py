@@ -11,6 +11,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from ._abi import HipUnavailableError, KimiHipError  # noqa: F401
 from .intake import DEFAULT_TEASAR_PARAMS, DimensionError, skeletonize  # noqa: F401
+from .lanes import skeletonize_many  # noqa: F401
 from .post import join_close_components, postprocess  # noqa: F401
 from .skeleton import Skeleton  # noqa: F401
 

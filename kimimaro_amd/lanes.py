@@ -160,6 +160,55 @@ class Lanes:
                 th.join()
 
 
+def lanes_for(shape, free_bytes, most=12, share=1.0):
+    """how many volumes of `shape` to keep in flight on a GPU with `free_bytes` of HBM free: a lane holds the whole-volume
+    fields of its volume (56 B per voxel at 512^3 scale: ids, DBF, neighbour masks, PDRF, search scratch, the sweep's per-voxel
+    words) and the per-label scratch of the components it traces (82 B per voxel when the volume is all foreground; `share` =
+    the fraction of them this process traces), measured 17.9 GB at 512^3; 80 % of the free memory at most, `most` lanes at most."""
+    nvox = 1
+    for v in shape:
+        nvox *= int(v)
+    per_lane = (56.0 + 82.0 * float(share)) * nvox
+    return int(max(1, min(int(most), (0.80 * float(free_bytes)) // per_lane)))
+
+
+def skeletonize_many(volumes, teasar_params=None, lanes=None, width=None, **kwargs):
+    """kimimaro.skeletonize over MANY label volumes with several of them in flight on this GPU -- the form in which a dataset
+    cut into chunks (kimimaro's own deployment, README "Scaling"; `parallel=` of kimimaro/intake.py:344-408 has no meaning on
+    one GPU) reaches the throughput of bench.py.  `volumes`: a sequence of label arrays, or of zero-argument callables that load
+    one (called by the lane that takes the job, so loading overlaps tracing).  Yields (index, {label: Skeleton}) in order.
+    `lanes`: a Lanes object to reuse; else `width` lanes are made (default: lanes_for() on the first volume's shape).
+    The other keyword arguments are those of kimimaro_amd.skeletonize."""
+    from . import intake
+    n = len(volumes)
+    if n == 0:
+        return
+    params = intake.DEFAULT_TEASAR_PARAMS if teasar_params is None else teasar_params
+    cache = {}
+
+    def load(k):
+        v = volumes[k]
+        return v() if callable(v) else v
+
+    own = lanes is None
+    if own:
+        if width is None:
+            import torch
+            cache[0] = load(0)
+            width = min(n, lanes_for(cache[0].shape, torch.cuda.mem_get_info()[0]))
+        lanes = Lanes(max(1, int(width)))
+
+    def job(eng, k):
+        lab = cache.pop(k) if k in cache else load(k)
+        return intake.skeletonize(lab, params, _engine=eng, **kwargs)
+
+    try:
+        yield from lanes.run(job, n)
+    finally:
+        if own:
+            lanes.engines = []
+
+
 class _StreamScope:
     """Makes the lane's device and a non-blocking stream of its own current in the lane's thread."""
 

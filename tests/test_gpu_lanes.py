@@ -40,3 +40,18 @@ def test_lanes_match_oracle_on_different_volumes():
     again = dict(lanes.run(lambda eng, k: kimimaro_amd.skeletonize(vols[k], params, _engine=eng, **kw), 2, width=1))
     for k in again:
         _same(again[k], got[k])
+
+
+def test_skeletonize_many_in_order_with_loaders():
+    """kimimaro_amd.skeletonize_many: arrays and loader callables mixed, results in order, equal to one volume at a time"""
+    import kimimaro_amd
+    from shapes import voronoi_labels
+    an = (16, 16, 40)
+    vols = [voronoi_labels((80, 64, 40), 9 + s, 200 + s, pts_per_label=4, anisotropy=an) for s in range(5)]
+    kw = dict(anisotropy=an, dust_threshold=200, fix_borders=True, progress=False)
+    mixed = [vols[0], (lambda: vols[1]), vols[2], (lambda: vols[3]), vols[4]]
+    got = list(kimimaro_amd.skeletonize_many(mixed, width=3, **kw))
+    assert [k for k, _ in got] == list(range(5))
+    for k, sk in got:
+        _same(sk, kimimaro_amd.skeletonize(vols[k], **kw))
+    assert len(list(kimimaro_amd.skeletonize_many([], **kw))) == 0
