@@ -49,8 +49,10 @@ def c3():
         labels = np.unique(label_of[1:])
         chosen = set(label_of[big].tolist()) | set(rng.choice(labels, size=min(200, labels.size), replace=False).tolist())
         only = set(np.flatnonzero(np.isin(label_of, list(chosen)) & (np.arange(counts.size) > 0)).tolist())
+    from oracle.cpu_pool_baseline import usable_cores
+    aff, quota = usable_cores()                      # (the pool's boxes show 256 CPUs and grant 16: that many workers)
     want, cc, counts = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True,
-                                             fix_borders=True, only=only)
+                                             fix_borders=True, only=only, workers=max(2, int(min(aff, quota)) if quota else aff))
     return lab, an, params, want, only
 
 

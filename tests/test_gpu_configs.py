@@ -77,7 +77,10 @@ def c2():
     from oracle import pool
     lab, an = bench.make_volume("c2")
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
-    want, cc, counts = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True, fix_borders=True)
+    from oracle.cpu_pool_baseline import usable_cores
+    aff, quota = usable_cores()
+    want, cc, counts = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True, fix_borders=True,
+                                             workers=max(2, int(min(aff, quota)) if quota else aff))
     return lab, an, params, want, cc, counts
 
 
@@ -138,12 +141,15 @@ def test_c5_sample_matches_oracle(eng):
     segs, cnts = tk["segid"].astype(np.int64), tk["count"].astype(np.int64)
     big = segs[np.argsort(-cnts, kind="stable")[:32]]
     rng = np.random.default_rng(5)
-    nrand = 480 if (os.cpu_count() or 1) >= 64 else 96
+    from oracle.cpu_pool_baseline import usable_cores
+    aff, quota = usable_cores()
+    cores = int(min(aff, quota)) if quota else aff            # the pool's boxes show 256 CPUs and grant 16 (cgroup quota)
+    nrand = 480 if cores >= 64 else 96
     labels = np.unique(label_of[segs])
     chosen = set(label_of[big].tolist()) | set(rng.choice(labels, size=min(nrand, labels.size), replace=False).tolist())
     only = set(np.flatnonzero(np.isin(label_of, list(chosen)) & (np.arange(ncomp + 1) > 0)).tolist())
     want, _, _ = pool.skeletonize_pool(lab, params, anisotropy=an, dust_threshold=1000, fix_branching=True, fix_borders=True,
-                                       only=only)
+                                       only=only, workers=max(2, cores))
     assert sorted(want) == sorted(k for k in chosen if k in got) and len(want) >= 64
     for k, w in want.items():
         _same(got[k], w, k)
