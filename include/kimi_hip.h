@@ -147,6 +147,10 @@ typedef struct kh_label_t {
                             the label's radius, from the key table): the label then keeps lev_window level words, used round
                             robin, instead of nlev.  A bound that turns out too small costs speed, not results (the event
                             abandons the call to the heap emulation). */
+  uint32_t ev_spill;     /* in: entries of the sweep's candidate-spill table at the front of the arena (0 or a power of two; 12 bytes
+                            each, rounded up to 256 bytes): the fifth to eighth possible owner of a voxel (csrc/sweep.h) */
+  uint32_t stat_ghost_calls;  /* out: calls of the sweep that left voxels undecided and went on with them as ghosts */
+  uint32_t stat_rollbacks;    /* out: times the label rolled back to such a call and redid it by the heap emulation */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
@@ -208,10 +212,16 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * zeroed u64 per voxel (zero again on exit), event_arena = 256-byte aligned scratch addressed by ev_offset /
  * ev_chunks / ev_shift / nlev / lev_window of each task; max_nlev = the number of level words every workgroup of the launch
  * gets in LDS (<= KH_SWEEP_LDS_LEVELS): a task keeps its words there when its lev_window (if non-zero) or else its nlev fits;
- * a task for which neither does runs all its invalidations as the heap emulation.  A task's arena = a free stack of ev_chunks u32,
- * rounded up to 256 bytes, followed by the chunks.  level_rank == NULL switches the sweep off.
+ * a task for which neither does runs all its invalidations as the heap emulation.  A task's arena = the candidate-spill table,
+ * a free stack of ev_chunks u32 (each rounded up to 256 bytes), then the chunks.  level_rank == NULL switches the sweep off.
  * sched (nullable) = one u32 per voxel, 0xFFFFFFFF on entry for every voxel that is alive (and again on exit): the sweep's
  * pending-deadline filter (csrc/sweep.h) -- with it a voxel is handed ~1.3 events per call instead of ~13; NULL = unfiltered.
+ * Ghosts: journal (nullable) = u32 scratch, 2 * q_capacity entries per task at 2 * q_offset; rail_save (nullable)
+ * = f32 scratch laid out like path_vertices.  With both, a call of the sweep that leaves voxels undecided goes on with them as
+ * "ghosts" instead of running the heap emulation at once; the label rolls back to that call and redoes it exactly only if a
+ * ghost would influence the loop.  Results are identical either way (KH_TRACE_NO_GHOSTS switches it off for A/B runs,
+ * KH_TRACE_GHOST_PARANOID rolls every such call back at once -- a test of the roll-back itself).  Each task's arena starts with
+ * its candidate-spill table (ev_spill entries of 12 bytes, rounded up to 256 bytes), then the free stack, then the chunks.
  * flags: KH_TRACE_PROFILE also fills cyc_pop / cyc_push / cyc_fire (slower kernel variant); KH_TRACE_HEAP_PRIO see below.
  * fix_branching = 0 selects the parental-field variant (trace.py:155,244): one weighted Dijkstra
  * from the root, paths returned root -> target.                                                  */
@@ -219,6 +229,8 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
 #define KH_TRACE_HEAP_PRIO 2   /* the wave running the heap emulation raises its issue priority (several volumes in flight) */
 #define KH_TRACE_THREADS_64 4  /* workgroups of 64 threads (one wave per label, up to 12 labels per CU) instead of 256 */
 #define KH_TRACE_THREADS_128 8 /* workgroups of 128 threads */
+#define KH_TRACE_NO_GHOSTS 16  /* undecided voxels abandon the call to the heap emulation at once (rounds 2-4) */
+#define KH_TRACE_GHOST_PARANOID 32  /* roll back after every call that made a ghost (tests) */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,
@@ -228,7 +240,8 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
                    uint32_t* queues, void* heap_nodes,
                    uint32_t* path_vertices, uint32_t* path_lengths,
                    const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                   uint64_t* cstate, uint32_t* sched, void* event_arena, int flags, int fix_branching, void* stream);
+                   uint64_t* cstate, uint32_t* sched, void* event_arena, uint32_t* journal, float* rail_save,
+                   int flags, int fix_branching, void* stream);
 
 /* keys[a + ra*(b + rb*c)] = the flood's key of the voxel offset (a, b, c): sqrt(fl(fl((wx*a)^2 + (wy*b)^2) + (wz*c)^2)),
  * float operation order of dijkstra_invalidation.hpp:310-316.  Device array of ra*rb*rc floats.              */

@@ -30,7 +30,7 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 47 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 50 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
@@ -43,9 +43,9 @@ LABEL_T = np.dtype([
     ("soma_mode", "<u4"), ("fsr", "<f4"), ("soma_radius", "<f4"), ("soma_scale", "<f4"), ("soma_const", "<f4"),
     ("nlev", "<u4"), ("sweep_rmax", "<f4"), ("ev_offset", "<u4"), ("ev_chunks", "<u4"), ("ev_shift", "<u4"),
     ("stat_sweep_calls", "<u4"), ("stat_sweep_bails", "<u4"), ("stat_sweep_levels", "<u4"), ("stat_sweep_events", "<u4"),
-    ("stat_sweep_why", "<u4"), ("lev_window", "<u4"),
+    ("stat_sweep_why", "<u4"), ("lev_window", "<u4"), ("ev_spill", "<u4"), ("stat_ghost_calls", "<u4"), ("stat_rollbacks", "<u4"),
 ])
-assert LABEL_T.itemsize == 188
+assert LABEL_T.itemsize == 200
 SWEEP_LDS_LEVELS = 16384  # KH_SWEEP_LDS_LEVELS
 SWEEP_MAX_LEVELS = 1 << 22  # labels with more levels than this use the heap emulation only
 PDRF_BASE, PDRF_FINISH = -1, -2  # KH_PDRF_BASE / KH_PDRF_FINISH
@@ -56,10 +56,12 @@ def is_pow2_exponent(e):
     The reference's test (trace.py:310-313) evaluates `num & (num - 1)`: an integral FLOAT exponent (16.0, np.float64(4))
     passes its `int(num) != num` line and then raises TypeError there; so does this mirror."""
     try:
-        i = int(e)
-    except (TypeError, ValueError):
+        i = int(e)           # (a NaN raises ValueError here, as the reference's `int(num)` does)
+    except TypeError:
         return False
     if i != e:
+        return False
+    if i == 0:               # trace.py:311: `if num != 0 and ...` short-circuits -- 0 and 0.0 take the np.power branch
         return False
     if isinstance(e, (float, np.floating)):
         raise TypeError("unsupported operand type(s) for &: 'float' and 'float' (pdrf_exponent must be an integer type, "
@@ -104,7 +106,7 @@ def lib():
     L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp]
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
-                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, ci, ci, vp]
+                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, ci, ci, vp]
     L.kh_invalidate_ball.argtypes = [vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, i64, f32, f32,
                                      vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.kh_apply_voxel_graph.argtypes = [vp, vp, i64, vp, vp]

@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void apply_voxel_graph_kernel(uint32_t* nbrmas
   if (corner_gate) {
     // a corner entry (18..25) of a voxel on an x face of its array degenerates into the yz diagonal with the corner's y / z steps
     // (dijkstra_invalidation.hpp:116-123), and the graph gates it by the CORNER's bit (:182-190): bit j = that diagonal exists
-    // (same label, in bounds) and corner 18 + j is allowed.  Only the heap emulation's tie order can see it.
+    // (same label, in bounds) and corner 18 + j is allowed.  Both the heap emulation and the sweep (sweep_mask) read it: the
+    // diagonal can be ENTERED through such a corner although its own bit is clear.
     uint32_t cg = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {

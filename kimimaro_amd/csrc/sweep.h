@@ -42,6 +42,8 @@ namespace kh {
 
 static constexpr uint32_t SW_NONE = 0xFFFFFFFFu;
 static constexpr unsigned long long SW_DYING = 1ull << 63;
+static constexpr unsigned long long SW_SPILL = 1ull << 15;      // the voxel's fifth to eighth possible owners are in the spill table
+static constexpr uint8_t SW_GHOST = 3;                          // alive byte of a voxel that is dead under SOME resolutions of an earlier call
 static constexpr uint32_t SW_P = 1u << 16, SW_D = 1u << 17;     // event meta = source index (15 bits) | type
 static constexpr uint32_t SW_CHAIN = 512;                        // chunks per level the reader can take (LDS list)
 static constexpr uint32_t SW_NOCHUNK = 0x3FFFFFu;                // 22-bit chunk ids
@@ -54,6 +56,9 @@ static constexpr uint32_t SW_BAIL_M = 1, SW_BAIL_CAND = 2, SW_BAIL_ARENA = 4, SW
 struct SweepShared {
   uint32_t lvl, nev, ord, openid;
   uint32_t na, nb, nnp, bump, nkill, snap, bail;
+  uint32_t nkg;        // killed voxels that were ghosts (they do not count as invalidated: the caller's count of valid voxels never held them)
+  uint32_t nspill;     // voxels with an entry in the spill table (the table is cleared at the end of a call that used it)
+  uint32_t nghost;     // out: voxels this call left undecided (ghosts made)
   int32_t nM;
   int32_t nfree;       // chunks on the free stack (transiently negative while lanes that found it empty put their claim back)
   uint32_t nprev;      // chunks of the level being processed: they go to the free stack when the next level is looked for
@@ -93,6 +98,14 @@ struct Sweep {
   KH_AS_GLOBAL unsigned long long* np;   // [ncap] pairs added by pure P events (their voxel may survive the level)
   KH_AS_GLOBAL uint32_t* wb;             // [ncap] deadline cascade
   uint32_t ncap;
+  // voxel_connectivity_graph only (nullptr otherwise): bit j = corner entry 18 + j of the voxel is allowed AND the yz diagonal it
+  // degenerates into at an x face of the label's array exists (kh_apply_voxel_graph); xmin / xmax = those faces
+  const KH_AS_GLOBAL uint8_t* gate;
+  uint32_t xmin, xmax;
+  // candidate spill: open-addressing table keyed by voxel, for the voxels with more than four possible owners (front of the arena)
+  KH_AS_GLOBAL uint32_t* spk;              // [spcap] voxel + 1, 0 = free
+  KH_AS_GLOBAL unsigned long long* spc;    // [spcap] four more 15-bit candidate slots, laid out like the voxel's own word
+  uint32_t spcap;                          // a power of two, 0 = no table (a fifth candidate abandons the call)
 };
 typedef const KH_AS_LDS Sweep& SweepRef;   // the workgroup's record (LDS)
 
@@ -201,6 +214,25 @@ __device__ __forceinline__ void sweep_coords(SweepRef s, uint32_t v, int& x, int
   const uint32_t sx = (uint32_t)s.g->sx, sxy = (uint32_t)s.g->sxy;
   const uint32_t zz = v / sxy, r = v - zz * sxy, yy = r / sx;
   z = (int)zz; y = (int)yy; x = (int)(r - yy * sx);
+}
+
+// The neighbours the flood can reach from v.  With a voxel_connectivity_graph the reference gates a corner entry that degenerated
+// into a yz diagonal at an x face by the CORNER's bit (dijkstra_invalidation.hpp:116-123, 182-190), so that diagonal can be
+// entered although its own bit is clear: the sweep follows it too (the heap emulation reads the gate bytes for the same reason).
+__device__ __forceinline__ uint32_t sweep_mask(SweepRef s, uint32_t v, uint32_t nm) {
+  if (s.gate == nullptr) return nm;
+  const uint32_t g = s.gate[v];
+  const uint32_t x = v % (uint32_t)s.g->sx;
+  uint32_t extra = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    int dx, dy, dz;
+    dir_delta(18 + j, dx, dy, dz);
+    const int kd = 10 + (dy > 0 ? 2 : 0) + (dz > 0 ? 1 : 0);
+    const bool face = dx < 0 ? x == s.xmin : x == s.xmax;
+    extra |= (uint32_t)(((g >> j) & 1u) && face) << kd;
+  }
+  return nm | extra;
 }
 
 // ---- neighbour batches.  An event looks at its 26 neighbours; done one after the other that is a chain of ~50
@@ -345,11 +377,54 @@ __device__ __forceinline__ uint32_t sweep_claim13(KH_AS_GLOBAL uint32_t* sched, 
   return keep & want;
 }
 
+// ---- candidate spill.  Four possible owners per voxel are the rule; a voxel near the bisector planes of several path vertices
+// (or deep inside overlapping balls of a thick object) can have more, and without their identities no deadline can be derived
+// from its death.  Owners five to eight go to a small label-private hash table (linear probing on voxel + 1); the voxel's own word
+// gets the SW_SPILL flag once the entry is complete.  Candidates are only added in the candidate phase of a level and only read
+// in its deadline phase, with workgroup barriers between the two, so a reader always sees a finished entry.
+// Returns 0 = c was a candidate already, 1 = added, 2 = no room (table full or a ninth candidate).
+__device__ __attribute__((noinline)) int sweep_spill_add(SweepRef s, uint32_t v, uint32_t c) {
+  if (s.spcap == 0u) return 2;
+  const uint32_t mask = s.spcap - 1u;
+  uint32_t h = (v * 0x9E3779B1u) >> 7 & mask;
+  for (uint32_t probes = 0;; probes++, h = (h + 1u) & mask) {
+    if (probes == s.spcap) return 2;
+    const uint32_t k = sw_g_cas(&s.spk[h], 0u, v + 1u);
+    if (k == 0u) { SW_L_ADD(&s.sh->nspill, 1u); break; }
+    if (k == v + 1u) break;
+  }
+  unsigned long long cs = __hip_atomic_load(&s.spc[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    int freeslot = -1;
+#pragma unroll
+    for (int i = 3; i >= 0; i--) {
+      const uint32_t sl = (uint32_t)(cs >> (16 * i)) & 0x7fffu;
+      if (sl == c + 1u) return 0;
+      if (sl == 0u) freeslot = i;
+    }
+    if (freeslot < 0) return 2;
+    const unsigned long long old = sw_g_cas(&s.spc[h], cs, cs | ((unsigned long long)(c + 1u) << (16 * freeslot)));
+    if (old == cs) return 1;
+    cs = old;
+  }
+}
+// the spilled candidates of v (its own word carries SW_SPILL)
+__device__ __attribute__((noinline)) unsigned long long sweep_spill_get(SweepRef s, uint32_t v) {
+  const uint32_t mask = s.spcap - 1u;
+  uint32_t h = (v * 0x9E3779B1u) >> 7 & mask;
+  for (uint32_t probes = 0; probes < s.spcap; probes++, h = (h + 1u) & mask) {
+    const uint32_t k = sweep_ld(&s.spk[h]);
+    if (k == v + 1u) return __hip_atomic_load(&s.spc[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == 0u) break;
+  }
+  return 0ull;
+}
+
 // a P event (c may own v from this level on)
 __device__ __forceinline__ void sweep_possible(SweepRef s, uint32_t lvl, uint32_t v, uint32_t c, bool has_deadline) {
   const uint8_t live = s.alive[v];
   unsigned long long cs = s.cstate[v];
-  const uint32_t nm = s.nbrmask[v];
+  const uint32_t nm = sweep_mask(s, v, s.nbrmask[v]);
   const u32x4_t src = s.srcs[c];
   if (!live) return;
   // the neighbours' alive bytes are asked for before the CAS below, so that the two round trips overlap (an event that
@@ -364,7 +439,14 @@ __device__ __forceinline__ void sweep_possible(SweepRef s, uint32_t lvl, uint32_
       if (sl == c + 1u) return;                  // already a candidate
       if (sl == 0u) freeslot = i;
     }
-    if (freeslot < 0) { sweep_bail(s, SW_BAIL_CAND); return; }
+    if (freeslot < 0) {
+      // a fifth-plus possible owner: the spill table (rare)
+      const int r = sweep_spill_add(s, v, c);
+      if (r == 2) { sweep_bail(s, SW_BAIL_CAND); return; }
+      if (r == 0) return;
+      if (!(cs & SW_SPILL)) SW_G_OR(&s.cstate[v], SW_SPILL);
+      break;
+    }
     want = cs | ((unsigned long long)(c + 1u) << (16 * freeslot));
     const unsigned long long old = sw_g_cas(&s.cstate[v], cs, want);
     if (old == cs) break;
@@ -406,7 +488,7 @@ __device__ __forceinline__ void sweep_possible(SweepRef s, uint32_t lvl, uint32_
 // P events of the pair (v, c) to the levels above lvl (the pair was added by a pure P event and v survives the level)
 __device__ __forceinline__ void sweep_emit_possible(SweepRef s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
                                                     uint32_t c) {
-  const uint32_t nm = s.nbrmask[v];
+  const uint32_t nm = sweep_mask(s, v, s.nbrmask[v]);
   const u32x4_t src = s.srcs[c];
   const uint32_t am = sweep_alive_nbrs(s, v, nm);
   if (!am) return;
@@ -446,6 +528,42 @@ __device__ __forceinline__ void sweep_deadline_one(SweepRef s, const SweepFilter
   }
 }
 
+// the neighbours of a dying voxel with up to eight candidate sources (w0: its own word, w1: the spilled ones) or of a dying
+// ghost -- the rare cases, written as plain loops.  A neighbour dies with v when ALL candidates cover it (deadline at the largest
+// of their keys); every candidate's possible node of a later level goes out on its own.  A ghost may have been dead all along:
+// it emits its possible nodes but no deadlines.
+__device__ __attribute__((noinline)) void sweep_deadline_many(SweepRef s, const SweepFilter flt, uint32_t& spare, uint32_t lvl,
+                                                             uint32_t v, unsigned long long w0, unsigned long long w1, uint32_t am,
+                                                             bool ghost) {
+  int x, y, z;
+  sweep_coords(s, v, x, y, z);
+  for (uint32_t m = am; m; m &= m - 1u) {
+    const int k = __ffs((int)m) - 1;
+    const uint32_t q = v + (uint32_t)s.g->off[k];
+    int dx, dy, dz;
+    sweep_dir(k, dx, dy, dz);
+    bool all = true;
+    uint32_t tr = 0;
+    for (int i = 0; i < 8; i++) {
+      const uint32_t sl = (uint32_t)((i < 4 ? w0 : w1) >> (16 * (i & 3))) & 0x7fffu;
+      if (sl == 0u) continue;
+      uint32_t rk = 0;
+      const bool cov = sweep_eval(s, s.srcs[sl - 1u], x + dx, y + dy, z + dz, rk);
+      all = all && cov;
+      if (cov && rk > tr) tr = rk;
+      if (cov && rk > lvl && !sweep_moot(flt, q, rk)) sweep_push(s, spare, lvl, rk, q, (sl - 1u) | SW_P);
+    }
+    if (!all || ghost) continue;
+    if (tr <= lvl) {
+      if (s.cstate[q] & SW_DYING) continue;
+      const uint32_t p = SW_L_ADD(&s.sh->nb, 1u);
+      if (p < s.ncap) s.wb[p] = q; else sweep_bail(s, SW_BAIL_LIST);
+    } else if (sweep_claim(flt, q, tr, 0u)) {
+      sweep_push(s, spare, lvl, tr, q, SW_D);
+    }
+  }
+}
+
 // a D event: v is dead once this level is complete
 // `hint`: the source of the event when it is a PD event (the usual single candidate of its voxel), SW_NONE otherwise.
 // The first round trip carries everything that does not depend on anything else: the voxel's alive byte and neighbour mask,
@@ -455,7 +573,7 @@ __device__ __forceinline__ void sweep_deadline_one(SweepRef s, const SweepFilter
 __device__ __forceinline__ void sweep_deadline(SweepRef s, const SweepFilter flt, uint32_t& spare, uint32_t lvl, uint32_t v,
                                                uint32_t hint) {
   const uint8_t live = s.alive[v];
-  const uint32_t nm = s.nbrmask[v];
+  const uint32_t nm = sweep_mask(s, v, s.nbrmask[v]);
   const u32x4_t hsrc = s.srcs[hint != SW_NONE ? hint : 0u];
   const unsigned long long old = SW_G_OR(&s.cstate[v], SW_DYING);
   const uint32_t am = sweep_alive_nbrs(s, v, nm);
@@ -466,6 +584,8 @@ __device__ __forceinline__ void sweep_deadline(SweepRef s, const SweepFilter flt
   if (old & SW_DYING) return;
   if (old == 0ull) { sweep_bail(s, SW_BAIL_UNTOUCHED); return; }
   s.killed[SW_L_ADD(&s.sh->nkill, 1u)] = v;
+  const bool ghost = live == SW_GHOST;
+  if (ghost) SW_L_ADD(&s.sh->nkg, 1u);
   // the candidate slots stay where they are in the word (no compaction: every array below is indexed by constants only,
   // so nothing of this lives in scratch memory)
   uint32_t cid[4];
@@ -479,16 +599,23 @@ __device__ __forceinline__ void sweep_deadline(SweepRef s, const SweepFilter flt
     nc += has[i] ? 1 : 0;
   }
   if (!am) return;
-  int x, y, z;
-  sweep_coords(s, v, x, y, z);
+  if ((old & SW_SPILL) || (ghost && nc > 1)) {
+    sweep_deadline_many(s, flt, spare, lvl, v, old, (old & SW_SPILL) ? sweep_spill_get(s, v) : 0ull, am, ghost);
+    return;
+  }
   if (nc == 1) {
     uint32_t c1 = cid[0];
 #pragma unroll
     for (int i = 1; i < 4; i++) if (has[i]) c1 = cid[i];
+    if (ghost) { sweep_emit_possible(s, flt, spare, lvl, v, c1); return; }   // its possible nodes, no deadlines
+    int x, y, z;
+    sweep_coords(s, v, x, y, z);
     const u32x4_t s1 = c1 == hint ? hsrc : s.srcs[c1];       // (the hinted record is here already)
     sweep_deadline_one(s, flt, spare, lvl, v, c1, s1, x, y, z, am);
     return;
   }
+  int x, y, z;
+  sweep_coords(s, v, x, y, z);
   u32x4_t src[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) src[i] = s.srcs[has[i] ? cid[i] : 0u];
@@ -536,9 +663,16 @@ __device__ __forceinline__ u32x2_t sweep_event(SweepRef s, uint32_t e, uint32_t 
 // Whole workgroup.  path / npath: the vertices of the new path; srcs has room for npath records.
 // Returns true when certified (alive updated, *count = voxels invalidated); false when the call has to be redone by
 // the heap emulation (alive and cstate are as they were on entry).
+// allow_ghosts: a call that ends with undecided voxels (state M: alive under some resolutions of the heap's tie order only) is
+// not abandoned; those voxels become GHOSTS (alive byte SW_GHOST) and the call counts as certified.  In the calls that follow a
+// ghost takes candidates and passes possible nodes on like an alive voxel (it may be one), a deadline kills it for certain, and
+// it emits no deadlines itself (it may have been dead all along) -- so everything those calls decide holds under either
+// status.  The caller must not let a ghost influence its control flow (it rolls back to this call and redoes
+// it by the heap emulation when one would).  The ghosts made are appended to s.killed behind the killed voxels
+// (sh->nkill of them; sh->nghost ghosts), *count = killed voxels that were no ghosts, sh->nkg = killed ghosts.
 __device__ __forceinline__ bool sweep_ball(SweepRef s, const uint32_t* path, uint32_t npath, const float* __restrict__ dbf,
                                                      float scale, float constant, float rmax, const uint32_t* list, uint32_t nf,
-                                                     uint32_t* count) {
+                                                     uint32_t* count, bool allow_ghosts = false) {
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   KH_AS_LDS SweepShared* sh = s.sh;
   const SweepFilter flt = sweep_filter(s, npath);
@@ -550,6 +684,7 @@ __device__ __forceinline__ bool sweep_ball(SweepRef s, const uint32_t* path, uin
   if (tid == 0) {
     sh->na = sh->nb = sh->nnp = sh->bump = sh->nkill = sh->snap = sh->bail = 0u;
     sh->nM = 0;
+    sh->nkg = sh->nspill = sh->nghost = 0u;
     sh->nfree = 0;
     sh->nprev = 0u;
     sh->lvl = 0u;
@@ -717,19 +852,37 @@ __device__ __forceinline__ bool sweep_ball(SweepRef s, const uint32_t* path, uin
   }
   __syncthreads();
   uint32_t bail = sh->bail;
-  if (!bail && sh->nM != 0) bail = SW_BAIL_M;
-  const uint32_t nk = sh->nkill;
+  const int nM = sh->nM;
+  if (!bail && nM != 0 && !allow_ghosts) bail = SW_BAIL_M;
+  const uint32_t nk = sh->nkill, nsp = sh->nspill;
   __syncthreads();
+  if (nsp) {
+    // the spill table goes back to all-free (only a call that used it pays for this)
+    for (uint32_t i = tid; i < s.spcap; i += nthr) { s.spk[i] = 0u; s.spc[i] = 0ull; }
+  }
   if (bail) {
-    // undo: the killed voxels come back, every per-voxel word of the label is cleared
+    // undo: the killed voxels come back (ghosts as ghosts), every per-voxel word of the label is cleared
     if (tid == 0) sh->bail = bail;
-    for (uint32_t i = tid; i < nk; i += nthr) s.alive[s.killed[i]] = 1;
+    for (uint32_t i = tid; i < nk; i += nthr) { const uint32_t v = s.killed[i]; s.alive[v] = (uint8_t)(s.alive[v] == 0 ? 1 : s.alive[v]); }
     for (uint32_t i = tid; i < nf; i += nthr) s.cstate[list[i]] = 0ull;
     if (s.sched != nullptr) for (uint32_t i = tid; i < nf; i += nthr) s.sched[list[i]] = SW_SCHED_NONE;
     __syncthreads();
     return false;
   }
-  *count = nk;
+  if (nM != 0) {
+    // undecided voxels = the ones that still carry candidates: they become ghosts (an old ghost that was touched again stays one)
+    for (uint32_t i = tid; i < nf; i += nthr) {
+      const uint32_t v = list[i];
+      if (s.cstate[v] == 0ull) continue;
+      s.cstate[v] = 0ull;
+      if (s.alive[v] == 1) {
+        s.alive[v] = SW_GHOST;
+        s.killed[nk + SW_L_ADD(&sh->nghost, 1u)] = v;
+      }
+    }
+    __syncthreads();
+  }
+  *count = nk - sh->nkg;
   return true;
 }
 

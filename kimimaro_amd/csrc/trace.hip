@@ -536,7 +536,7 @@ __device__ __forceinline__ void heap_pop_wave(H& h, int lane) {
 // wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
 // cycle split (s_memtime waits on the scalar memory counter, so the production kernel leaves it out).
 template <bool PROF, class H>
-__device__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
+__device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                     float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3, const uint8_t* __restrict__ corner_gate = nullptr) {
@@ -770,18 +770,31 @@ struct SweepGlobal {
 };
 
 // One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
-// certifies the call, the heap emulation (wave 0) otherwise.  Returns the number of voxels invalidated.
+// certifies the call, the heap emulation (wave 0) otherwise.  Returns the number of voxels invalidated (ghosts that were killed
+// not counted: sw->sh->nkg; ghosts made: sw->sh->nghost -- both zero unless allow_ghosts).
+//   kill_log      where the sweep logs the voxels it kills (+ the ghosts it makes): the label's journal in ghost mode
+//   allow_ghosts  a call that leaves voxels undecided ends as certified, the voxels become ghosts (sweep.h)
+//   force_heap    skip the sweep (the redo of a call after a roll-back)
+//   heap_ok       false while ghosts exist: the heap emulation needs the exact mask, so a call the sweep abandons cannot be
+//                 redone here -- ctl->u0 = 1 tells the caller to roll back (nothing has been changed)
 template <bool PROF, class H>
 __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                                const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
                                                float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
-                                               uint32_t* sweep_stats, uint32_t heap_prio,
+                                               uint32_t* sweep_stats, uint32_t heap_prio, uint32_t* kill_log,
+                                               bool allow_ghosts = false, bool force_heap = false, bool heap_ok = true,
                                                const uint8_t* __restrict__ corner_gate = nullptr) {
   const int tid = threadIdx.x;
   bool ok = false;
-  if (sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
+  if (tid == 0) {
+    sw->killed = (KH_AS_GLOBAL uint32_t*)kill_log;
+    sw->sh->nkg = 0u; sw->sh->nghost = 0u;
+    ctl->u0 = 0u;
+  }
+  __syncthreads();
+  if (!force_heap && sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
     uint32_t cnt = 0;
-    ok = sweep_ball(*(const KH_AS_LDS Sweep*)sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt);
+    ok = sweep_ball(*(const KH_AS_LDS Sweep*)sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt, allow_ghosts);
     if (tid == 0) {
       sweep_stats[0]++;
       sweep_stats[2] += sw->sh->levels;
@@ -792,11 +805,18 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
                sw->sh->levels, sw->sh->events, sw->sh->cyc[0], sw->sh->cyc[1], sw->sh->cyc[2], sw->sh->cyc[3], sw->sh->cyc[6],
                sw->sh->cyc[4], sw->sh->cyc[5]);
 #endif
-      if (!ok) { sweep_stats[1]++; sweep_stats[4] |= sw->sh->bail; }
+      if (!ok) { sweep_stats[1]++; sweep_stats[4] |= sw->sh->bail; sw->sh->nkg = 0u; sw->sh->nghost = 0u; }
       if (sw->sh->maxnev > task->cyc_pop) task->cyc_pop = sw->sh->maxnev;   // diagnostic: busiest level
       if (sw->sh->bump > task->cyc_push) task->cyc_push = sw->sh->bump;      // diagnostic: arena blocks used
       ctl->u1 = cnt;
     }
+  } else if (tid == 0 && force_heap) {
+    sweep_stats[1]++; sweep_stats[4] |= SW_BAIL_M;       // a call redone by the heap emulation after a roll-back
+  }
+  if (!ok && !heap_ok) {
+    if (tid == 0) { ctl->u0 = 1u; ctl->u1 = 0u; }
+    __syncthreads();
+    return 0u;
   }
   if (!ok) {
     __syncthreads();
@@ -821,7 +841,7 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
 // pointers get their address spaces here (sweep.h works on typed pointers only).
 __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* ctl, const SweepGlobal& sg, const kh_label_t* task,
                                             const uint32_t* nbrmask, uint8_t* alive, hnode_t* heap_node, uint32_t* killed,
-                                            uint32_t nf, unsigned char* lds) {
+                                            uint32_t nf, unsigned char* lds, const uint8_t* corner_gate = nullptr) {
   typedef KH_AS_GLOBAL unsigned char gbyte_t;
   const uint32_t nlev = task->nlev;
   sw.g = (const KH_AS_LDS Geometry*)&ctl->g;
@@ -847,8 +867,13 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   if (!windowed && nlev > sg.lds_levels) sw.rank = nullptr;
   sw.nslots = windowed ? win : nlev;
   sw.wmask = windowed ? win - 1u : 0xFFFFFFFFu;
-  // arena: [free stack: one u32 per chunk][chunks]
+  // arena: [spill table: ev_spill keys (u32) + ev_spill candidate words (u64)][free stack: one u32 per chunk][chunks]
   gbyte_t* fsp = (gbyte_t*)(sg.arena + (size_t)task->ev_offset * 256u);
+  const uint32_t spcap = task->ev_spill;          // 0 or a power of two
+  sw.spcap = (spcap & (spcap - 1u)) == 0u ? spcap : 0u;
+  sw.spc = (KH_AS_GLOBAL unsigned long long*)fsp;
+  sw.spk = (KH_AS_GLOBAL uint32_t*)(fsp + (size_t)sw.spcap * 8u);
+  fsp += (((size_t)sw.spcap * 12u) + 255u) & ~(size_t)255u;
   sw.fs = (KH_AS_GLOBAL uint32_t*)fsp;
   sw.chunks = (KH_AS_GLOBAL u32x2_t*)(fsp + ((((size_t)task->ev_chunks * 4u) + 255u) & ~(size_t)255u));
   sw.chcap = task->ev_chunks;
@@ -859,7 +884,22 @@ __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* c
   sw.words = sw.chain + SW_CHAIN;
   sw.lvbits = sw.words + sw.nslots;
   sw.sh = (KH_AS_LDS SweepShared*)swsh;
+  sw.gate = (const KH_AS_GLOBAL uint8_t*)corner_gate;
+  sw.xmin = task->xmin; sw.xmax = task->xmax;
 }
+
+// Ghosts and roll-back.  A call of the sweep that leaves voxels undecided no longer runs the heap emulation
+// at once: the voxels become ghosts (sweep.h) and the loop goes on -- everything the later calls decide holds under either status
+// of a ghost, and most ghosts are killed for certain by a later ball.  The loop itself must never act on a ghost: when a ghost
+// could be the next target, when no certainly-valid voxel is left while ghosts are, or when a later call would need the heap
+// emulation (which needs the exact mask), the label ROLLS BACK to the call that made the first ghost -- the journal holds every
+// voxel that changed since (killed or made a ghost: all alive again), the rails of the later paths get their weights back -- and
+// that call is redone by the exact heap emulation; then the loop continues from there, without ghosts.
+struct GhostState {
+  uint32_t nghost;       // ghosts alive now
+  uint32_t jpos;         // journal entries (0 whenever no ghost exists)
+  uint32_t paths, verts, valid, nb, na;   // the state before the call that made the first ghost
+};
 
 template <bool PROF, int TOPL>
 __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
@@ -870,7 +910,8 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
                                                           const uint32_t* __restrict__ manual_targets,
                                                           float scale, float constant, uint32_t* queues, hnode_t* heap_nodes,
                                                           uint32_t* path_vertices,
-                                                          uint32_t* path_lengths, int fix_branching, SweepGlobal sg) {
+                                                          uint32_t* path_lengths, int fix_branching, SweepGlobal sg,
+                                                          uint32_t* journal_buf, float* rail_save, uint32_t ghost_mode) {
   __shared__ Ctl ctl;
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
@@ -898,6 +939,8 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   heap_init_lane(heap, lane);
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
+  float* psave = rail_save ? rail_save + task->path_offset : nullptr;        // the weight a path vertex had before it became a rail
+  uint32_t* journal = journal_buf ? journal_buf + (uint64_t)task->q_offset * 2 : nullptr;   // 2 * q_capacity entries
   const uint32_t pcap = task->path_capacity;
   const uint32_t root = task->root;
   const uint32_t* before = manual_targets + task->tgt_offset;
@@ -909,11 +952,19 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   uint32_t valid = nf;
   uint32_t npaths = 0, nverts = 0;
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
+  // ghost mode: bit 0 = on, bit 1 = every call that makes a ghost is rolled back at once (tests of the roll-back itself)
+  const bool ghosts_on = (ghost_mode & 1u) != 0u && journal != nullptr && (psave != nullptr || !fix_branching) && sg.rank != nullptr;
+  const bool paranoid = (ghost_mode & 2u) != 0u;
+  GhostState gs = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t n_ghost_calls = 0, n_rollbacks = 0;
   if (tid == 0) {
     ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
     sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top);
   }
+  __syncthreads();
+  // the spill table of the sweep starts all-free (the arena is uninitialised memory)
+  for (uint32_t i = tid; i < sw.spcap; i += nthr) { sw.spk[i] = 0u; sw.spc[i] = 0ull; }
   __syncthreads();
   if (soma) {
     // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
@@ -921,7 +972,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                          heap, list, nf, sweep_stats, sg.heap_prio);   // trace.py:211 counts what is left
+                                          heap, list, nf, sweep_stats, sg.heap_prio, q.a);   // trace.py:211 counts what is left
   }
   const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
   if (nb + na >= max_paths) {                           // trace.py:217-218
@@ -935,131 +986,185 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
   }
   __syncthreads();
-  while ((valid > 0 || nb > 0 || na > 0) && npaths < max_paths) {
-    // ---- target selection, trace.py:225-230
-    t0 = clock64();
-    uint32_t target;
-    if (nb > 0) { nb--; target = implicit ? task->max_loc : before[nb]; }
-    else if (valid == 0) { na--; target = after[na]; }
-    else {
-      // CachedTargetFinder.find_target: the valid voxel with the largest DAF (ties: largest index)
-      unsigned long long best = 0;
-      for (uint32_t i = tid; i < nf; i += nthr) {
-        const uint32_t v = list[i];
-        if (!alive[v]) continue;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(ldaf[i]) << 32) | v;
-        if (key >= best) best = key;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long ob = __shfl_xor(best, o);
-        if (ob > best) best = ob;
-      }
-      if (lane == 0) ctl.red64[wave] = best;
-      __syncthreads();
-      best = ctl.red64[0];
-      for (int i = 1; i < nwav; i++) if (ctl.red64[i] > best) best = ctl.red64[i];
-      target = (uint32_t)best;
-      __syncthreads();
-    }
-    // ---- railroad, trace.py:240-242
-    t_target += clock64() - t0; t0 = clock64();
+  bool redo = false;      // this iteration redoes the invalidation of path `npaths` by the heap emulation (after a roll-back)
+  for (;;) {
+    if (npaths >= max_paths) break;
+    bool rollback = false;
     uint32_t plen = 0;
-    if (nverts >= pcap || npaths >= pcap) {
-      if (tid == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW);
-      __syncthreads();
-      break;
-    }
     uint32_t* out = pverts + nverts;
-    if (!fix_branching) {
-      // dijkstra3d.path_from_parents (trace.py:244): walk target -> root, return root -> target
-      if (tid == 0) ctl.u0 = 0;
-      __syncthreads();
-      if (wave == 0) {
-        const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, q.a, q.b, q.cap,
-                                            qstate, &ctl.status);
-        for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
-        if (lane == 0) ctl.u0 = n;
-      }
-      __syncthreads();
-      plen = ctl.u0;
-      if (plen == 0) break;
-    } else if (pdrf[target] == 0.0f) {
-      if (tid == 0) out[0] = target;
-      plen = 1;
-    } else {
-      sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f);
-      const unsigned long long br = ctl.best_rail;
-      if (tid == 0) { ctl.u0 = 0; ctl.u2 += ctl.n_touched; }
-      __syncthreads();
-      if (br == NONE64) {
-        if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
-      } else if (wave == 0) {
-        const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, q.a, q.b,
-                                           q.cap, qstate, &ctl.status);
-        if (lane == 0) ctl.u0 = n;
-      }
-      __syncthreads();
-      plen = ctl.u0;
-      // restore dist = +inf and the queue flags on everything the search touched
-      const uint32_t nt = ctl.n_touched < q.cap ? ctl.n_touched : q.cap;
-      for (uint32_t i = tid; i < nt; i += nthr) {
-        const uint32_t v = q.touched[i];
-        st_f32_l2(&dist[v], KH_INF);
-        qstate[v] = 0;
-      }
-      __syncthreads();
-      if (plen == 0) break;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (soma) {
-      // trace.py:246-251: path = concat(path[:1], path[dist_to_soma_root > soma_radius]) -- path[0] is kept
-      // unconditionally AND again if it passes the test itself (the reference duplicates it then).  The
-      // distance is float64 like numpy's (float32 anisotropy * int64 offsets -> float64, norm in float64).
-      uint32_t* tmp = q.touched;  // free between searches; capacity >= Nf + 64 > plen + 1
-      if (wave == 0) {
-        const uint32_t sxu = (uint32_t)ctl.g.sx, sxy = (uint32_t)ctl.g.sxy;
-        const uint32_t rz = root / sxy, rr = root - rz * sxy, ry = rr / sxu, rx = rr - ry * sxu;
-        const double sr = (double)task->soma_radius;
-        uint32_t kept = 1;
-        if (lane == 0) tmp[0] = out[0];
-        for (uint32_t b0 = 0; b0 < plen; b0 += 64) {
-          const uint32_t i = b0 + lane;
-          bool keep = false;
-          uint32_t v = 0;
-          if (i < plen) {
-            v = out[i];
-            const uint32_t z = v / sxy, r = v - z * sxy, y = r / sxu, x = r - y * sxu;
-            const double ax = (double)ctl.g.wx * (double)((long long)x - (long long)rx);
-            const double ay = (double)ctl.g.wy * (double)((long long)y - (long long)ry);
-            const double az = (double)ctl.g.wz * (double)((long long)z - (long long)rz);
-            const double d = sqrt(ax * ax + ay * ay + az * az);
-            keep = d > sr;
-          }
-          const unsigned long long m = __ballot(keep);
-          if (keep) tmp[kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
-          kept += (uint32_t)__popcll(m);
+    if (gs.nghost > 0 && (valid == 0 || paranoid)) rollback = true;   // nothing certainly valid is left, but ghosts are
+    if (!rollback && !redo) {
+      if (!(valid > 0 || nb > 0 || na > 0)) break;
+      // ---- target selection, trace.py:225-230
+      t0 = clock64();
+      uint32_t target;
+      if (nb > 0) { nb--; target = implicit ? task->max_loc : before[nb]; }
+      else if (valid == 0) { na--; target = after[na]; }
+      else {
+        // CachedTargetFinder.find_target: the valid voxel with the largest DAF (ties: largest index)
+        unsigned long long best = 0;
+        for (uint32_t i = tid; i < nf; i += nthr) {
+          const uint32_t v = list[i];
+          if (!alive[v]) continue;
+          const unsigned long long key = ((unsigned long long)__float_as_uint(ldaf[i]) << 32) | v;
+          if (key >= best) best = key;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (kept > pcap - nverts) { if (lane == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW); kept = 0; }
-        for (uint32_t i = lane; i < kept; i += 64) out[i] = tmp[i];
-        if (lane == 0) ctl.u0 = kept;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long ob = __shfl_xor(best, o);
+          if (ob > best) best = ob;
+        }
+        if (lane == 0) ctl.red64[wave] = best;
+        __syncthreads();
+        best = ctl.red64[0];
+        for (int i = 1; i < nwav; i++) if (ctl.red64[i] > best) best = ctl.red64[i];
+        target = (uint32_t)best;
+        __syncthreads();
+        if (gs.nghost > 0 && alive[target] == SW_GHOST) rollback = true;   // a ghost could be the target: its status decides
+      }
+      if (!rollback) {
+      // ---- railroad, trace.py:240-242
+      t_target += clock64() - t0; t0 = clock64();
+      if (nverts >= pcap || npaths >= pcap) {
+        if (tid == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW);
+        __syncthreads();
+        break;
+      }
+      if (!fix_branching) {
+        // dijkstra3d.path_from_parents (trace.py:244): walk target -> root, return root -> target
+        if (tid == 0) ctl.u0 = 0;
+        __syncthreads();
+        if (wave == 0) {
+          const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, q.a, q.b, q.cap,
+                                              qstate, &ctl.status);
+          for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
+          if (lane == 0) ctl.u0 = n;
+        }
+        __syncthreads();
+        plen = ctl.u0;
+        if (plen == 0) break;
+      } else if (pdrf[target] == 0.0f) {
+        if (tid == 0) out[0] = target;
+        plen = 1;
+      } else {
+        sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f);
+        const unsigned long long br = ctl.best_rail;
+        if (tid == 0) { ctl.u0 = 0; ctl.u2 += ctl.n_touched; }
+        __syncthreads();
+        if (br == NONE64) {
+          if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
+        } else if (wave == 0) {
+          const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, q.a, q.b,
+                                             q.cap, qstate, &ctl.status);
+          if (lane == 0) ctl.u0 = n;
+        }
+        __syncthreads();
+        plen = ctl.u0;
+        // restore dist = +inf and the queue flags on everything the search touched
+        const uint32_t nt = ctl.n_touched < q.cap ? ctl.n_touched : q.cap;
+        for (uint32_t i = tid; i < nt; i += nthr) {
+          const uint32_t v = q.touched[i];
+          st_f32_l2(&dist[v], KH_INF);
+          qstate[v] = 0;
+        }
+        __syncthreads();
+        if (plen == 0) break;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
-      plen = ctl.u0;
-      __syncthreads();
-      if (plen == 0) break;
+      if (soma) {
+        // trace.py:246-251: path = concat(path[:1], path[dist_to_soma_root > soma_radius]) -- path[0] is kept
+        // unconditionally AND again if it passes the test itself (the reference duplicates it then).  The
+        // distance is float64 like numpy's (float32 anisotropy * int64 offsets -> float64, norm in float64).
+        uint32_t* tmp = q.touched;  // free between searches; capacity >= Nf + 64 > plen + 1
+        if (wave == 0) {
+          const uint32_t sxu = (uint32_t)ctl.g.sx, sxy = (uint32_t)ctl.g.sxy;
+          const uint32_t rz = root / sxy, rr = root - rz * sxy, ry = rr / sxu, rx = rr - ry * sxu;
+          const double sr = (double)task->soma_radius;
+          uint32_t kept = 1;
+          if (lane == 0) tmp[0] = out[0];
+          for (uint32_t b0 = 0; b0 < plen; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            bool keep = false;
+            uint32_t v = 0;
+            if (i < plen) {
+              v = out[i];
+              const uint32_t z = v / sxy, r = v - z * sxy, y = r / sxu, x = r - y * sxu;
+              const double ax = (double)ctl.g.wx * (double)((long long)x - (long long)rx);
+              const double ay = (double)ctl.g.wy * (double)((long long)y - (long long)ry);
+              const double az = (double)ctl.g.wz * (double)((long long)z - (long long)rz);
+              const double d = sqrt(ax * ax + ay * ay + az * az);
+              keep = d > sr;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) tmp[kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+            kept += (uint32_t)__popcll(m);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (kept > pcap - nverts) { if (lane == 0) atomicOr(&ctl.status, KH_ST_PATH_OVERFLOW); kept = 0; }
+          for (uint32_t i = lane; i < kept; i += 64) out[i] = tmp[i];
+          if (lane == 0) ctl.u0 = kept;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        plen = ctl.u0;
+        __syncthreads();
+        if (plen == 0) break;
+      }
+      t_rail += clock64() - t0;
+      }
+    } else if (!rollback) {
+      plen = __hip_atomic_load(&plens[npaths], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the path whose invalidation is redone
     }
     // ---- invalidation, trace.py:253-259
-    t_rail += clock64() - t0; t0 = clock64();
-    if (valid > 0)
-      valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap, list, nf,
-                                            sweep_stats, sg.heap_prio);
-    // ---- rails, trace.py:261-263
+    t0 = clock64();
+    if (!rollback && valid > 0) {
+      if (gs.nghost == 0) {           // (the state a roll-back returns to, should this call make the first ghost)
+        gs.jpos = 0; gs.paths = npaths; gs.verts = nverts; gs.valid = valid; gs.nb = nb; gs.na = na;
+      }
+      const bool go_ghost = ghosts_on && !redo;
+      const uint32_t killed = invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap,
+                                                          list, nf, sweep_stats, sg.heap_prio, go_ghost ? journal + gs.jpos : q.a,
+                                                          go_ghost, redo, gs.nghost == 0);
+      if (ctl.u0 != 0u) {
+        rollback = true;                                   // the sweep abandoned the call while ghosts exist
+      } else {
+        const uint32_t made = swsh.nghost, gkilled = swsh.nkg;
+        valid -= killed + made;                            // the voxels that are certainly valid
+        if (go_ghost) {
+          gs.nghost += made;
+          gs.nghost -= gkilled;
+          gs.jpos = gs.nghost ? gs.jpos + killed + gkilled + made : 0u;
+          if (made) n_ghost_calls++;
+        }
+      }
+      __syncthreads();                                     // (swsh / ctl are rewritten by the next call)
+    }
     t_inval += clock64() - t0;
-    if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) pdrf[out[i]] = 0.0f;
+    if (rollback) {
+      // every voxel the journal holds is alive again, the rails of the later paths get their weights back
+      for (uint32_t i = tid; i < gs.jpos; i += nthr) {
+        const uint32_t v = journal[i];
+        alive[v] = 1;
+        if (sg.sched != nullptr) sg.sched[v] = SW_SCHED_NONE;
+      }
+      const uint32_t keep = gs.verts + __hip_atomic_load(&plens[gs.paths], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the path of the call being redone stays a rail
+      if (fix_branching) for (uint32_t i = keep + tid; i < nverts; i += nthr) { const float w = psave[i]; if (w != 0.0f) pdrf[pverts[i]] = w; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      npaths = gs.paths; nverts = gs.verts; valid = gs.valid; nb = gs.nb; na = gs.na;
+      gs.nghost = 0; gs.jpos = 0;
+      n_rollbacks++;
+      redo = true;
+      continue;
+    }
+    redo = false;
+    // ---- rails, trace.py:261-263
+    if (fix_branching) for (uint32_t i = tid; i < plen; i += nthr) {
+      const uint32_t v = out[i];
+      if (psave) psave[nverts + i] = pdrf[v];
+      pdrf[v] = 0.0f;
+    }
     if (tid == 0) plens[npaths] = plen;
     npaths++;
     nverts += plen;
@@ -1087,6 +1192,8 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     task->stat_sweep_levels = sweep_stats[2];
     task->stat_sweep_events = sweep_stats[3];
     task->stat_sweep_why = sweep_stats[4];
+    task->stat_ghost_calls = n_ghost_calls;
+    task->stat_rollbacks = n_rollbacks;
   }
 }
 
@@ -1115,11 +1222,14 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
   if (tid == 0) {
     ctl.status = 0; ctl.u1 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top);
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top, corner_gate);
   }
   __syncthreads();
+  for (uint32_t i = tid; i < sw.spcap; i += blockDim.x) { sw.spk[i] = 0u; sw.spc[i] = 0ull; }   // (the arena is uninitialised memory)
+  __syncthreads();
   const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
-                                               lists + task->list_offset, nf, sweep_stats, sg.heap_prio, corner_gate);
+                                               lists + task->list_offset, nf, sweep_stats, sg.heap_prio,
+                                               queues + (uint64_t)task->q_offset * 4, false, false, true, corner_gate);
   if (tid == 0) {
     *invalidated = (long long)c;
     task->status |= ctl.status;
@@ -1254,7 +1364,8 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
-                        int fix_branching, const SweepGlobal& sg, uint32_t max_nlev, unsigned nthreads) {
+                        int fix_branching, const SweepGlobal& sg, uint32_t max_nlev, unsigned nthreads, uint32_t* journal,
+                        float* rail_save, uint32_t ghost_mode) {
   if (count <= 0) return KH_OK;
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
@@ -1269,7 +1380,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
   }
   hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                     path_lengths, fix_branching, sg);
+                     path_lengths, fix_branching, sg, journal, rail_save, ghost_mode);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -1306,13 +1417,15 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
                               void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                               const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
-                              uint64_t* cstate, uint32_t* sched, void* event_arena, int flags, int fix_branching, void* stream) {
+                              uint64_t* cstate, uint32_t* sched, void* event_arena, uint32_t* journal, float* rail_save,
+                              int flags, int fix_branching, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
-  if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128)) ||
+  if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128 | KH_TRACE_NO_GHOSTS |
+                 KH_TRACE_GHOST_PARANOID)) ||
       ((flags & KH_TRACE_THREADS_64) && (flags & KH_TRACE_THREADS_128))) {
     set_error("kh_trace_paths: unknown flags");
     return KH_EINVAL;
@@ -1335,12 +1448,14 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   sg.heap_prio = (flags & KH_TRACE_HEAP_PRIO) ? 1u : 0u;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
+  // ghosts need the journal (and, with rails, the saved weights); bit 1: roll every ghost call back at once
+  const uint32_t ghost_mode = (journal && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u);
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                    scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                   (uint32_t)max_nlev, nthreads)
+                                   (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode)
               : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                     scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                    (uint32_t)max_nlev, nthreads);
+                                    (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode);
 }
 
 extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,

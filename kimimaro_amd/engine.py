@@ -72,6 +72,19 @@ def plan_arena(cnt, nlev, filtered, window=None):
     return shift, chunks
 
 
+def plan_spill(cnt):
+    """entries (a power of two) of the sweep's candidate-spill table per label (csrc/sweep.h: the fifth to eighth possible
+    owner of a voxel; 12 bytes per entry at the front of the label's arena).  Few voxels ever need one -- five in the label
+    of c3 whose longest call used to be abandoned for them -- so the table is small: Nf / 64, between 256 and 16384 entries."""
+    cnt = np.maximum(np.asarray(cnt, dtype=np.int64), 1)
+    return np.clip(2 ** np.ceil(np.log2(cnt / 64.0)).astype(np.int64), 256, 16384)
+
+
+def arena_units(chunks, shift, spill):
+    """256-byte units of a label's arena: [spill table: 12 B per entry][free stack: 4 B per chunk][chunks of 8-byte slots]"""
+    return (spill * 12 + 255) // 256 + (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256
+
+
 def level_windows(keys, anisotropy, nlev, lds_levels):
     """kh_label_t.lev_window per label (numpy u32): a power of two above the number of levels an event can lie ahead of the
     level being processed, or 0 when that does not fit `lds_levels` words.  An event's key is the distance of a 26-neighbour
@@ -108,6 +121,10 @@ class Engine:
         self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
+        # ghosts: a call of the sweep that leaves voxels undecided goes on with them as ghosts instead of running
+        # the heap emulation at once; "paranoid" rolls every such call back at once (a test of the roll-back; results identical)
+        self.ghosts = os.environ.get("KH_GHOSTS", "1") != "0"
+        self.ghost_paranoid = os.environ.get("KH_GHOSTS", "1") == "paranoid"
         # threads per label in the path loop (64, 128 or 256).  256 serves one volume best (its searches are 4 x as wide);
         # with volumes in flight 64 does: a label whose call runs on the heap emulation -- one wave for seconds -- then holds a
         # twelfth of a CU instead of a third, and the sweep's levels hold tens of events, not hundreds (kimimaro_amd.lanes
@@ -360,8 +377,10 @@ class Engine:
                 win = int(level_windows(keys, anisotropy, [nlev], self.sweep_lds_levels)[0]) if self.sweep_window else 0
                 shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter, win))
                 in_lds = win > 0 or nlev <= self.sweep_lds_levels       # else: heap emulation only (the kernel decides the same)
-                ev_units = (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256   # free stack, chunks
+                spill = int(plan_spill(cnt))
+                ev_units = int(arena_units(chunks, shift, spill))   # spill table, free stack, chunks
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
+                task["ev_spill"] = spill
                 task["lev_window"] = win
                 max_nlev = win if win > 0 else (nlev if in_lds else 0)
             else:
@@ -422,7 +441,7 @@ class Engine:
             # more per-label scratch than the budget: several launches, each over a group of labels that fits
             groups = plan_launches(counts, self.scratch_budget)
             if len(groups) > 1:
-                done = []
+                done, retried = [], 0
                 pick_list = lambda a, g: [a[i] for i in g] if a is not None else None
                 for g in groups:
                     g = np.asarray(g, dtype=np.int64)
@@ -434,7 +453,9 @@ class Engine:
                                     timings=timings, soma=sub_soma, consume=consume,
                                     scratch_scale=scratch_scale)
                     done.append(self.last_tasks)
+                    retried += self.last_retries
                 self.last_tasks = np.concatenate(done)
+                self.last_retries = retried           # (each nested call resets it: accumulate over the groups)
                 return None
         order = np.argsort(-counts, kind="stable")  # big labels first: their workgroups start first
         slot_of_label = -np.ones(nlabels + 1, dtype=np.int32)
@@ -499,8 +520,9 @@ class Engine:
                 shift, chunks = plan_arena(cnt, nlev, self.sweep_filter, win)
                 chunks = np.maximum(chunks // int(self.arena_divisor), 8)
                 in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)   # the others: heap emulation only (the kernel decides the same)
-                # [free stack, 4 B per chunk][chunks]
-                units = np.where((nlev > 0) & in_lds, (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256, 0)
+                # [spill table, 12 B per entry][free stack, 4 B per chunk][chunks]
+                spill = plan_spill(cnt)
+                units = np.where((nlev > 0) & in_lds, arena_units(chunks, shift, spill), 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
                 ev_total = int(units.sum())
                 self.last_arena_bytes = ev_total * 256
@@ -511,6 +533,7 @@ class Engine:
                 tasks["ev_offset"] = ev_off
                 tasks["ev_chunks"] = np.where(nlev > 0, chunks, 0)
                 tasks["ev_shift"] = shift
+                tasks["ev_spill"] = np.where((nlev > 0) & in_lds, spill, 0)
                 if int(nlev.max()) == 0:
                     d_rank = None
                 tasks["lev_window"] = win
@@ -594,11 +617,20 @@ class Engine:
         arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
+        # ghosts: the journal of the voxels that changed since the call that made the first ghost (2 entries per voxel of a
+        # label at most: made a ghost, killed) and the weights the path vertices had before they became rails
+        use_ghosts = self.ghosts and d_rank is not None
+        d_journal = self.empty(2 * int(qcap.sum()), t.int32) if use_ghosts else None
+        d_psave = self.empty(int(pcap.sum()), t.float32) if use_ghosts and fix_branching else None
+        if use_ghosts and not fix_branching:
+            d_psave = None
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
         # are consumed incrementally they go to a second stream and the others are collected while they still run
         n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
         # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 / _128
-        prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0)
+        # ... | KH_TRACE_NO_GHOSTS | KH_TRACE_GHOST_PARANOID
+        prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0) | \
+            (0 if use_ghosts else 16) | (32 if use_ghosts and self.ghost_paranoid else 0)
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
 
         def launch(first, count, stream):
@@ -607,7 +639,8 @@ class Engine:
                                           P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
-                                          P(d_cstate), self.optr(d_sched), arena_ptr, prof, int(bool(fix_branching)), stream))
+                                          P(d_cstate), self.optr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
+                                          prof, int(bool(fix_branching)), stream))
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""

@@ -78,6 +78,12 @@ class Lanes:
         self.engines = [engine_factory() for _ in range(self.width)]
         self._scopes = [stream_factory(e) if stream_factory is not None else None for e in self.engines]
 
+    def close(self):
+        """drop the lanes' engines AND their stream scopes (each scope holds its engine and HIP stream: clearing `engines`
+        alone frees nothing), so that their scratch goes back to the allocator"""
+        self.engines = []
+        self._scopes = []
+
     def run(self, job, n, width=None, stagger=0.0):
         """Generator over (k, job(engine, k)) for k = 0..n-1, in order, with at most `width` jobs in flight.  An exception
         of job k is raised when k is reached (later jobs may have run).
@@ -206,7 +212,7 @@ def skeletonize_many(volumes, teasar_params=None, lanes=None, width=None, **kwar
         yield from lanes.run(job, n)
     finally:
         if own:
-            lanes.engines = []
+            lanes.close()
 
 
 class _StreamScope:

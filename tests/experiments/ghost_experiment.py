@@ -10,9 +10,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, oracle as K
 from oracle import pipeline as P
 import bench
-cert = C.CDLL(os.path.join(ROOT, "tests", "experiments", "cert_ball4.so"))
-cert.cert_ball4.restype = C.c_int64
-cert.cert_ball4.argtypes = [C.c_void_p] + [C.c_int64] * 3 + [C.c_float] * 3 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+CERT = os.environ.get("CERT_LIB", "cert_ball4")     # cert_ball5 = + candidate spill
+cert = C.CDLL(os.path.join(ROOT, "tests", "experiments", CERT + ".so"))
+cert_fn = getattr(cert, CERT)
+cert_fn.restype = C.c_int64
+cert_fn.argtypes = [C.c_void_p] + [C.c_int64] * 3 + [C.c_float] * 3 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
 orig = K.roll_invalidation_ball_inside_component
 state = dict(amask=None, ahead=0, need_exact=0, calls=0, ghost_calls=0, ghosts_made=0, unsound=0, hard_bail=0)
 def hooked(labels, DBF, scale, const, anisotropy, path, return_stats=False):
@@ -26,7 +28,7 @@ def hooked(labels, DBF, scale, const, anisotropy, path, return_stats=False):
     radii = np.empty(locs.size, dtype=np.float32)
     K.lib().ko_ball_radii(DBF.ctypes.data_as(C.c_void_p), locs.ctypes.data_as(C.c_void_p), locs.size, np.float32(scale), np.float32(const), radii.ctypes.data_as(C.c_void_p))
     st = np.zeros(8, dtype=np.int64)
-    c = cert.cert_ball4(am.ctypes.data_as(C.c_void_p), sx, sy, sz, float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]),
+    c = cert_fn(am.ctypes.data_as(C.c_void_p), sx, sy, sz, float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]),
                         locs.ctypes.data_as(C.c_void_p), radii.ctypes.data_as(C.c_void_p), locs.size, st.ctypes.data_as(C.c_void_p))
     out = orig(labels, DBF, scale, const, anisotropy, path, return_stats=True)
     state['calls'] += 1
@@ -35,6 +37,7 @@ def hooked(labels, DBF, scale, const, anisotropy, path, return_stats=False):
         am[...] = lab     # resynchronise
     else:
         if st[4] > 0: state['ghost_calls'] += 1; state['ghosts_made'] += int(st[4])
+        if CERT != 'cert_ball4': state['spills'] = state.get('spills', 0) + int(st[6]); state['ovf'] = state.get('ovf', 0) + int(st[7])
         if np.any((am == 0) & (lab != 0)) or np.any((am == 1) & (lab == 0)): state['unsound'] += 1
     return out if return_stats else out[:2]
 K.roll_invalidation_ball_inside_component = hooked
@@ -68,7 +71,7 @@ for sid in order[first:first + maxl]:
     dbf = K.edt(crop, an, black_border=False)
     mask = crop == sid
     dbf = np.where(mask, dbf, 0.0).astype(np.float32)
-    state.update(amask=None, ahead=0, need_exact=0, calls=0, ghost_calls=0, ghosts_made=0, unsound=0, hard_bail=0)
+    state.update(amask=None, ahead=0, need_exact=0, calls=0, ghost_calls=0, ghosts_made=0, unsound=0, hard_bail=0, spills=0, ovf=0)
     paths = P.trace(mask, dbf, anisotropy=an, fix_branching=True, return_paths=True, **P.DEFAULT_TEASAR_PARAMS)
     endg = int(np.count_nonzero(state['amask'] == 3)) if state['amask'] is not None else 0
     if endg: state['need_exact'] = 1; tot['end_ghost_labels'] += 1
@@ -76,7 +79,7 @@ for sid in order[first:first + maxl]:
     tot['ghosts'] += state['ghosts_made']; tot['unsound'] += state['unsound']; tot['hard'] += state['hard_bail']
     if state['ghosts_made']: tot['ghost_labels'] += 1; tot['ghost_vox'] += int(counts[sid])
     if state['need_exact']: tot['exact_labels'] += 1; tot['exact_vox'] += int(counts[sid])
-    if state['ghosts_made'] or state['need_exact']:
-        print("label", sid, "vox", int(counts[sid]), "calls", state['calls'], "ghost calls", state['ghost_calls'], "ghosts", state['ghosts_made'], "end ghosts", endg, "need exact", state['need_exact'], flush=True)
+    if state['ghosts_made'] or state['need_exact'] or state.get('spills'):
+        print("label", sid, "vox", int(counts[sid]), "calls", state['calls'], "ghost calls", state['ghost_calls'], "ghosts", state['ghosts_made'], "end ghosts", endg, "need exact", state['need_exact'], "spills", state.get('spills', 0), "ovf voxels", state.get('ovf', 0), flush=True)
     if tot['labels'] % 20 == 0: print(tot, flush=True)
 print(tot)

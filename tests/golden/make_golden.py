@@ -594,6 +594,50 @@ def gen_ball_graph(st):
         cases["count_%d" % n] = np.array(cnt)
         cases["after_%d" % n] = np.packbits(m.ravel(order="F"))
         n += 1
+    # Round 5: cases in which a voxel is reached ONLY through a corner entry that degenerated into a yz diagonal at an x face of
+    # the array (dijkstra_invalidation.hpp:116-123), which the graph gates by the CORNER's bit (:182-190) although the diagonal's
+    # own bit is clear.  First the hand-derived one (shape (1, 2, 2), one allowed corner: the reference invalidates 2 voxels), then
+    # thin slabs (sx = 1..3: every voxel on an x face) whose graphs have all four yz-diagonal bits cleared everywhere.
+    rng2 = np.random.default_rng(20260928)
+    yz_diag = sum(1 << b for b in (17, 13, 16, 12))
+    for t in range(13):
+        if t == 0:
+            shape, an = (1, 2, 2), (1, 1, 1)
+            m = np.ones(shape, np.uint8, order="F")
+            vcg = np.zeros(shape, np.uint32, order="F")
+            vcg[0, 0, 0] = 1 << 18
+            path = np.array([[0, 0, 0]])
+            dbf = np.full(shape, 10.0, np.float32, order="F")
+            scale, const = 1.0, 0.0
+        else:
+            shape = (int(rng2.integers(1, 4)), int(rng2.integers(4, 12)), int(rng2.integers(4, 12)))
+            an = [(1, 1, 1), (16, 16, 40), (4, 4, 40), (1, 2, 3)][t % 4]
+            m = np.asfortranarray((rng2.random(shape) < 0.9).astype(np.uint8))
+            dbf = edt_like(m, an, rng2)
+            vcg = np.full(shape, (1 << 26) - 1, dtype=np.uint32, order="F") & np.uint32(~yz_diag & 0xFFFFFFFF)
+            drop = [0.3, 0.6, 0.8][t % 3]
+            for b in range(18):                              # faces and edges mostly closed, corners stay open
+                vcg &= ~(np.asfortranarray(rng2.random(shape) < drop).astype(np.uint32) << np.uint32(b))
+            for b in range(18, 26):
+                vcg &= ~(np.asfortranarray(rng2.random(shape) < 0.15).astype(np.uint32) << np.uint32(b))
+            idx = np.flatnonzero(m.ravel(order="F"))
+            sel = rng2.choice(idx, min(int(rng2.integers(1, 4)), idx.size), replace=False)
+            sx, sy = shape[0], shape[1]
+            path = np.stack([sel % sx, (sel // sx) % sy, sel // (sx * sy)], axis=1)
+            scale, const = [4.0, 8.0][t % 2], 6.0 * max(an)
+        before = m.copy(order="F")
+        cnt, _ = st.roll_invalidation_ball_inside_component(
+            m, dbf, scale, const, an, [tuple(int(v) for v in p) for p in path], voxel_connectivity_graph=vcg)
+        cases["shape_%d" % n] = np.array(shape)
+        cases["an_%d" % n] = np.array(an, np.float32)
+        cases["mask_%d" % n] = np.packbits(before.ravel(order="F"))
+        cases["graph_%d" % n] = vcg.ravel(order="F").copy()
+        cases["path_%d" % n] = path.astype(np.int32)
+        cases["dbfpath_%d" % n] = dbf[path[:, 0], path[:, 1], path[:, 2]].astype(np.float32)
+        cases["sc_%d" % n] = np.array([scale, const], np.float32)
+        cases["count_%d" % n] = np.array(cnt)
+        cases["after_%d" % n] = np.packbits(m.ravel(order="F"))
+        n += 1
     cases["n"] = np.array(n)
     np.savez_compressed(os.path.join(HERE, "invalidation_ball_graph.npz"), **cases)
     print("invalidation_ball_graph:", n)

@@ -94,6 +94,35 @@ def test_c2_full_size_every_skeleton(eng, c2):
         _same(got[k], want[k], k)
 
 
+@pytest.mark.parametrize("mode", ["ghosts", "paranoid", "off"])
+def test_c2_ghost_modes_every_skeleton(c2, mode):
+    """DESIGN.md 3.4.6 at full size: c2 traced with ghosts (the default: a call of the sweep that leaves voxels undecided goes on
+    with them as ghosts, the label rolls back only when a ghost would matter), with every ghost call rolled back at once (the
+    roll-back path itself: journal revival, rail weights restored, the call redone by the heap emulation) and with ghosts off
+    (rounds 2-4) -- all three equal to the pooled oracle, skeleton by skeleton.  The counters prove the paths ran."""
+    import kimimaro_amd
+    from kimimaro_amd.engine import Engine
+    lab, an, params, want, _, _ = c2
+    e = Engine()
+    e.ghosts = mode != "off"
+    e.ghost_paranoid = mode == "paranoid"
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=1000, fix_borders=True, fix_branching=True,
+                                   progress=False, _engine=e)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        _same(got[k], want[k], k)
+    tk = e.last_tasks
+    ghost_calls, rollbacks = int(tk["stat_ghost_calls"].sum()), int(tk["stat_rollbacks"].sum())
+    bails = int(tk["stat_sweep_bails"].sum())
+    if mode == "off":
+        assert ghost_calls == 0 and rollbacks == 0 and bails > 0
+    elif mode == "paranoid":
+        assert ghost_calls > 0 and 0 < rollbacks <= ghost_calls
+    else:
+        assert ghost_calls > 0 and rollbacks <= ghost_calls   # (most ghosts are killed for certain by a later ball)
+    print("c2 %s: ghost calls %d, roll-backs %d, calls redone by the heap %d" % (mode, ghost_calls, rollbacks, bails))
+
+
 def test_c2_sharded_over_two_ranks(eng, c2):
     from kimimaro_amd.intake import shard_components
     lab, an, params, want, cc, counts = c2
