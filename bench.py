@@ -32,9 +32,12 @@ ms_per_step = wall / K.  The latency of a single volume on an otherwise idle GPU
 engine: what kimimaro_amd.skeletonize() does) and printed as single_volume_ms; --inflight 1 times the steps one after the other.
 
 Extra objects on the JSON line:
-  roofline      EDT pass kernel (the kernel BASELINE.json's metric names): algorithmic bytes / the
-                pass duration measured with HIP events on the launch stream (kh_edt_timed).
-  roofline_trace  the per-label path kernel (where the wall clock goes): SURVEY 8d per-label bytes.
+  roofline      the DOMINANT kernel, trace_paths_kernel (97 % of the GPU time): SURVEY 8d per-label algorithmic bytes of one
+                volume / the longest of the volume's (overlapped) path-loop launches, HIP events on each launch's own stream;
+                `traffic` from the newest committed rocprofv3 --pmc pass (marked STALE when it predates this round's kernels).
+  roofline_edt  EDT pass kernels (the kernel BASELINE.json's metric names): algorithmic bytes / the pass durations measured
+                with HIP events on the launch stream (kh_edt_timed); edt_total_GBps = (3L + 20) B/voxel over the three passes.
+  value_single_volume  components / single_volume_ms: the rate of ONE volume alone on the GPU (`value` is the pipelined rate).
   cpu_baseline  the oracle (CPU restatement, 1 core) on a bounded sample of the same labels.
   cpu_baseline_all_cores  the same work on a process pool over every USABLE host core (affinity and cgroup quota are
                 printed: the pool's 256-core boxes grant 16), components largest first, in two legs -- `latency`: one
@@ -490,6 +493,7 @@ def main():
                                   params, an, dust, True, fix_borders, empty, empty, black_border=False, d_cc=i_cc, timings=timings)
             tk = ieng.last_tasks
             state["retries"] = getattr(ieng, "last_retries", 0)
+            state["path_kernel_ms"] = list(getattr(ieng, "last_path_kernel_ms", []))
             del i_cc
     lanes = None
     torch.cuda.empty_cache()
@@ -549,9 +553,9 @@ def main():
         hit = [v for name, v in kern.items() if tag in name]
         if hit:
             traffic = hit[0]["hbm_bytes_corrected"]
-    roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline_edt = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/%s (PMC pass, not live)" % os.path.basename(pmc) if traffic else None,
+                "traffic_source": "profiles/%s (rocprofv3 --pmc pass of an earlier run of the same kernels: edt.hip is unchanged since; not live)" % os.path.basename(pmc) if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
@@ -570,7 +574,11 @@ def main():
     tr_s = phases.get("paths", float("nan"))
     calls = int(tk["stat_sweep_calls"].astype(np.int64).sum())
     bails = int(tk["stat_sweep_bails"].astype(np.int64).sum())
+    ghost_calls = int(tk["stat_ghost_calls"].astype(np.int64).sum())
+    rollbacks = int(tk["stat_rollbacks"].astype(np.int64).sum())
     sweep = {"invalidation_calls": calls, "certified": calls - bails, "fell_back_to_heap": bails,
+             "calls_that_went_on_with_ghosts": ghost_calls, "rollbacks": rollbacks,
+             "labels_with_ghosts": int(np.count_nonzero(tk["stat_ghost_calls"])),
              "levels": int(tk["stat_sweep_levels"].astype(np.int64).sum()), "events": int(tk["stat_sweep_events"].astype(np.int64).sum()),
              "labels_with_fallback": int(np.count_nonzero(tk["stat_sweep_bails"])),
              "voxels_of_labels_with_fallback": int(tk["count"][tk["stat_sweep_bails"] > 0].astype(np.int64).sum()),
@@ -579,19 +587,29 @@ def main():
     # HBM traffic of that kernel from the committed counter passes (tools/pmc_trace_r3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs over one c3 volume, FETCH x 2 on gfx950): only valid for c3
     tr_traffic, tr_src = None, None
-    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_c3_trace_pmc.json", "r03_c3_trace_pmc.json"))
-                 if os.path.exists(q)), "")
+    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_c3_trace_pmc.json", "r04_c3_trace_pmc.json",
+                                                                         "r03_c3_trace_pmc.json")) if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(tpmc):
         for name, v in json.load(open(tpmc))["kernels"].items():
             if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected_per_volume"):
                 tr_traffic = v["hbm_bytes_corrected_per_volume"]
-                tr_src = "profiles/%s (PMC passes over one volume, not live; all path-kernel launches of the volume)" % os.path.basename(tpmc)
-    roofline_trace = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / tr_s / 1e9, 3),
-                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / tr_s / 1e9 / HBM_PEAK_GBS, 6),
-                      "traffic": tr_traffic, "traffic_source": tr_src, "bytes_per_launch": int(trace_bytes),
-                      "seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
-                      "note": "latency bound: level-synchronous sweep per label; the wall clock is the largest label whose call "
-                              "needed the exact heap emulation"}
+                stale = "" if "r05_" in os.path.basename(tpmc) else "; STALE: measured on the round-4 kernels"
+                tr_src = ("profiles/%s (rocprofv3 --pmc passes over one volume, all path-kernel launches of the volume; not live%s)"
+                          % (os.path.basename(tpmc), stale))
+    # the dominant kernel (97 % of the GPU time): its launches of ONE volume overlap on two streams (the largest labels on the
+    # second one), so the duration that counts is the span of the path phase; the HIP events of each launch are listed beside it
+    kms = state.get("path_kernel_ms") or []
+    span_s = max([m for _, m in kms], default=float("nan")) / 1e3 if kms else tr_s
+    roofline = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / span_s / 1e9, 3),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / span_s / 1e9 / HBM_PEAK_GBS, 6),
+                "traffic": tr_traffic, "traffic_source": tr_src, "bytes_per_launch": int(trace_bytes),
+                "ms_per_launch": round(span_s * 1e3, 3),
+                "launches": [{"labels": int(c), "ms": round(float(m), 3)} for c, m in kms],
+                "launch_note": "algorithmic bytes of ONE volume (SURVEY 8d, all its labels) / the longest of the volume's overlapped "
+                               "path-loop launches, HIP events on each launch's own stream (one volume alone on the GPU)",
+                "phase_seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
+                "note": "latency bound: level-synchronous sweep per label; the wall clock is the largest label whose call "
+                        "needed the exact heap emulation"}
 
     # the labels whose chains set the wall clock of the path kernel (clock64 ticks / 1024 per phase, solo pass)
     tot = tk["cyc_target"].astype(np.int64) + tk["cyc_rail"].astype(np.int64) + tk["cyc_inval"].astype(np.int64)
@@ -622,6 +640,8 @@ def main():
                 # the pool is throughput bound (245 components/s for one volume, 248 for four, 247 for eight at once on the
                 # 16-CPU cgroup of the pool's boxes): four volumes' worth is the bounded sample of the throughput leg
                 cpu_all = cpu_baseline_all_cores(cc_labels, an, params, dust, cpu["value"], volumes_in_flight=min(inflight, 4))
+                if isinstance(cpu_all, dict):
+                    cpu_all["volumes"] = min(inflight, 4)      # the throughput leg's sample (the pool is saturated from one volume on)
             except Exception as e:
                 cpu_all = {"value": None, "unit": "labels/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         except Exception as e:  # the baseline must never take the bench line down
@@ -640,6 +660,7 @@ def main():
         "value": round(value, 3), "unit": "labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
         "volumes_in_flight": inflight, "single_volume_ms": round(state.get("single_ms", float("nan")), 3),
+        "value_single_volume": round(ncomp / (single_ms / 1e3), 3) if single_ms == single_ms else None,
         "hbm_reserved_peak_gb": round((torch.cuda.max_memory_reserved() + plane["peak"]) / 1e9, 1),
         "lanes": args.lanes if inflight > 1 else "none",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -654,11 +675,13 @@ def main():
                    "volumes_in_flight": inflight},
         "skeletons": nskel, "labels_per_s_by_label_count": round(nskel * (world if args.scaling == "weak" else 1) / (ms_per_step / 1e3), 3),
         "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep, "chains": chain_info, "chains_under_load": loaded,
-        "roofline": roofline, "roofline_trace": roofline_trace, "cpu_baseline": cpu,
+        "roofline": roofline, "roofline_edt": roofline_edt, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
         "speedup_latency": speedup_latency, "speedup_throughput": speedup_throughput,
-        "speedup_note": "latency: components / single_volume_ms vs ONE volume on the all-cores pool; throughput: value (volumes "
-                        "in flight) vs the same number of volumes' components through the same pool at once",
+        "speedup_note": "latency: components / single_volume_ms vs ONE volume on the all-cores pool; throughput: value (%d volumes "
+                        "in flight) vs %d volumes' components through the same pool at once (cpu_baseline_all_cores.volumes: the "
+                        "pool is saturated from one volume on, 245 / 248 / 247 components/s for 1 / 4 / 8 volumes)"
+                        % (inflight, min(inflight, 4)),
     }
     if state.get("rank_times"):
         line["rank_times"] = state["rank_times"]

@@ -113,6 +113,7 @@ class Engine:
         # one process drives one GPU: the library launches on the CURRENT device, so make this engine's device current
         self.torch.cuda.set_device(self.device)
         self.last_tasks = None   # task records (statistics, status) of this engine's most recent run_labels call
+        self.last_path_kernel_ms = []   # (labels, milliseconds) of its path-loop launches when `timings` was asked for (HIP events)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
         self._side = None     # second stream: the biggest labels run there while the others are collected
         self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
@@ -633,14 +634,27 @@ class Engine:
             (0 if use_ghosts else 16) | (32 if use_ghosts and self.ghost_paranoid else 0)
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
 
-        def launch(first, count, stream):
+        kernel_events = []     # (first, count, start, end): HIP events on the stream each path-loop launch went to (timings only)
+
+        def launch(first, count, stream, tstream=None):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
+            if timings is not None:
+                tstream = tstream if tstream is not None else t.cuda.current_stream(self.device)
+                ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+                ev0.record(tstream)
+                kernel_events.append((first, count, ev0, ev1, tstream))
             _abi.check(lib.kh_trace_paths(tasks_ptr, count, P(d_lists), P(d_ldaf), P(d_nbr), sx, sy, sz, wx, wy, wz,
                                           P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
                                           P(d_cstate), self.optr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
                                           prof, int(bool(fix_branching)), stream))
+            if timings is not None:
+                kernel_events[-1][3].record(kernel_events[-1][4])
+
+        def kernel_times():
+            """milliseconds of each path-loop launch of this call, from HIP events on the launch's own stream"""
+            self.last_path_kernel_ms = [(c, e0.elapsed_time(e1)) for _, c, e0, e1, _ in kernel_events]
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
@@ -717,7 +731,7 @@ class Engine:
             if self._side is None:
                 self._side = t.cuda.Stream(device=self.device)
             self._side.wait_stream(cur)
-            launch(0, n_large, C.c_void_p(self._side.cuda_stream))
+            launch(0, n_large, C.c_void_p(self._side.cuda_stream), self._side)
             try:
                 launch(n_large, nl - n_large, st)
                 small = collect(n_large, nl)
@@ -728,12 +742,16 @@ class Engine:
                     self._side.synchronize()
             big = collect(0, n_large)
             mark("paths")
+            if timings is not None:
+                kernel_times()
             consume(big)
             mark("d2h")
             self.last_tasks = splice_retried(np.concatenate([big["tasks"], small["tasks"]]))
             return None
         launch(0, nl, st)
         mark("paths")
+        if timings is not None:
+            kernel_times()
         res = collect(0, nl)
         mark("d2h")
         if consume is not None:

@@ -38,4 +38,4 @@ def test_bench_two_ranks_gloo_dry_run():
     rt = d["rank_times"]
     assert len(rt["own_s_per_step"]) == 2 and len(rt["gather_s_per_step"]) == 2 and min(rt["own_s_per_step"]) > 0
     assert d["weak_scaling"]["scaling"] == "weak" and d["weak_scaling"]["skeletons"] >= 2 * 30   # both ranks' volumes gathered
-    assert d["roofline"]["frac"] > 0 and d["roofline_trace"]["bytes_per_launch"] > 0
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bytes_per_launch"] > 0 and d["roofline_edt"]["frac"] > 0
