@@ -231,6 +231,8 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
 #define KH_TRACE_THREADS_128 8 /* workgroups of 128 threads */
 #define KH_TRACE_NO_GHOSTS 16  /* undecided voxels abandon the call to the heap emulation at once (rounds 2-4) */
 #define KH_TRACE_GHOST_PARANOID 32  /* roll back after every call that made a ghost (tests) */
+#define KH_TRACE_BIG_LDS_HEAP 64    /* two chunks (8191 nodes, 128 KiB) of every label's invalidation heap live in LDS: one workgroup
+                                       per CU, for a launch of the few largest labels whose heap emulation sets the wall clock */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,

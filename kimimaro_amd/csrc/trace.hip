@@ -1359,7 +1359,7 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
 }
 
 namespace kh {
-template <bool PROF>
+template <bool PROF, int TOPL = 1>
 static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
@@ -1367,7 +1367,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         int fix_branching, const SweepGlobal& sg, uint32_t max_nlev, unsigned nthreads, uint32_t* journal,
                         float* rail_save, uint32_t ghost_mode) {
   if (count <= 0) return KH_OK;
-  size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
+  size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (sg.rank && swl > lds) lds = swl;
   {
@@ -1375,10 +1375,10 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
     // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
     // launch can ask for -- so that a concurrent caller never lowers it under somebody else's launch.
     const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
-    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, 1>),
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, TOPL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
-  hipLaunchKernelGGL((trace_paths_kernel<PROF, 1>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
+  hipLaunchKernelGGL((trace_paths_kernel<PROF, TOPL>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
                      path_lengths, fix_branching, sg, journal, rail_save, ghost_mode);
   KH_LAUNCH_CHECK();
@@ -1425,7 +1425,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128 | KH_TRACE_NO_GHOSTS |
-                 KH_TRACE_GHOST_PARANOID)) ||
+                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP)) ||
       ((flags & KH_TRACE_THREADS_64) && (flags & KH_TRACE_THREADS_128))) {
     set_error("kh_trace_paths: unknown flags");
     return KH_EINVAL;
@@ -1450,6 +1450,10 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   // ghosts need the journal (and, with rails, the saved weights); bit 1: roll every ghost call back at once
   const uint32_t ghost_mode = (journal && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u);
+  if (flags & KH_TRACE_BIG_LDS_HEAP)
+    return launch_trace<false, 2>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
+                                  scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
+                                  (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode);
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                    scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
                                    (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode)

@@ -77,7 +77,7 @@ def plan_spill(cnt):
     owner of a voxel; 12 bytes per entry at the front of the label's arena).  Few voxels ever need one -- five in the label
     of c3 whose longest call used to be abandoned for them -- so the table is small: Nf / 64, between 256 and 16384 entries."""
     cnt = np.maximum(np.asarray(cnt, dtype=np.int64), 1)
-    return np.clip(2 ** np.ceil(np.log2(cnt / 64.0)).astype(np.int64), 256, 16384)
+    return 2 ** np.clip(np.ceil(np.log2(cnt / 64.0)), 8, 14).astype(np.int64)
 
 
 def arena_units(chunks, shift, spill):
@@ -126,6 +126,9 @@ class Engine:
         # the heap emulation at once; "paranoid" rolls every such call back at once (a test of the roll-back; results identical)
         self.ghosts = os.environ.get("KH_GHOSTS", "1") != "0"
         self.ghost_paranoid = os.environ.get("KH_GHOSTS", "1") == "paranoid"
+        # the launch of the largest labels (second stream, single-volume mode) keeps two chunks of the invalidation heap in LDS
+        # (128 KiB per workgroup, one workgroup per CU): every pop of a heap emulation saves one of its two L2 round trips
+        self.big_lds_heap = os.environ.get("KH_BIG_LDS_HEAP", "1") != "0"
         # threads per label in the path loop (64, 128 or 256).  256 serves one volume best (its searches are 4 x as wide);
         # with volumes in flight 64 does: a label whose call runs on the heap emulation -- one wave for seconds -- then holds a
         # twelfth of a CU instead of a third, and the sweep's levels hold tens of events, not hundreds (kimimaro_amd.lanes
@@ -636,8 +639,9 @@ class Engine:
 
         kernel_events = []     # (first, count, start, end): HIP events on the stream each path-loop launch went to (timings only)
 
-        def launch(first, count, stream, tstream=None):
+        def launch(first, count, stream, tstream=None, big=False):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
+            flags = prof | (64 if big and self.big_lds_heap and self.trace_threads == 256 else 0)   # KH_TRACE_BIG_LDS_HEAP
             if timings is not None:
                 tstream = tstream if tstream is not None else t.cuda.current_stream(self.device)
                 ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
@@ -648,7 +652,7 @@ class Engine:
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
                                           P(d_cstate), self.optr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
-                                          prof, int(bool(fix_branching)), stream))
+                                          flags, int(bool(fix_branching)), stream))
             if timings is not None:
                 kernel_events[-1][3].record(kernel_events[-1][4])
 
@@ -731,7 +735,7 @@ class Engine:
             if self._side is None:
                 self._side = t.cuda.Stream(device=self.device)
             self._side.wait_stream(cur)
-            launch(0, n_large, C.c_void_p(self._side.cuda_stream), self._side)
+            launch(0, n_large, C.c_void_p(self._side.cuda_stream), self._side, big=True)
             try:
                 launch(n_large, nl - n_large, st)
                 small = collect(n_large, nl)
