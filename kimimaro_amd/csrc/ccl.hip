@@ -8,8 +8,9 @@
 //
 // Lock-free union-find (every parent pointer points to a SMALLER index, so the root of a set is its
 // minimum element, stale reads are harmless and no cycle can form):
-//   init     parent[i] = i (foreground) / NONE (background)
-//   link     every voxel unions itself with its 13 already-rastered same-label neighbours (atomicCAS on roots)
+//   init     parent[i] = first voxel of i's x run inside its 64-lane chunk (foreground) / NONE (background)
+//   link     the unions with the 13 already-rastered same-label neighbours that the labels do not show to be redundant
+//            (atomicCAS on roots)
 //   flatten  parent[i] = root(i)
 //   number   roots are counted per 1024-voxel chunk, the chunk counts are scanned, every root gets
 //            id = 1 + (number of roots before it), every voxel copies its root's id.
@@ -20,10 +21,23 @@ namespace kh {
 
 static constexpr uint32_t CCL_NONE = 0xFFFFFFFFu;
 
+// init: lanes along x.  A voxel starts as a child of the first voxel of its x run INSIDE its 64-lane chunk (one ballot per chunk:
+// no atomics, and the "link with the left neighbour" union of rounds 1-4 disappears for 63 voxels in 64); a run that continues
+// over a chunk boundary is joined there by one union in the link pass.  Pointers still point to smaller (or equal) indices.
 template <typename LT>
-__global__ __launch_bounds__(256) void ccl_init_kernel(const LT* __restrict__ lab, uint32_t* __restrict__ parent, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    parent[i] = lab[i] != 0 ? (uint32_t)i : CCL_NONE;
+__global__ __launch_bounds__(256) void ccl_init_kernel(const LT* __restrict__ lab, uint32_t* __restrict__ parent, int sx, int64_t nrows) {
+  const int xt = (sx + 255) >> 8;
+  const int64_t ntiles = (int64_t)xt * nrows;
+  const int lane = threadIdx.x & 63;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int x = (int)(t % xt) * 256 + threadIdx.x;
+    const int64_t i = x + (int64_t)sx * (t / xt);
+    const LT L = x < sx ? lab[i] : (LT)0;
+    LT Lm = (LT)__shfl_up((unsigned long long)L, 1);
+    const bool start = L != 0 && (lane == 0 || Lm != L);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(start) & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    if (x < sx) parent[i] = L != 0 ? (uint32_t)(i - (lane - (63 - __clzll((long long)m)))) : CCL_NONE;
+  }
 }
 
 __device__ __forceinline__ uint32_t ccl_ld(uint32_t* parent, uint32_t i) {
@@ -51,6 +65,18 @@ __device__ __forceinline__ void ccl_union(uint32_t* parent, uint32_t a, uint32_t
   }
 }
 
+// link: the 13 neighbours that precede a voxel in the raster lie in its own row (x - 1) and in four earlier rows
+// (dy, dz) = (-1, 0), (-1, -1), (0, -1), (+1, -1) at x - 1, x, x + 1.  Most of those unions would find the two voxels in one set
+// already -- two root searches and, in rounds 1-4, a compare-and-swap each (34.7 GB of traffic for 3.7 GB of labels).  They
+// are skipped by looking at the labels first (a look before the atomic):
+//   * its own row: the x runs are pre-linked by ccl_init_kernel inside every 64-lane chunk; only a run that crosses a chunk
+//     boundary needs a union, at the chunk's first voxel;
+//   * an earlier row r', for the FIRST voxel of a run: the voxel above it (x, r') if it has the label -- (x - 1, r') and
+//     (x + 1, r') are then in the same run of r' --, else (x - 1, r') and (x + 1, r');
+//   * an earlier row r', for any other voxel of a run: only (x + 1, r'), and only when (x, r') does NOT have the label -- else
+//     (x + 1, r') belongs to a run of r' that an earlier voxel of this run has linked already.
+// Every pair of adjacent runs still gets a link: take the leftmost voxel of this run that touches the run of r'; it is either
+// the first voxel of this run (first rule) or sits one to the left of that run's start (second rule).
 template <typename LT>
 __global__ __launch_bounds__(256) void ccl_link_kernel(const LT* __restrict__ lab, uint32_t* parent, int sx, int sy, int sz) {
   const int xt = (sx + 255) >> 8;
@@ -64,21 +90,25 @@ __global__ __launch_bounds__(256) void ccl_link_kernel(const LT* __restrict__ la
     const int64_t i = x + (int64_t)sx * y + sxy * z;
     const LT L = lab[i];
     if (L == 0) continue;
-    // the 13 neighbours that precede i in the raster: (-1,0,0), (*, -1, 0), (*, *, -1).  If the left neighbour has
-    // the same label it links every preceding neighbour with dx <= 0 itself (they are among ITS 13), so only the
-    // dx = +1 column is left for this voxel: 5 unions instead of 13 inside an object.
     const bool left = x > 0 && lab[i - 1] == L;
-    if (left) ccl_union(parent, (uint32_t)i, (uint32_t)(i - 1));
+    if (left && (x & 63) == 0) ccl_union(parent, (uint32_t)i, (uint32_t)(i - 1));
 #pragma unroll
-    for (int k = 1; k < 13; k++) {
-      const int dx = ((k - 1) % 3) - 1;
-      const int dy = k < 4 ? -1 : ((k - 4) / 3) - 1;
-      const int dz = (k < 4) ? 0 : -1;
-      if (left && dx <= 0) continue;
-      const int nx = x + dx, ny = y + dy, nz = z + dz;
-      if (nx < 0 || nx >= sx || ny < 0 || ny >= sy || nz < 0) continue;
-      const int64_t j = i + dx + (int64_t)sx * dy + sxy * dz;
-      if (lab[j] == L) ccl_union(parent, (uint32_t)i, (uint32_t)j);
+    for (int k = 0; k < 4; k++) {
+      const int dy = k == 2 ? 0 : (k == 3 ? 1 : -1);
+      const int dz = k == 0 ? 0 : -1;
+      const int ny = y + dy, nz = z + dz;
+      if (ny < 0 || ny >= sy || nz < 0) continue;
+      const int64_t j = i + (int64_t)sx * dy + sxy * dz;
+      const bool b = lab[j] == L;
+      const bool c = x + 1 < sx && lab[j + 1] == L;
+      if (left) {
+        if (c && !b) ccl_union(parent, (uint32_t)i, (uint32_t)(j + 1));
+      } else if (b) {
+        ccl_union(parent, (uint32_t)i, (uint32_t)j);
+      } else {
+        if (x > 0 && lab[j - 1] == L) ccl_union(parent, (uint32_t)i, (uint32_t)(j - 1));
+        if (c) ccl_union(parent, (uint32_t)i, (uint32_t)(j + 1));
+      }
     }
   }
 }
@@ -192,8 +222,8 @@ static int ccl_impl(const LT* lab, int64_t sx, int64_t sy, int64_t sz, uint32_t*
                     uint32_t* rep, uint32_t* total, uint16_t* out16, hipStream_t st) {
   const int64_t n = sx * sy * sz;
   const int64_t nchunks = (n + 1023) / 1024;
-  hipLaunchKernelGGL((ccl_init_kernel<LT>), dim3(ccl_grid(n, 256)), dim3(256), 0, st, lab, parent, n);
   const int64_t ntiles = ((sx + 255) / 256) * sy * sz;
+  hipLaunchKernelGGL((ccl_init_kernel<LT>), dim3(ccl_grid(ntiles, 1, 1 << 20)), dim3(256), 0, st, lab, parent, (int)sx, sy * sz);
   hipLaunchKernelGGL((ccl_link_kernel<LT>), dim3(ccl_grid(ntiles, 1, 1 << 20)), dim3(256), 0, st, lab, parent, (int)sx, (int)sy, (int)sz);
   hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(ccl_grid(nchunks, 1)), dim3(256), 0, st, parent, n, chunk_counts);
   hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, nchunks, total);
