@@ -572,10 +572,16 @@ __device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_
   int dx, dy, dz;
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
+  // (the pop counter and its exit are a guard against a corrupted heap -- a flood pops at most 26 * Nf + npath nodes -- and, measured
+  // in round 5, the build WITHOUT a second exit from this loop mis-ran on the MI355X: 6 instead of 884 voxels on reference vector 45,
+  // a hang on vector 0, identically in every run, while the same source with the exit -- or with a printf in the loop -- passes all
+  // vectors and tools/selftest/heap_selftest.py; kept as the shape that is tested)
+  uint32_t npop = 0;
   while (h.n > 0) {
     const hnode_t top = *h.root;
     const uint32_t vox = top.y, si = top.z;
     const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the walk
+    if (++npop > 0xFFFFFFF0u) { ovf = true; break; }
     if (PROF) tt = clock64();
     heap_pop_wave(h, lane);
     if (PROF) c_pop += clock64() - tt;

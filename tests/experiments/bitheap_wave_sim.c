@@ -171,7 +171,7 @@ int main(void) {
     for (long t = 0; t < steps && hn; t++) {
       ref_pop(); pop_wave(); ops++;
       if (check("pop", t)) return 1;
-      if (RND() % 100 < (trial < 50 ? 30 : 55)) {          /* a live pop: up to 26 pushes in lane order */
+      if (hn < 400000u && RND() % 100 < (trial < 50 ? 30 : 55)) {          /* a live pop: up to 26 pushes in lane order */
         uint64_t m = 0;
         for (int l = 0; l < 26; l++) if (RND() % 100 < 45) { m |= 1ull << l; ndb[l] = base + (uint32_t)(RND() % nkeys); }
         uint32_t id2 = id;
