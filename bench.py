@@ -492,6 +492,10 @@ def main():
             intake.skeletonize_cc(ieng, intake.LazyVolume(ieng, i_cc, lab0.shape), i_n, {i + 1: i_orig[i].item() for i in range(i_n)},
                                   params, an, dust, True, fix_borders, empty, empty, black_border=False, d_cc=i_cc, timings=timings)
             tk = ieng.last_tasks
+            dump = os.environ.get("KIMI_BENCH_DUMP_TASKS")      # tools/strong_scaling_model.py reads this (per-label voxels and cycles)
+            if dump and tk is not None:
+                np.savez_compressed(dump, **{k: tk[k] for k in ("segid", "count", "n_paths", "cyc_target", "cyc_rail", "cyc_inval",
+                                                                  "stat_heap_pushes", "stat_sweep_bails", "stat_rollbacks")})
             state["retries"] = getattr(ieng, "last_retries", 0)
             state["path_kernel_ms"] = list(getattr(ieng, "last_path_kernel_ms", []))
             del i_cc

@@ -204,9 +204,7 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * Paths are written as linear indices, rail end first, into path_vertices with
  * path_lengths (one u32 per path, same slice offsets /capacity as the vertices).
  * qstate as for kh_edf_batch.  heap_nodes: scratch for the invalidation heaps, 16 bytes per node
- * (16-byte aligned), each label owning nodes [heap_offset, heap_offset + heap_capacity) AND, right behind them, room for the
- * decision-bit words of its heap (8 bytes each; 65 words up to 8189 nodes, at most 4161 up to 524285 nodes, then
- * 4161 + (heap_capacity / 2 - 262142): kimimaro_amd/engine.py heap_words).
+ * (16-byte aligned), each label owning nodes [heap_offset, heap_offset + heap_capacity).
  * Invalidation runs as the order-free level sweep of csrc/sweep.h whenever that certifies the call (the result is
  * then independent of the heap's tie order, hence equal to the reference's), and as the exact emulation of
  * std::priority_queue otherwise.  The sweep needs: level_rank = u32 [ra, rb, rc] table (x fastest) of the rank of
@@ -233,8 +231,8 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
 #define KH_TRACE_THREADS_128 8 /* workgroups of 128 threads */
 #define KH_TRACE_NO_GHOSTS 16  /* undecided voxels abandon the call to the heap emulation at once (rounds 2-4) */
 #define KH_TRACE_GHOST_PARANOID 32  /* roll back after every call that made a ghost (tests) */
-#define KH_TRACE_BIG_LDS_HEAP 64    /* the heap emulation keeps the decision-bit words of its chunks of depth 12 in LDS too (33 KiB per
-                                       workgroup instead of 0.5): one L2 round trip less per pop of a heap above 4095 nodes */
+#define KH_TRACE_BIG_LDS_HEAP 64    /* two chunks (8191 nodes, 128 KiB) of every label's invalidation heap live in LDS: one workgroup
+                                       per CU, for a launch of the few largest labels whose heap emulation sets the wall clock */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,

@@ -366,197 +366,179 @@ __global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int 
 // The invalidation heap: an exact emulation of std::priority_queue<HeapDistanceNode, vector, Compare>
 // with Compare = `t1.dist >= t2.dist` (dijkstra_invalidation.hpp:233-237, 262-264) as libstdc++
 // implements it (bits/stl_heap.h), because the pop order among equal keys decides which source owns
-// a voxel.  The array layout after every operation is identical to libstdc++'s.
-//
-// Round 5: the DECISION-BIT form (tests/experiments/bitheap_sim.c checks its rules against a literal transcription of
-// bits/stl_heap.h on 4.6 million operations with heavy ties).  libstdc++'s pop (__adjust_heap) walks the hole from the root to
-// a LEAF along the smaller child (ties: left) whatever the keys are, and only then pushes the former last element up again.
-// Which child is the smaller one is ONE BIT per internal node (1 = the right child exists and right.key < left.key), and an
-// operation changes that bit only for the parents of the few slots whose content it changes.  With the bits kept up to date
-//   pop  = read one 64-bit word per six levels of the walk (the bits of a six-level sub-tree, chunk-major layout: the words of
-//          the chunks rooted at depth 0 and 6 -- and 12 in the large-LDS launch -- live in LDS), let 64 lanes test the 64 possible
-//          depth-6 descendants against it (two ANDs, one compare, one ballot), then load the nodes ON the path and their siblings'
-//          keys in ONE parallel round trip (lane d = depth d).  Path nodes with key < last.key move up one slot, `last` lands
-//          behind them (path keys never decrease with depth, so they form a prefix: one ballot).  Rounds 1-4 fetched 126
-//          speculative whole nodes per six levels -- three dependent round trips and ~250 instructions per pop, 3.1 k cycles;
-//   push = __push_heap: the ancestors of the new leaf are known up front, lane g loads generation g + 1 and the sibling key of the
-//          chain node below it (one round trip), a ballot gives the climb length, the lanes shift the chain down in one step;
-//   the bits of the parents of the changed slots are rewritten from keys that are in registers by then (LDS / L2 atomics, nobody
-//   waits for them).
-// Nodes are 16-byte records {key bits, voxel, source index, -} in the label's slice of HBM scratch (one dwordx4 per node);
-// keys are non-negative floats compared as their bit patterns (unsigned).  The root has a copy in LDS (every pop starts there).
+// a voxel.  The array layout after every operation is identical to libstdc++'s:
+//   push  = __push_heap: the new key climbs over every ancestor with key >= it.  The ancestors of the
+//           new leaf are known up front, so the wave loads them all at once (lane g = generation g),
+//           a ballot gives the climb length and the lanes shift the chain down in one step.
+//   pop   = __pop_heap/__adjust_heap: libstdc++ walks the hole to a leaf along the smaller child
+//           (ties: left) and then pushes the last element up again.  Because keys never decrease
+//           from parent to child this lands exactly where the text-book early-exit sift-down lands
+//           (verified against the libstdc++ form in oracle/ tests), so the wave descends 6 levels
+//           per memory round trip: 126 speculative child nodes are fetched by the 64 lanes, the path
+//           is resolved from registers, and the nodes on it are moved up in one parallel step.
+// Nodes are 16-byte records {key bits, voxel, source index, -} in the label's slice of HBM scratch, so
+// a node is one dwordx4 load or store.  Keys are non-negative floats: they are compared as their bit
+// patterns (unsigned), which lets "ties go left" be written as k < sibling + (1 on left lanes).
+// A write-through LDS mirror of heap levels 0-12 was tried twice and measured 10-15 % SLOWER: the pop is
+// bound by instruction issue of its single wave more than by memory latency.
 // a native LLVM vector (HIP's uint4 is a struct around a union, which ends up in scratch memory here)
 typedef uint32_t hnode_t __attribute__((ext_vector_type(4)));
 // LDS pointers keep their address space in the type, so LDS and HBM accesses can never be merged into flat_* ones
 typedef __attribute__((address_space(3))) hnode_t lds_hnode_t;
-typedef KH_AS_GLOBAL hnode_t g_hnode_t;
-typedef KH_AS_GLOBAL unsigned long long gu64_t;
-typedef KH_AS_LDS unsigned long long lu64_t;
 
-// words of the chunks rooted at depth 0, 6 (and 12): the LDS part of the decision bits
-static constexpr uint32_t KH_HEAP_WORDS_SMALL = 65u, KH_HEAP_WORDS_BIG = 4161u;
-#define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
-
+// Heap slots 0..TOP-1 live in LDS and nowhere else; slots >= TOP live in the label's slice of HBM scratch.
+// TOPL = 1: the root and the first 6-level chunk under it (127 slots, 2 KiB) -- every label affords that.
+// TOPL = 2: two chunks (8191 slots, 128 KiB): one such workgroup fits on a CU, so it is reserved for the few
+// largest labels, whose sequential chain is the critical path of the whole launch.  Every pop starts in the
+// LDS part, so the top read and the first TOPL chunks cost LDS round trips instead of L2 ones.
+template <int TOPL_>
 struct Heap {
-  g_hnode_t* node;     // [cap] HBM scratch of this label (L2 resident in practice)
-  gu64_t* wg;          // decision-bit words by flat chunk index (HBM, behind the nodes); indices < wlds live in LDS instead
-  lu64_t* wl;          // [wlds] LDS
-  lds_hnode_t* root;   // LDS copy of slot 0
-  uint32_t cap, n, wlds;
-  unsigned long long pmask, ppat;   // per lane j: the six ancestors of the depth-6 descendant j of a chunk root, and the bits that lead to it
+  static constexpr int TOPL = TOPL_;
+  static constexpr uint32_t TOP = TOPL_ == 1 ? 127u : 8191u;
+  hnode_t* node;   // HBM scratch of this label (L2 resident in practice); slots < TOP unused
+  lds_hnode_t* top;  // LDS, TOP + 3 entries (the last LDS chunk's lanes 62/63 read two slots past the end)
+  uint32_t cap, n;
+  // per-lane constants of the 126-node speculative sub-tree (children of node m: 2m+2, 2m+3; parent of
+  // m >= 2: (m-2)>>1).  Lane l holds node m = l ("slot 0", depths 1..6) and m = l+64 ("slot 1", depth 6).
+  unsigned long long am0, am1;  // slot-0 ballot bits of the node's ancestors (am0 including itself)
+  uint32_t sh0, j0, j1;         // heap index of my slot-0 node = ((hole+1) << sh0) - 1 + j0, slot 1: << 6, + j1
+  uint32_t lf;                  // 1 on even lanes (left children), 0 on odd lanes
 };
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
-__device__ __forceinline__ void heap_init_lane(Heap& h, int lane) {
-  // chunk-relative heap indices: the root is 0, the children of m are 2m+1 (left) and 2m+2 (right); descendant j at depth 6 is 63 + j
-  unsigned long long mask = 0, pat = 0;
-  const uint32_t t = 63u + (uint32_t)lane;
-  for (int d = 0; d < 6; d++) {
-    const uint32_t a = ((t + 1u) >> (6 - d)) - 1u;              // ancestor at depth d
-    const uint32_t nx = ((t + 1u) >> (5 - d)) - 1u;             // ... and the next node towards j (depth d + 1)
-    mask |= 1ull << a;
-    pat |= (unsigned long long)((nx & 1u) == 0u) << a;          // right children have even indices
-  }
-  h.pmask = mask;
-  h.ppat = pat;
+// value of lane l^1 (the sibling node): DPP quad_perm [1,0,3,2], no LDS crossbar round trip
+__device__ __forceinline__ uint32_t sibling_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
-// where the decision bit of internal node q lives: flat chunk-word index and bit position
-__device__ __forceinline__ void heap_bit_loc(uint32_t q, uint32_t& flat, uint32_t& rel) {
-  const uint32_t dq = 31u - (uint32_t)__clz((int)(q + 1u));     // depth of q
-  const uint32_t cq = (dq * 43u) >> 8;                          // dq / 6 for dq < 32
-  const uint32_t sh = dq - 6u * cq;                             // depth inside its chunk
-  const uint32_t root1 = (q + 1u) >> sh;                        // chunk root + 1
-  rel = (q + 1u) - (root1 << sh) + (1u << sh) - 1u;
-  const uint32_t first1 = 1u << (6u * cq);                      // first chunk root of that depth + 1
-  flat = (first1 - 1u) / 63u + (root1 - first1);               // words of the shallower chunk depths come first: (64^c - 1) / 63
-}
-// rewrite the decision bit of q (per lane; `on` = false: a lane that has nothing to write)
-__device__ __forceinline__ void heap_set_bit(const Heap& h, bool on, uint32_t q, bool value) {
-  uint32_t flat, rel;
-  heap_bit_loc(on ? q : 0u, flat, rel);
-  const unsigned long long bm = 1ull << rel;
-  const bool in_lds = flat < h.wlds;
-  if (on && in_lds) {
-    __hip_atomic_fetch_and(&h.wl[flat], ~bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (value) __hip_atomic_fetch_or(&h.wl[flat], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  if (on && !in_lds) {
-    __hip_atomic_fetch_and(&h.wg[flat], ~bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (value) __hip_atomic_fetch_or(&h.wg[flat], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// the word of the chunk rooted at r (depth 6c); wave uniform
-__device__ __forceinline__ unsigned long long heap_chunk_word(const Heap& h, int c, uint32_t r) {
-  const uint32_t first1 = 1u << (6 * c);
-  const uint32_t flat = (first1 - 1u) / 63u + (r + 1u - first1);
-  if (flat < h.wlds) return __hip_atomic_load(&h.wl[flat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return __hip_atomic_load(&h.wg[flat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the bits are written by L2 atomics)
+template <class H>
+__device__ __forceinline__ void heap_init_lane(H& h, int lane) {
+  unsigned long long a0 = 0, a1 = 0;
+  for (int m = lane; ; m = (m - 2) >> 1) { a0 |= 1ull << m; if (m < 2) break; }
+  if (lane + 64 < 126) for (int m = (lane + 62) >> 1; ; m = (m - 2) >> 1) { a1 |= 1ull << m; if (m < 2) break; }
+  h.am0 = a0;
+  h.am1 = a1;
+  const int d0 = 31 - __clz(lane + 2);
+  h.sh0 = (uint32_t)d0;
+  h.j0 = (uint32_t)(lane + 2 - (1 << d0));
+  h.j1 = (uint32_t)(lane + 2);
+  h.lf = (lane & 1) ? 0u : 1u;
 }
 
-// all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads the whole node of ancestor
-// generation g + 1 and the key of the sibling of the chain node of generation g (the new leaf is generation 0); a ballot gives the
-// climb length m (the ancestors with key >= k form a prefix because keys never decrease from parent to child), lanes < m write
-// their ancestor one generation down, lane m drops the new node into generation m's slot, and lanes <= m rewrite the decision
-// bit of their chain node's parent.
-__device__ __forceinline__ bool heap_push_wave(Heap& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
+// all 64 lanes of the wave call this with uniform arguments.  One memory round trip: lane g loads
+// the whole node of ancestor generation g+1 (from LDS or HBM, whichever holds that slot), a ballot gives
+// the climb length m (the ancestors with key >= k form a prefix because keys never decrease from parent
+// to child), lanes < m write their ancestor one generation down and lane m drops the new node into
+// generation m's slot.
+template <class H>
+__device__ __forceinline__ bool heap_push_wave(H& h, uint32_t kbits, uint32_t vox, uint32_t src, int lane) {
   if (h.n >= h.cap) return false;
   const uint32_t pos = h.n++;
-  const uint32_t len = pos + 1u;
-  const int sh = lane < 31 ? lane : 31;
-  const uint32_t ce = ((pos + 1u) >> sh) - 1u;                  // chain node of generation `lane` (lane 0: the new leaf); 0xFFFFFFFF beyond the root
-  const bool chain = (lane < 32) && ((pos + 1u) >> sh) >= 1u;
-  const bool valid = chain && ce != 0u;                        // it has a parent = ancestor generation lane + 1
-  const uint32_t ai = valid ? (ce - 1u) >> 1 : 0u;
-  const hnode_t a = h.node[ai];
-  const uint32_t sib = (ce & 1u) ? ce + 1u : ce - 1u;           // the other child of that parent
-  const bool sib_ok = valid && sib < len;
-  const uint32_t sk = h.node[sib_ok ? sib : 0u].x;
+  const int sh = lane + 1 < 32 ? lane + 1 : 31;
+  const uint32_t q = (pos + 1u) >> sh;
+  const bool valid = (lane < 31) && q >= 1u;
+  const uint32_t ai = q - 1u;
+  hnode_t a;
+  if (pos < H::TOP) {                     // wave uniform: the whole chain is in LDS
+    a = h.top[valid ? ai : 0u];
+  } else {
+    const bool lo = !valid || ai < H::TOP;
+    const hnode_t ag = h.node[lo ? H::TOP : ai];
+    const hnode_t al = h.top[lo && valid ? ai : 0u];
+    a = lo ? al : ag;
+  }
   const unsigned long long climb = ballot64(valid && a.x >= kbits);
   const int m = __ffsll((long long)~climb) - 1;  // length of the leading run of set bits (lane 63 never set)
+  const uint32_t dest = ((pos + 1u) >> (lane < 31 ? lane : 31)) - 1u;  // slot of generation `lane` (lane 0: the new leaf)
   const hnode_t fresh = {kbits, vox, src, 0u};
   const hnode_t val = lane < m ? a : fresh;
-  if (chain && lane <= m) {
-    h.node[ce] = val;
-    if (ce == 0u) *h.root = val;
+  if (lane <= m) {
+    if (dest < H::TOP) h.top[dest] = val;
+    else h.node[dest] = val;
   }
-  // the slots of generations 0 .. m changed: the decision bit of each one's parent from the two children's keys
-  const uint32_t mykey = val.x;
-  const bool right_is_me = (ce & 1u) == 0u;
-  const bool bit = sib_ok && (right_is_me ? mykey < sk : sk < mykey);
-  heap_set_bit(h, valid && lane <= m, ai, bit);
   return true;
 }
 
-// removes the top; precondition h.n > 0.  See the head comment: the walk reads decision-bit words only, the nodes of the path and
-// the keys of their siblings arrive in one parallel round trip, lane d = depth d.
-__device__ __forceinline__ void heap_pop_wave(Heap& h, int lane) {
+// removes the top; precondition h.n > 0.  libstdc++'s __adjust_heap walks the hole to a leaf along the
+// smaller child (ties: left) and then pushes the former last element up again; the result is: the path
+// nodes with key < last.key move up one level and `last` takes the slot of the deepest of them.
+// The wave fetches 6 levels (126 whole nodes, 2 per lane) per round trip.  A node is on the path iff it
+// and all its ancestors in the sub-tree beat their siblings: one sibling compare per lane, one ballot,
+// one mask test against the lane's constant ancestor mask.  The chunks nest (chunk c+1 runs inside
+// chunk c, which keeps its two nodes in registers) and every write is issued on the way back up, so the
+// load of `last` overlaps the whole descent.  Loads are unconditional (index clamped, key masked
+// to +inf): no divergent branches in the descent.  Chunk 0 is exactly the LDS part of the heap.
+// 32-bit index math is safe: the hole of chunk c sits at level 6c <= 24, so (hole+1) << 6 < 2^31.
+#define KH_POP_CHUNKS 5  /* 5 * 6 = 30 levels */
+template <int C, class H>
+__device__ __forceinline__ void heap_pop_chunk(const H& h, uint32_t hole, uint32_t len, uint32_t vk, int lane,
+                                               uint32_t& deepest, bool& found) {
+  const uint32_t i0 = ((hole + 1u) << h.sh0) - 1u + h.j0;
+  const uint32_t i1 = ((hole + 1u) << 6) - 1u + h.j1;
+  const bool e0 = i0 < len, e1 = (lane < 62) && (i1 < len);
+  hnode_t n0, n1;
+  if constexpr (C < H::TOPL) { n0 = h.top[i0]; n1 = h.top[i1]; }   // an LDS chunk: i0, i1 < TOP + 3 by construction
+  else { n0 = h.node[e0 ? i0 : H::TOP]; n1 = h.node[e1 ? i1 : H::TOP]; }
+  const uint32_t k0 = e0 ? n0.x : INF_BITS, k1 = e1 ? n1.x : INF_BITS;
+  // a node beats its sibling if it is the left one and left.key <= right.key, or the right one and
+  // right.key < left.key (comp(right, left) of dijkstra_invalidation.hpp:233-237: ties go left)
+  const bool w0 = e0 & (k0 < sibling_u32(k0) + h.lf);
+  const bool w1 = e1 & (k1 < sibling_u32(k1) + h.lf);
+  const unsigned long long W0 = ballot64(w0);
+  const bool on0 = (W0 & h.am0) == h.am0;
+  const bool on1 = w1 && ((W0 & h.am1) == h.am1);
+  if constexpr (C + 1 < KH_POP_CHUNKS) {
+    // next hole = the depth-6 node of the path, if the path got that deep and that node has children
+    const unsigned long long P0 = ballot64(on0), P1 = ballot64(on1);
+    uint32_t nh = 0;
+    if (P1) nh = rdlane_u32(i1, __ffsll((long long)P1) - 1);
+    else if (P0 >> 62) nh = rdlane_u32(i0, (P0 >> 63) ? 63 : 62);
+    if (nh != 0u && 2u * nh + 1u < len) heap_pop_chunk<C + 1, H>(h, nh, len, vk, lane, deepest, found);
+  }
+  // every path node with key < last.key moves to its parent's slot; `last` lands in the slot of the
+  // deepest such node (or the root).  Path keys are non-decreasing with depth.
+  const bool mv0 = on0 && k0 < vk;
+  const bool mv1 = on1 && k1 < vk;
+  const uint32_t q0 = (i0 - 1u) >> 1, q1 = (i1 - 1u) >> 1;
+  if constexpr (C < H::TOPL) {
+    if (mv0) h.top[q0] = n0;
+    if (mv1) h.top[q1] = n1;
+  } else if constexpr (C == H::TOPL) {
+    // the parent of this chunk's two depth-1 nodes (lanes 0, 1) is the hole: a leaf of the LDS part
+    if (mv0) { if (lane < 2) h.top[hole] = n0; else h.node[q0] = n0; }
+    if (mv1) h.node[q1] = n1;
+  } else {
+    if (mv0) h.node[q0] = n0;
+    if (mv1) h.node[q1] = n1;
+  }
+  if (!found) {
+    const unsigned long long M0 = ballot64(mv0), M1 = ballot64(mv1);
+    if (M1) { deepest = rdlane_u32(i1, __ffsll((long long)M1) - 1); found = true; }
+    else if (M0) { deepest = rdlane_u32(i0, 63 - __clzll((long long)M0)); found = true; }
+  }
+}
+
+template <class H>
+__device__ __forceinline__ void heap_pop_wave(H& h, int lane) {
   const uint32_t len = h.n - 1u;
   h.n = len;
   if (len == 0) return;
-  const hnode_t last = h.node[len];                             // consumed only after the walk
-  // the heap shrinks first: a parent that loses its right child walks left from now on
-  uint32_t sflat = 0xFFFFFFFFu, srel = 0;
-  if ((len & 1u) == 0u) {
-    heap_bit_loc((len - 2u) >> 1, sflat, srel);
-    heap_set_bit(h, lane == 0, (len - 2u) >> 1, false);
+  const hnode_t last = len < H::TOP ? h.top[len] : h.node[len];  // consumed only after the descent
+  uint32_t deepest = 0;
+  bool found = false;
+  if (len > 1u) heap_pop_chunk<0, H>(h, 0u, len, last.x, lane, deepest, found);
+  if (lane == 0) {
+    if (deepest < H::TOP) h.top[deepest] = last;
+    else h.node[deepest] = last;
   }
-  uint32_t myp = 0u;                                            // lane d: slot of the path node of depth d
-  bool mine = false;
-  uint32_t r = 0u, D = 0u;
-#pragma unroll
-  for (int c = 0; c < KH_POP_CHUNKS; c++) {
-    if (2u * r + 1u >= len) break;                              // r is a leaf (wave uniform)
-    unsigned long long w = heap_chunk_word(h, c, r);
-    {
-      const uint32_t first1 = 1u << (6 * c);
-      if ((first1 - 1u) / 63u + (r + 1u - first1) == sflat) w &= ~(1ull << srel);   // (the shrink above, should its atomic still be on its way)
-    }
-    const unsigned long long hit = ballot64(((w ^ h.ppat) & h.pmask) == 0ull);      // exactly one lane: the depth-6 descendant the bits lead to
-    const uint32_t t1 = 64u + (uint32_t)(__ffsll((long long)hit) - 1);              // its chunk-relative index + 1
-    const int d = lane - 6 * c;                                 // this lane's depth inside the chunk
-    const bool inch = d >= 1 && d <= 6;
-    const int dd = inch ? d : 1;
-    const uint32_t idx = ((r + 1u) << dd) - 1u + ((t1 >> (6 - dd)) - (1u << dd));
-    const bool ex = inch && idx < len;
-    if (inch) { myp = idx; mine = ex; }
-    const uint32_t cnt = (uint32_t)__popcll(ballot64(ex));
-    D += cnt;
-    if (cnt < 6u) break;
-    r = rdlane_u32(idx, 6 * c + 6);
-  }
-  // one round trip: the path nodes and the keys of their siblings
-  const hnode_t nd = h.node[mine ? myp : 0u];
-  const uint32_t sib = (myp & 1u) ? myp + 1u : myp - 1u;
-  const bool sib_ok = mine && sib < len;
-  const uint32_t sk = h.node[sib_ok ? sib : 0u].x;
-  // path nodes with key < last.key move up one slot; `last` lands in the slot of the deepest of them (or the root)
-  const uint32_t m = (uint32_t)__popcll(ballot64(mine && nd.x < last.x));
-  const bool mover = mine && (uint32_t)lane <= m;               // lanes 1 .. m
-  const uint32_t par = (myp - 1u) >> 1;
-  if (mover) {
-    h.node[par] = nd;
-    if (lane == 1) *h.root = nd;
-  }
-  if ((uint32_t)lane == m) {                                    // (lane 0 when nothing moves: myp = 0 there)
-    h.node[myp] = last;
-    if (m == 0u) *h.root = last;
-  }
-  // the new content of slot p_e (e = 1 .. m): the key of lane e + 1, or last.key for e = m; its parent's decision bit
-  const uint32_t nxt = (uint32_t)__shfl_down((int)nd.x, 1);
-  const uint32_t mykey = (uint32_t)lane == m ? last.x : nxt;
-  const bool right_is_me = (myp & 1u) == 0u;
-  const bool bit = sib_ok && (right_is_me ? mykey < sk : sk < mykey);
-  heap_set_bit(h, mover, par, bit);
 }
 
 // wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
 // cycle split (s_memtime waits on the scalar memory counter, so the production kernel leaves it out).
-template <bool PROF>
+template <bool PROF, class H>
 __device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
-                                    float scale, float constant, Heap& h, uint32_t* status, uint32_t* pushes,
+                                    float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3, const uint8_t* __restrict__ corner_gate = nullptr) {
   const int lane = threadIdx.x & 63;
   unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt = 0;
@@ -572,16 +554,10 @@ __device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_
   int dx, dy, dz;
   dir_delta(lane < 26 ? lane : 0, dx, dy, dz);
   uint32_t count = 0;
-  // (the pop counter and its exit are a guard against a corrupted heap -- a flood pops at most 26 * Nf + npath nodes -- and, measured
-  // in round 5, the build WITHOUT a second exit from this loop mis-ran on the MI355X: 6 instead of 884 voxels on reference vector 45,
-  // a hang on vector 0, identically in every run, while the same source with the exit -- or with a printf in the loop -- passes all
-  // vectors and tools/selftest/heap_selftest.py; kept as the shape that is tested)
-  uint32_t npop = 0;
   while (h.n > 0) {
-    const hnode_t top = *h.root;
+    const hnode_t top = h.top[0];
     const uint32_t vox = top.y, si = top.z;
-    const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the walk
-    if (++npop > 0xFFFFFFF0u) { ovf = true; break; }
+    const uint8_t live = alive[vox];   // issued before the pop so its latency overlaps the sift-down
     if (PROF) tt = clock64();
     heap_pop_wave(h, lane);
     if (PROF) c_pop += clock64() - tt;
@@ -634,9 +610,9 @@ __device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_
     const uint32_t ndb = __float_as_uint(nd);
     // The pushes of one fired voxel go to consecutive leaves, in direction order.  About three quarters of them do
     // not climb (measured: 76 % on the largest label of the bench volume): such a push writes its own leaf and
-    // nothing else but its parent's decision bit, and whether it climbs depends on its parent only.  So every pending lane
-    // looks at the parent of the leaf it would get, the leading run of non-climbing pushes is appended with one store per
-    // lane, the first climbing one goes through the ordinary push, and the rest is looked at again (its parents may have
+    // nothing else, and whether it climbs depends on its parent only.  So every pending lane looks at the parent
+    // of the leaf it would get, the leading run of non-climbing pushes is appended with one store per lane, the
+    // first climbing one goes through the ordinary push, and the rest is looked at again (its parents may have
     // changed).  A new leaf is nobody's parent here because the heap is larger than the batch.
     while (m) {
       const uint32_t base = h.n;
@@ -649,28 +625,20 @@ __device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_
         continue;
       }
       const bool mine = (m >> lane) & 1ull;
-      const unsigned long long below = m & ((1ull << lane) - 1ull);
-      const uint32_t leaf = base + (uint32_t)__popcll(below);
+      const uint32_t leaf = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       const uint32_t par = (leaf - 1u) >> 1;
-      const uint32_t kp = h.node[mine ? par : 0u].x;
-      // a right child's decision bit needs its left sibling's key: an older leaf (the first of the run only) or the previous lane's
-      const bool right = mine && (leaf & 1u) == 0u;
-      const uint32_t kold = h.node[right && leaf == base ? leaf - 1u : 0u].x;
-      const int prev = below ? 63 - __clzll((long long)below) : 0;
-      const uint32_t kprev = (uint32_t)__shfl((int)ndb, prev);
-      const bool stay = mine && kp < ndb;                       // __push_heap climbs while parent.key >= key
+      const bool plo = !mine || par < H::TOP;
+      const uint32_t kg = h.node[plo ? H::TOP : par].x;
+      const uint32_t kl = h.top[plo && mine ? par : 0u].x;
+      const bool stay = mine && (plo ? kl : kg) < ndb;          // __push_heap climbs while parent.key >= key
       const unsigned long long climbers = m & ~ballot64(stay);
       const int c = climbers ? __ffsll((long long)climbers) - 1 : 64;   // first lane whose push climbs
       const unsigned long long run = c < 64 ? (m & ((1ull << c) - 1ull)) : m;
-      const bool inrun = (run >> lane) & 1ull;
-      if (inrun) {
+      if ((run >> lane) & 1ull) {
         const hnode_t fresh = {ndb, q, si, 0u};
-        h.node[leaf] = fresh;
+        if (leaf < H::TOP) h.top[leaf] = fresh;
+        else h.node[leaf] = fresh;
       }
-      // decision bit of the new leaf's parent: 0 for a left child (no right one yet -- the right child's lane, if it is in
-      // the run too, writes the real bit: both clear first, then it sets), the comparison for a right child
-      const uint32_t kl = leaf == base ? kold : kprev;
-      heap_set_bit(h, inrun, par, right && ndb < kl);
       const uint32_t nrun = (uint32_t)__popcll(run);
       h.n = base + nrun;
       npush += nrun;
@@ -809,10 +777,10 @@ struct SweepGlobal {
 //   force_heap    skip the sweep (the redo of a call after a roll-back)
 //   heap_ok       false while ghosts exist: the heap emulation needs the exact mask, so a call the sweep abandons cannot be
 //                 redone here -- ctl->u0 = 1 tells the caller to roll back (nothing has been changed)
-template <bool PROF>
+template <bool PROF, class H>
 __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                                const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
-                                               float scale, float constant, Heap& heap, const uint32_t* list, uint32_t nf,
+                                               float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
                                                uint32_t* sweep_stats, uint32_t heap_prio, uint32_t* kill_log,
                                                bool allow_ghosts = false, bool force_heap = false, bool heap_ok = true,
                                                const uint8_t* __restrict__ corner_gate = nullptr) {
@@ -857,7 +825,7 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
       // loads) and it sets the wall clock of the label; the waves it shares its SIMD with -- other labels' sweeps and
       // searches -- are throughput work.  With several volumes in flight they compete for issue slots all the time.
       if (heap_prio) __builtin_amdgcn_s_setprio(3);
-      const uint32_t c = invalidate_ball<PROF>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+      const uint32_t c = invalidate_ball<PROF, H>(ctl->g, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
                                                   &ctl->status, &ctl->u3, ctl->cyc3, corner_gate);
       if (heap_prio) __builtin_amdgcn_s_setprio(0);
       if (tid == 0) ctl->u1 = c;
@@ -867,21 +835,6 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
   const uint32_t c = ctl->u1;
   __syncthreads();
   return c;
-}
-
-// the label's heap: nodes [heap_offset, + heap_capacity) of the scratch, the decision-bit words right behind them (the host leaves
-// room: kimimaro_amd/engine.py heap_words), the root copy and the first `wlds` words in the dynamic LDS (bytes the sweep's level
-// words use while IT runs)
-__device__ __forceinline__ void heap_setup(Heap& heap, hnode_t* heap_nodes, const kh_label_t* task, unsigned char* lds, uint32_t wlds,
-                                           int lane) {
-  heap.node = (g_hnode_t*)(heap_nodes + task->heap_offset);
-  heap.cap = task->heap_capacity;
-  heap.wg = (gu64_t*)(heap_nodes + task->heap_offset + task->heap_capacity);
-  heap.root = (lds_hnode_t*)lds;
-  heap.wl = (lu64_t*)(lds + sizeof(hnode_t));
-  heap.wlds = wlds;
-  heap.n = 0;
-  heap_init_lane(heap, lane);
 }
 
 // thread 0: fill the workgroup's Sweep record for `task` (LDS carve-out `lds` = the dynamic shared memory).  The kernel's
@@ -948,7 +901,7 @@ struct GhostState {
   uint32_t paths, verts, valid, nb, na;   // the state before the call that made the first ghost
 };
 
-template <bool PROF, int BIGW>
+template <bool PROF, int TOPL>
 __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
@@ -963,7 +916,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
   __shared__ uint32_t sweep_stats[5];
-  // the heap emulation's root copy and decision-bit words; the sweep's level words and lists use the same bytes
+  // (Heap<TOPL>::TOP + 3) nodes for the heap emulation; the sweep's level words and lists use the same bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
@@ -978,8 +931,12 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
-  Heap heap;
-  heap_setup(heap, heap_nodes, task, heap_top, BIGW ? KH_HEAP_WORDS_BIG : KH_HEAP_WORDS_SMALL, lane);
+  Heap<TOPL> heap;
+  heap.node = heap_nodes + task->heap_offset;
+  heap.top = (lds_hnode_t*)heap_top;
+  heap.cap = task->heap_capacity;
+  heap.n = 0;
+  heap_init_lane(heap, lane);
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
   float* psave = rail_save ? rail_save + task->path_offset : nullptr;        // the weight a path vertex had before it became a rail
@@ -1003,7 +960,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   if (tid == 0) {
     ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap_nodes + task->heap_offset, q.a, nf, heap_top);
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top);
   }
   __syncthreads();
   // the spill table of the sweep starts all-free (the arena is uninitialised memory)
@@ -1014,7 +971,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     if (tid == 0) pverts[0] = root;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    valid -= invalidate<PROF>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
+    valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
                                           heap, list, nf, sweep_stats, sg.heap_prio, q.a);   // trace.py:211 counts what is left
   }
   const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
@@ -1166,7 +1123,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
         gs.jpos = 0; gs.paths = npaths; gs.verts = nverts; gs.valid = valid; gs.nb = nb; gs.na = na;
       }
       const bool go_ghost = ghosts_on && !redo;
-      const uint32_t killed = invalidate<PROF>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap,
+      const uint32_t killed = invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap,
                                                           list, nf, sweep_stats, sg.heap_prio, go_ghost ? journal + gs.jpos : q.a,
                                                           go_ghost, redo, gs.nghost == 0);
       if (ctl.u0 != 0u) {
@@ -1256,17 +1213,21 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
   extern __shared__ __attribute__((aligned(16))) unsigned char heap_top[];
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t nf = task->count;
-  Heap heap;
-  heap_setup(heap, heap_nodes, task, heap_top, KH_HEAP_WORDS_SMALL, lane);
+  Heap<1> heap;
+  heap.node = heap_nodes + task->heap_offset;
+  heap.top = (lds_hnode_t*)heap_top;
+  heap.cap = task->heap_capacity;
+  heap.n = 0;
+  heap_init_lane(heap, lane);
   if (tid == 0) {
     ctl.status = 0; ctl.u1 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap_nodes + task->heap_offset, queues + (uint64_t)task->q_offset * 4, nf, heap_top, corner_gate);
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top, corner_gate);
   }
   __syncthreads();
   for (uint32_t i = tid; i < sw.spcap; i += blockDim.x) { sw.spk[i] = 0u; sw.spc[i] = 0ull; }   // (the arena is uninitialised memory)
   __syncthreads();
-  const uint32_t c = invalidate<false>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
+  const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
                                                lists + task->list_offset, nf, sweep_stats, sg.heap_prio,
                                                queues + (uint64_t)task->q_offset * 4, false, false, true, corner_gate);
   if (tid == 0) {
@@ -1398,7 +1359,7 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
 }
 
 namespace kh {
-template <bool PROF, int BIGW = 0>
+template <bool PROF, int TOPL = 1>
 static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
@@ -1406,7 +1367,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         int fix_branching, const SweepGlobal& sg, uint32_t max_nlev, unsigned nthreads, uint32_t* journal,
                         float* rail_save, uint32_t ghost_mode) {
   if (count <= 0) return KH_OK;
-  size_t lds = sizeof(hnode_t) + (size_t)(BIGW ? KH_HEAP_WORDS_BIG : KH_HEAP_WORDS_SMALL) * 8;
+  size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (sg.rank && swl > lds) lds = swl;
   {
@@ -1414,10 +1375,10 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
     // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
     // launch can ask for -- so that a concurrent caller never lowers it under somebody else's launch.
     const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
-    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, BIGW>),
+    KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, TOPL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
-  hipLaunchKernelGGL((trace_paths_kernel<PROF, BIGW>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
+  hipLaunchKernelGGL((trace_paths_kernel<PROF, TOPL>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
                      path_lengths, fix_branching, sg, journal, rail_save, ghost_mode);
   KH_LAUNCH_CHECK();
@@ -1490,7 +1451,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   // ghosts need the journal (and, with rails, the saved weights); bit 1: roll every ghost call back at once
   const uint32_t ghost_mode = (journal && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u);
   if (flags & KH_TRACE_BIG_LDS_HEAP)
-    return launch_trace<false, 1>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
+    return launch_trace<false, 2>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                   scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
                                   (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode);
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
@@ -1528,7 +1489,7 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
   sg.arena = reinterpret_cast<unsigned char*>(event_arena);
   sg.lds_levels = (uint32_t)max_nlev;
   sg.heap_prio = 0u;
-  size_t lds = sizeof(hnode_t) + (size_t)KH_HEAP_WORDS_SMALL * 8;
+  size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
   if (level_rank && swl > lds) lds = swl;
   {

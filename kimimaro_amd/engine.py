@@ -80,18 +80,6 @@ def plan_spill(cnt):
     return 2 ** np.clip(np.ceil(np.log2(cnt / 64.0)), 8, 14).astype(np.int64)
 
 
-def heap_words(cap):
-    """u64 decision-bit words the heap emulation keeps BEHIND a heap of `cap` 16-byte nodes (csrc/trace.hip, "The invalidation
-    heap"): one word per six-level chunk, flat index (64^c - 1) / 63 + (root - (64^c - 1)) for a chunk root of depth 6c; only roots
-    that can have children (index < cap / 2) are ever touched.  Returned in NODES (two words each), numpy array or int."""
-    cap = np.asarray(cap, dtype=np.int64)
-    h = cap // 2 + 1
-    words = np.where(h <= 4095, 65,
-                     np.where(h <= 262143, np.minimum(4161, 65 + h - 4095),
-                              np.where(h <= 16777215, 4161 + (h - 262143), 266305 + (h - 16777215))))
-    return (words + 1) // 2
-
-
 def arena_units(chunks, shift, spill):
     """256-byte units of a label's arena: [spill table: 12 B per entry][free stack: 4 B per chunk][chunks of 8-byte slots]"""
     return (spill * 12 + 255) // 256 + (chunks * 4 + 255) // 256 + ((chunks * 8) << shift) // 256
@@ -128,7 +116,7 @@ class Engine:
         self.last_path_kernel_ms = []   # (labels, milliseconds) of its path-loop launches when `timings` was asked for (HIP events)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
         self._side = None     # second stream: the biggest labels run there while the others are collected
-        self.split_slots = 128              # labels that go to the second stream when results are consumed incrementally
+        self.split_slots = int(os.environ.get("KH_SPLIT_SLOTS", "256"))   # labels that go to the second stream (one big-LDS workgroup per CU) when results are consumed incrementally
         self.split_min_voxels = 16384       # ... if they have at least this many voxels
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
@@ -138,8 +126,8 @@ class Engine:
         # the heap emulation at once; "paranoid" rolls every such call back at once (a test of the roll-back; results identical)
         self.ghosts = os.environ.get("KH_GHOSTS", "1") != "0"
         self.ghost_paranoid = os.environ.get("KH_GHOSTS", "1") == "paranoid"
-        # 256-thread workgroups (one volume at a time) keep the decision-bit words of the heap emulation's chunks of depth 12 in
-        # LDS as well (33 KiB per workgroup, three per CU still fit): a pop of a heap above 4095 nodes saves an L2 round trip
+        # the launch of the largest labels (second stream, single-volume mode) keeps two chunks of the invalidation heap in LDS
+        # (128 KiB per workgroup, one workgroup per CU): every pop of a heap emulation saves one of its two L2 round trips
         self.big_lds_heap = os.environ.get("KH_BIG_LDS_HEAP", "1") != "0"
         # threads per label in the path loop (64, 128 or 256).  256 serves one volume best (its searches are 4 x as wide);
         # with volumes in flight 64 does: a label whose call runs on the heap emulation -- one wave for seconds -- then holds a
@@ -383,8 +371,7 @@ class Engine:
             _abi.check(lib.kh_apply_voxel_graph(P(d_nbr), P(d_graph), nvox, P(d_gate), st))
         ctx["d_gate"] = d_gate
         ctx.update(d_slot=d_slot, d_lists=d_lists, d_nbr=d_nbr, d_queues=self.empty(4 * (cnt + 64), t.int32),
-                   d_heap=self.empty(2 * (hcap + int(heap_words(hcap))), t.int64),      # nodes + the decision-bit words behind them
-                   d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
+                   d_heap=self.empty(2 * hcap, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
         d_rank, rdims, max_nlev, ev_units = None, (0, 0, 0), 0, 0
         rmax = float(np.float32(rmax))
         if self.sweep and cnt > 0 and np.isfinite(rmax) and rmax > 0:
@@ -489,11 +476,10 @@ class Engine:
         # label holds 0.7 nodes per voxel); never less than the sweep's lists need (11 / 8 nodes per voxel + 1536)
         hbase = np.maximum((3 * cnt) // 2 + 4096, np.minimum(3 * cnt + 2048, 32768))
         hcap = np.maximum(hbase * scratch_scale // self.scratch_divisor, (11 * cnt) // 8 + 1536)
-        hslice = hcap + heap_words(hcap)                       # nodes + the decision-bit words behind them
-        h_off = np.concatenate([[0], np.cumsum(hslice)[:-1]]).astype(np.int64)
+        h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
         pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
-        if max(total, int(qcap.sum()), int(hslice.sum()), int(pcap.sum())) >= 2 ** 32:
+        if max(total, int(qcap.sum()), int(hcap.sum()), int(pcap.sum())) >= 2 ** 32:
             raise ValueError("kimimaro_amd: scratch offsets exceed 32 bits; shard the labels")
 
         tasks = np.zeros(nl, dtype=_abi.LABEL_T)
@@ -628,7 +614,7 @@ class Engine:
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
-        d_heap = self.empty(2 * int(hslice.sum()), t.int64)  # 16-byte nodes
+        d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
         d_cstate = t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device)
         d_sched = self.sched_volume(nvox) if d_rank is not None else None
         d_arena = self.empty(max(ev_total, 1) * 32 + 32, t.int64)   # units of 256 bytes, 256-byte aligned start
@@ -655,7 +641,7 @@ class Engine:
 
         def launch(first, count, stream, tstream=None, big=False):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
-            flags = prof | (64 if self.big_lds_heap and self.trace_threads == 256 and not self.profile else 0)   # KH_TRACE_BIG_LDS_HEAP
+            flags = prof | (64 if big and self.big_lds_heap and self.trace_threads == 256 else 0)   # KH_TRACE_BIG_LDS_HEAP
             if timings is not None:
                 tstream = tstream if tstream is not None else t.cuda.current_stream(self.device)
                 ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)

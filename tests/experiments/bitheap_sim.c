@@ -1,5 +1,5 @@
 /* Developer experiment (round 5): the "decision-bit" form of the libstdc++ heap emulation, checked on the CPU before it was written
- * for the wave (kimimaro_amd/csrc/trace.hip, "The invalidation heap").
+ * for the wave (tests/experiments/bitheap_r5.patch: built, bit exact on the GPU, measured, and taken out again -- DESIGN.md 3.4.7).
  *
  * libstdc++'s pop walks the hole from the root to a LEAF along the smaller child (ties: left) whatever the keys are, then pushes the
  * former last element up from there.  Which child is the smaller one is ONE BIT per internal node, and a pop or a push changes that
