@@ -596,7 +596,8 @@ def main():
     if args.workload == "c3" and os.path.exists(tpmc):
         for name, v in json.load(open(tpmc))["kernels"].items():
             if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected_per_volume"):
-                tr_traffic = v["hbm_bytes_corrected_per_volume"]
+                # (the volume's launches -- the largest labels as a kernel variant of their own -- added up)
+                tr_traffic = (tr_traffic or 0.0) + v["hbm_bytes_corrected_per_volume"]
                 stale = "" if "r05_" in os.path.basename(tpmc) else "; STALE: measured on the round-4 kernels"
                 tr_src = ("profiles/%s (rocprofv3 --pmc passes over one volume, all path-kernel launches of the volume; not live%s)"
                           % (os.path.basename(tpmc), stale))

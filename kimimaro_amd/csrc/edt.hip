@@ -116,6 +116,78 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
   }
 }
 
+// x pass, round 5: rows of up to 64 * NW voxels (NW = 8 or 16: every BASELINE volume) without LDS and without the per-voxel word
+// scans.  A ballot is a scalar, so the NW "a run starts here" words of the row live in SGPRs; for every chunk the nearest run
+// start BEFORE the chunk and the nearest one AFTER it are scalars too (two short scalar loops per row), and a voxel needs one
+// clz and one ctz on its own chunk's word, falling back to those two scalars when its side of the word is empty.  All loads of
+// the row are issued before the first is consumed.  Same integers, same float operations as edt_x_voxel: bit identical.
+template <typename LT, int NW>
+__global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ lab, float* __restrict__ out,
+                                                         int sx, int64_t nrows, float w, int black_border) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nblk = gridDim.x;
+  const int64_t per_xcd = (nblk + 7) / 8;
+  const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t stride = per_xcd * 8;
+  const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // bits at or below this lane
+  for (int64_t row = logical * 4 + wave; row < nrows; row += stride * 4) {
+    const LT* __restrict__ r = lab + row * sx;
+    float* __restrict__ o = out + row * sx;
+    uint32_t L[NW];
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+      const int x = (c << 6) + lane;
+      L[c] = x < sx ? (uint32_t)r[x] : 0u;
+    }
+    unsigned long long word[NW];
+    uint32_t prev_last = 0;
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+      const int x = (c << 6) + lane;
+      uint32_t Lm = (uint32_t)__shfl_up((int)L[c], 1);
+      if (lane == 0) Lm = prev_last;
+      word[c] = __builtin_amdgcn_ballot_w64(x < sx && x > 0 && L[c] != Lm);
+      prev_last = (uint32_t)__builtin_amdgcn_readlane((int)L[c], 63);
+    }
+    // nearest run start before / after every chunk (scalars; -1 = none)
+    int before[NW], after[NW];
+    int run = -1;
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+      before[c] = run;
+      if (word[c]) run = (c << 6) + 63 - __clzll((long long)word[c]);
+    }
+    run = -1;
+#pragma unroll
+    for (int c = NW - 1; c >= 0; c--) {
+      after[c] = run;
+      if (word[c]) run = (c << 6) + __ffsll((long long)word[c]) - 1;
+    }
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+      const int x = (c << 6) + lane;
+      if (x >= sx) continue;
+      // left: the highest run start p <= x (the differing voxel is p - 1); right: the lowest run start q > x
+      const unsigned long long ml = word[c] & le, mr = word[c] & ~le;
+      int dl = -1, dr = -1;
+      if (ml) dl = lane - (63 - __clzll((long long)ml)) + 1;
+      else if (before[c] >= 0) dl = x - before[c] + 1;
+      else if (black_border) dl = x + 1;
+      if (mr) dr = (__ffsll((long long)mr) - 1) - lane;
+      else if (after[c] >= 0) dr = after[c] - x;
+      else if (black_border) dr = sx - x;
+      int d = dl;
+      if (d < 0 || (dr >= 0 && dr < d)) d = dr;
+      float v = 0.0f;
+      if (L[c] != 0u) {
+        const float dd = w * (float)d;
+        v = d < 0 ? KH_INF : dd * dd;
+      }
+      o[x] = v;
+    }
+  }
+}
+
 // y / z pass: best = min over the same-label segment of f[j] + (w*(i-j))^2, clamped by the segment
 // ends (label change, or the volume border when black_border).  The search walks outward and stops as
 // soon as (w*k)^2 >= best -- nothing farther can improve the minimum -- so the result is the exact
@@ -358,8 +430,13 @@ static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz,
     int64_t grid = need < 8192 ? need : 8192;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL((edt_x_kernel<LT>), dim3((unsigned)grid), dim3(256), 4 * nwords * 8, st, lab, bufs[cur],
-                       (int)sx, nrows, wx, black_border);
+    if (nwords <= 8)
+      hipLaunchKernelGGL((edt_x_rows_kernel<LT, 8>), dim3((unsigned)grid), dim3(256), 0, st, lab, bufs[cur], (int)sx, nrows, wx, black_border);
+    else if (nwords <= 16)
+      hipLaunchKernelGGL((edt_x_rows_kernel<LT, 16>), dim3((unsigned)grid), dim3(256), 0, st, lab, bufs[cur], (int)sx, nrows, wx, black_border);
+    else
+      hipLaunchKernelGGL((edt_x_kernel<LT>), dim3((unsigned)grid), dim3(256), 4 * nwords * 8, st, lab, bufs[cur],
+                         (int)sx, nrows, wx, black_border);
     KH_LAUNCH_CHECK();
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[1], st));
   }
