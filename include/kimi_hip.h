@@ -231,6 +231,9 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
 #define KH_TRACE_THREADS_128 8 /* workgroups of 128 threads */
 #define KH_TRACE_NO_GHOSTS 16  /* undecided voxels abandon the call to the heap emulation at once (rounds 2-4) */
 #define KH_TRACE_GHOST_PARANOID 32  /* roll back after every call that made a ghost (tests) */
+#define KH_TRACE_VOXEL_GRAPH 128    /* nbrmask went through kh_apply_voxel_graph (voxel_graph= of kimimaro.trace.trace): the edges are
+                                       one-way, the predecessor walks read the step u -> v from u's word; corner_gate = the array that
+                                       call filled (NULL without a graph) */
 #define KH_TRACE_BIG_LDS_HEAP 64    /* two chunks (8191 nodes, 128 KiB) of every label's invalidation heap live in LDS: one workgroup
                                        per CU, for a launch of the few largest labels whose heap emulation sets the wall clock */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
@@ -243,7 +246,7 @@ int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const f
                    uint32_t* path_vertices, uint32_t* path_lengths,
                    const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
                    uint64_t* cstate, uint32_t* sched, void* event_arena, uint32_t* journal, float* rail_save,
-                   int flags, int fix_branching, void* stream);
+                   const uint8_t* corner_gate, int flags, int fix_branching, void* stream);
 
 /* keys[a + ra*(b + rb*c)] = the flood's key of the voxel offset (a, b, c): sqrt(fl(fl((wx*a)^2 + (wy*b)^2) + (wz*c)^2)),
  * float operation order of dijkstra_invalidation.hpp:310-316.  Device array of ra*rb*rc floats.              */
@@ -274,11 +277,13 @@ int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* 
  *   mode 2  dijkstra3d.path_from_parents(parents, target) (trace.py:244) on that `dist`: path source -> target.
  * *path_length (device u32) = vertices written (0 on failure, see task.status).  Ties between equally short paths are
  * resolved by the canonical predecessor rule of DESIGN.md 3.3 (dijkstra3d's own tie order is not observable: its
- * source is absent from the reference tree).                                                                        */
+ * source is absent from the reference tree).  voxel_graph != 0: nbrmask went through kh_apply_voxel_graph (voxel_graph= of the
+ * dijkstra3d calls): one-way edges, the predecessor walk reads the step u -> v from u's word.                          */
 int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists, const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                    const float* field, float* dist, uint8_t* qstate, uint32_t* queues,
-                   uint64_t source, uint64_t target, uint32_t* path, int64_t path_capacity, uint32_t* path_length, void* stream);
+                   uint64_t source, uint64_t target, uint32_t* path, int64_t path_capacity, uint32_t* path_length,
+                   int voxel_graph, void* stream);
 
 /* ---- a3 / a5 / a6 as stand-alone operations (the path loop has them fused: kh_pdrf, kh_trace_paths) ----------------
  * kh_zero2inf / kh_inf2zero: skeletontricks.zero2inf / inf2zero (skeletontricks.pyx:177-224), in place.

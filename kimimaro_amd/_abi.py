@@ -106,11 +106,11 @@ def lib():
     L.kh_edf_batch.argtypes = [vp, ci, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp]
     L.kh_pdrf.argtypes = [vp, ci, i64, vp, vp, vp, vp, ci, f32, vp, vp]
     L.kh_trace_paths.argtypes = [vp, ci, vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, vp,
-                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, ci, ci, vp]
+                                 f32, f32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     L.kh_invalidate_ball.argtypes = [vp, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, vp, i64, f32, f32,
                                      vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.kh_apply_voxel_graph.argtypes = [vp, vp, i64, vp, vp]
-    L.kh_path_search.argtypes = [vp, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, i64, vp, vp]
+    L.kh_path_search.argtypes = [vp, ci, vp, vp, i64, i64, i64, f32, f32, f32, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, i64, vp, ci, vp]
     L.kh_zero2inf.argtypes = [vp, i64, vp]
     L.kh_inf2zero.argtypes = [vp, i64, vp]
     L.kh_pdrf_field.argtypes = [vp, vp, i64, f32, ci, f32, f32, vp, vp]

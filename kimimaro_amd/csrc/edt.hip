@@ -130,14 +130,25 @@ __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ 
   const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t stride = per_xcd * 8;
   const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // bits at or below this lane
-  for (int64_t row = logical * 4 + wave; row < nrows; row += stride * 4) {
-    const LT* __restrict__ r = lab + row * sx;
-    float* __restrict__ o = out + row * sx;
-    uint32_t L[NW];
+  // the labels of the NEXT row are requested before this row is worked on (a wave has one row in flight otherwise: 1 KiB)
+  uint32_t Ln[NW];
+  {
+    const int64_t row0 = logical * 4 + wave;
 #pragma unroll
     for (int c = 0; c < NW; c++) {
       const int x = (c << 6) + lane;
-      L[c] = x < sx ? (uint32_t)r[x] : 0u;
+      Ln[c] = (row0 < nrows && x < sx) ? (uint32_t)lab[row0 * sx + x] : 0u;
+    }
+  }
+  for (int64_t row = logical * 4 + wave; row < nrows; row += stride * 4) {
+    float* __restrict__ o = out + row * sx;
+    uint32_t L[NW];
+    const int64_t rown = row + stride * 4;
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+      const int x = (c << 6) + lane;
+      L[c] = Ln[c];
+      Ln[c] = (rown < nrows && x < sx) ? (uint32_t)lab[rown * sx + x] : 0u;
     }
     unsigned long long word[NW];
     uint32_t prev_last = 0;

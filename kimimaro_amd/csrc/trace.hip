@@ -668,12 +668,37 @@ __device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_
 //     equal-distance achieving neighbours (FIFO, neighbours in direction order) to the first voxel with a
 //     strictly smaller achieving predecessor; the BFS route is followed.  bq / bpar: scratch lists (>= Nf
 //     entries), visited marks live in bit 4 of the label's own qstate bytes.
+// With a voxel graph (kh_apply_voxel_graph) the masks are one-way: bit k of nbrmask[v] says "a step FROM v in direction k is
+// allowed".  A predecessor u of v needs the step u -> v, i.e. the bit of the OPPOSITE direction in u's word; without a graph
+// the masks are symmetric and v's own word serves (one load less per step).
+__device__ __forceinline__ bool pred_edge(const Geometry& g, const uint32_t* __restrict__ nbrmask, uint32_t v, int lane, bool graph) {
+  if (lane >= 26) return false;
+  if (!graph) return ((nbrmask[v] >> lane) & 1u) != 0u;
+  int dx, dy, dz;
+  dir_delta(lane, dx, dy, dz);
+  const uint32_t sx = (uint32_t)g.sx, sxy = (uint32_t)g.sxy;
+  const uint32_t z = v / sxy, r = v - z * sxy, y = r / sx, x = r - y * sx;
+  const int nx = (int)x + dx, ny = (int)y + dy, nz = (int)z + dz;
+  if (nx < 0 || ny < 0 || nz < 0 || nx >= g.sx || ny >= g.sy || nz >= g.sz) return false;
+  // the opposite direction: the table of common.h lists every direction next to its opposite (0/1, 2/3, ... are pairs by
+  // construction for the faces; looked up by offset for the rest)
+  int opp = 0;
+#pragma unroll
+  for (int j = 0; j < 26; j++) {
+    int ex, ey, ez;
+    dir_delta(j, ex, ey, ez);
+    if (ex == -dx && ey == -dy && ez == -dz) opp = j;
+  }
+  const uint32_t u = v + (uint32_t)g.off[lane];
+  return ((nbrmask[u] >> opp) & 1u) != 0u;
+}
+
 template <bool RAILS>
 __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const uint32_t* __restrict__ nbrmask,
                                                         const float* __restrict__ pdrf, const float* dist,
                                                         uint32_t rail_end, uint32_t target, uint32_t* out, uint32_t cap,
                                                         uint32_t* bq, uint32_t* bpar, uint32_t bcap, uint8_t* qstate,
-                                                        uint32_t* status) {
+                                                        uint32_t* status, bool graph = false) {
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t v = rail_end, n = 0;
@@ -684,7 +709,7 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
     const float fv = pdrf[v];
     const bool at_rail_end = RAILS && v == rail_end;
     unsigned long long key = NONE64;
-    if (lane < 26 && ((nbrmask[v] >> lane) & 1u)) {
+    if (pred_edge(g, nbrmask, v, lane, graph)) {
       const uint32_t u = v + (uint32_t)g.off[lane];
       const float fu = pdrf[u];
       if (!RAILS || fu != 0.0f) {
@@ -715,7 +740,7 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
       const float fx = pdrf[x];
       bool strict = false, equal = false;
       uint32_t u = 0;
-      if (lane < 26 && ((nbrmask[x] >> lane) & 1u)) {
+      if (pred_edge(g, nbrmask, x, lane, graph)) {
         u = x + (uint32_t)g.off[lane];
         const float fu = pdrf[u];
         if (!RAILS || fu != 0.0f) {
@@ -911,7 +936,8 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
                                                           float scale, float constant, uint32_t* queues, hnode_t* heap_nodes,
                                                           uint32_t* path_vertices,
                                                           uint32_t* path_lengths, int fix_branching, SweepGlobal sg,
-                                                          uint32_t* journal_buf, float* rail_save, uint32_t ghost_mode) {
+                                                          uint32_t* journal_buf, float* rail_save, uint32_t ghost_mode,
+                                                          const uint8_t* __restrict__ corner_gate) {
   __shared__ Ctl ctl;
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
@@ -955,12 +981,13 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
   // ghost mode: bit 0 = on, bit 1 = every call that makes a ghost is rolled back at once (tests of the roll-back itself)
   const bool ghosts_on = (ghost_mode & 1u) != 0u && journal != nullptr && (psave != nullptr || !fix_branching) && sg.rank != nullptr;
   const bool paranoid = (ghost_mode & 2u) != 0u;
+  const bool graph = (ghost_mode & 4u) != 0u;     // the neighbour masks carry a voxel graph: predecessor edges are one-way
   GhostState gs = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t n_ghost_calls = 0, n_rollbacks = 0;
   if (tid == 0) {
     ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top);
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top, corner_gate);
   }
   __syncthreads();
   // the spill table of the sweep starts all-free (the arena is uninitialised memory)
@@ -972,7 +999,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                          heap, list, nf, sweep_stats, sg.heap_prio, q.a);   // trace.py:211 counts what is left
+                                          heap, list, nf, sweep_stats, sg.heap_prio, q.a, false, false, true, corner_gate);   // trace.py:211 counts what is left
   }
   const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
   if (nb + na >= max_paths) {                           // trace.py:217-218
@@ -1036,7 +1063,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
         __syncthreads();
         if (wave == 0) {
           const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, target, root, out, pcap - nverts, q.a, q.b, q.cap,
-                                              qstate, &ctl.status);
+                                              qstate, &ctl.status, graph);
           for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
           if (lane == 0) ctl.u0 = n;
         }
@@ -1055,7 +1082,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
           if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
         } else if (wave == 0) {
           const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, target, out, pcap - nverts, q.a, q.b,
-                                             q.cap, qstate, &ctl.status);
+                                             q.cap, qstate, &ctl.status, graph);
           if (lane == 0) ctl.u0 = n;
         }
         __syncthreads();
@@ -1125,7 +1152,7 @@ __global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, 
       const bool go_ghost = ghosts_on && !redo;
       const uint32_t killed = invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap,
                                                           list, nf, sweep_stats, sg.heap_prio, go_ghost ? journal + gs.jpos : q.a,
-                                                          go_ghost, redo, gs.nghost == 0);
+                                                          go_ghost, redo, gs.nghost == 0, corner_gate);
       if (ctl.u0 != 0u) {
         rollback = true;                                   // the sweep abandoned the call while ghosts exist
       } else {
@@ -1251,7 +1278,7 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
 __global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int mode, const uint32_t* __restrict__ lists,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g, const float* pdrf,
                                                           float* dist, uint8_t* qstate, uint32_t* queues, uint32_t src, uint32_t dst,
-                                                          uint32_t* out, uint32_t cap, uint32_t* out_n) {
+                                                          uint32_t* out, uint32_t cap, uint32_t* out_n, int graph) {
   __shared__ Ctl ctl;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   Queues q;
@@ -1266,7 +1293,7 @@ __global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int 
     sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f);
   } else if (mode == 2) {
     if (wave == 0) {
-      const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, dst, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status);
+      const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, dst, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status, graph != 0);
       for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
       if (lane == 0) ctl.u0 = n;
     }
@@ -1278,7 +1305,7 @@ __global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int 
     if (br == NONE64) {
       if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
     } else if (wave == 0) {
-      const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status);
+      const uint32_t n = backtrack<true>(ctl.g, nbrmask, pdrf, dist, (uint32_t)br, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status, graph != 0);
       if (lane == 0) ctl.u0 = n;
     }
     __syncthreads();
@@ -1365,7 +1392,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                         int fix_branching, const SweepGlobal& sg, uint32_t max_nlev, unsigned nthreads, uint32_t* journal,
-                        float* rail_save, uint32_t ghost_mode) {
+                        float* rail_save, uint32_t ghost_mode, const uint8_t* corner_gate) {
   if (count <= 0) return KH_OK;
   size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
@@ -1380,7 +1407,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
   }
   hipLaunchKernelGGL((trace_paths_kernel<PROF, TOPL>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                     path_lengths, fix_branching, sg, journal, rail_save, ghost_mode);
+                     path_lengths, fix_branching, sg, journal, rail_save, ghost_mode, corner_gate);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -1418,14 +1445,14 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
                               void* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
                               const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, int64_t max_nlev,
                               uint64_t* cstate, uint32_t* sched, void* event_arena, uint32_t* journal, float* rail_save,
-                              int flags, int fix_branching, void* stream) {
+                              const uint8_t* corner_gate, int flags, int fix_branching, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_trace_paths: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128 | KH_TRACE_NO_GHOSTS |
-                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP)) ||
+                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP | KH_TRACE_VOXEL_GRAPH)) ||
       ((flags & KH_TRACE_THREADS_64) && (flags & KH_TRACE_THREADS_128))) {
     set_error("kh_trace_paths: unknown flags");
     return KH_EINVAL;
@@ -1449,17 +1476,18 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   // ghosts need the journal (and, with rails, the saved weights); bit 1: roll every ghost call back at once
-  const uint32_t ghost_mode = (journal && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u);
+  const uint32_t ghost_mode = (journal && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u) |
+                              ((flags & KH_TRACE_VOXEL_GRAPH) ? 4u : 0u);
   if (flags & KH_TRACE_BIG_LDS_HEAP)
     return launch_trace<false, 2>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                   scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                  (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode);
+                                  (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode, corner_gate);
   return prof ? launch_trace<true>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                    scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                   (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode)
+                                   (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode, corner_gate)
               : launch_trace<false>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                     scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
-                                    (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode);
+                                    (uint32_t)max_nlev, nthreads, journal, rail_save, ghost_mode, corner_gate);
 }
 
 extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,
@@ -1507,7 +1535,7 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
 extern "C" int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy,
                               int64_t sz, float wx, float wy, float wz, const float* field, float* dist, uint8_t* qstate,
                               uint32_t* queues, uint64_t source, uint64_t target, uint32_t* path, int64_t path_capacity,
-                              uint32_t* path_length, void* stream) {
+                              uint32_t* path_length, int voxel_graph, void* stream) {
   if (int rc2 = require_device()) return rc2;
   if (!task || !lists || !nbrmask || !field || !dist || !qstate || !queues || !path_length || mode < 0 || mode > 2 ||
       (mode != 1 && !path) || sx * sy * sz >= (1ll << 32) || path_capacity < 0 || path_capacity >= (1ll << 32) ||
@@ -1518,7 +1546,7 @@ extern "C" int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists,
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
   hipLaunchKernelGGL(path_search_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, task, mode, lists, nbrmask, g, field, dist, qstate,
-                     queues, (uint32_t)source, (uint32_t)target, path, (uint32_t)path_capacity, path_length);
+                     queues, (uint32_t)source, (uint32_t)target, path, (uint32_t)path_capacity, path_length, voxel_graph);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

@@ -423,7 +423,7 @@ class Engine:
     # -- the per-label pipeline -------------------------------------------------
     def run_labels(self, d_cc, label_bytes, d_dbf, shape, anisotropy, nlabels, segids, counts, dbf_max, first_index,
                    xmin, xmax, roots, targets_before, targets_after, params, fix_branching=True, max_paths=None,
-                   return_fields=False, timings=None, soma=None, consume=None, scratch_scale=1):
+                   return_fields=False, timings=None, soma=None, consume=None, scratch_scale=1, voxel_graph=None):
         """Run find_root -> DAF -> PDRF -> path loop for the connected components `segids`.
 
         segids/counts/...: host arrays indexed by position (same order).  roots: array of linear indices or
@@ -455,7 +455,7 @@ class Engine:
                                     np.asarray(xmax)[g], np.asarray(roots, dtype=np.uint32)[g], pick_list(targets_before, g),
                                     pick_list(targets_after, g), params, fix_branching=fix_branching, max_paths=max_paths,
                                     timings=timings, soma=sub_soma, consume=consume,
-                                    scratch_scale=scratch_scale)
+                                    scratch_scale=scratch_scale, voxel_graph=voxel_graph)
                     done.append(self.last_tasks)
                     retried += self.last_retries
                 self.last_tasks = np.concatenate(done)
@@ -578,6 +578,12 @@ class Engine:
         mark("setup")
         _abi.check(lib.kh_scatter_lists(P(d_cc), label_bytes, nvox, P(d_slot), nl, P(d_off), P(d_cur), P(d_lists), st))
         _abi.check(lib.kh_neighbor_mask(P(d_cc), label_bytes, sx, sy, sz, P(d_nbr), st))
+        d_gate = None
+        if voxel_graph is not None:
+            # voxel_graph= of kimimaro.trace.trace (a u32 device volume, cc3d's bit layout): the directions a voxel's word does not
+            # allow leave the masks every search and the invalidation work from; d_gate = the corner entries at the x faces
+            d_gate = t.zeros(nvox + 4, dtype=t.uint8, device=self.device)
+            _abi.check(lib.kh_apply_voxel_graph(P(d_nbr), P(voxel_graph), nvox, P(d_gate), st))
         mark("lists+nbrmask")
         # find_root (trace.py:291-308) then DAF (trace.py:139-145)
         _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
@@ -652,7 +658,7 @@ class Engine:
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
                                           P(d_cstate), self.optr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
-                                          flags, int(bool(fix_branching)), stream))
+                                          self.optr(d_gate), flags | (128 if d_gate is not None else 0), int(bool(fix_branching)), stream))
             if timings is not None:
                 kernel_events[-1][3].record(kernel_events[-1][4])
 
@@ -712,7 +718,7 @@ class Engine:
                                   np.asarray(dbf_max)[pick], np.asarray(first_index)[pick], np.asarray(xmin)[pick],
                                   np.asarray(xmax)[pick], np.asarray(roots, dtype=np.uint32)[pick], sub(targets_before),
                                   sub(targets_after), params, fix_branching=fix_branching, max_paths=max_paths, soma=subsoma,
-                                  consume=sink, scratch_scale=scratch_scale * 8)
+                                  consume=sink, scratch_scale=scratch_scale * 8, voxel_graph=voxel_graph)
             self.last_retries = nretry + self.last_retries      # (the nested call counted its own)
             return got
 

@@ -148,9 +148,15 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     one process drives one GPU; multi-GPU runs shard the connected components round robin over the
     ranks of torch.distributed (see kimimaro_amd.distributed).
     """
-    if fix_avocados or voxel_graph is not None:
-        raise NotImplementedError("fix_avocados / voxel_graph: optional pre-passes outside the "
-                                  "MI355X hot-path scope (SURVEY.md section 8, rows out of scope)")
+    if fix_avocados:
+        raise NotImplementedError("fix_avocados: an optional pre-pass outside the MI355X hot-path scope (SURVEY.md section 8)")
+    if voxel_graph is not None:
+        # The searches and the invalidation take the graph (kimimaro_amd.trace.trace(voxel_graph=), the function-level mirrors of
+        # kimimaro_amd.ops; kh_apply_voxel_graph).  What the whole-volume call still lacks is edt.edt(voxel_graph=) -- the walls of
+        # the transform -- and cc3d's graph-aware components (kimimaro/intake.py:178-183, utility.py:73-75): both packages are
+        # absent from the reference tree, their wall semantics cannot be pinned here (DESIGN.md section 7).
+        raise NotImplementedError("skeletonize(voxel_graph=): edt.edt(voxel_graph=) / cc3d's graph-aware components are not restated; "
+                                  "kimimaro_amd.trace.trace(voxel_graph=) and the kimimaro_amd.ops searches do take a graph")
     eng = _engine or Engine()  # raises HipUnavailableError without a GPU: no CPU fallback
     anisotropy = np.array(anisotropy, dtype=np.float32)
 

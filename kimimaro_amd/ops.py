@@ -22,7 +22,9 @@ def engine():
 def edt(labels, anisotropy=(1, 1, 1), black_border=False, parallel=1, voxel_graph=None):
     """edt.edt as called at kimimaro/intake.py:178-183."""
     if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph")
+        # edt.edt(voxel_graph=) treats the blocked directions as walls of the transform; the package's source is absent and the
+        # semantics of a wall BETWEEN two voxels of one label cannot be pinned here (DESIGN.md section 7)
+        raise NotImplementedError("edt(voxel_graph=): the wall semantics of the absent `edt` package are not restated")
     eng = engine()
     lab = np.asarray(labels)
     shape0 = lab.shape
@@ -189,11 +191,11 @@ def euclidean_distance_field(labels, source, anisotropy=(1, 1, 1), free_space_ra
                              return_max_location=False):
     """dijkstra3d.euclidean_distance_field as called at kimimaro/trace.py:139-145, 302-307: geodesic distance inside
     the mask from `source`, +inf elsewhere; with return_max_location also the (x, y, z) of the largest finite value."""
-    if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph")
     eng = engine()
     lab = _f3(labels)
-    ctx = eng.single_object(lab, anisotropy)
+    # voxel_graph: the directions a voxel's word does not allow leave the neighbour masks the search works from
+    # (kh_apply_voxel_graph; one-way edges for an asymmetric graph, like the invalidation reads it)
+    ctx = eng.single_object(lab, anisotropy, voxel_graph=voxel_graph)
     shape = ctx["shape"]
     t = eng.torch
     task = ctx["task"]
@@ -215,13 +217,14 @@ def euclidean_distance_field(labels, source, anisotropy=(1, 1, 1), free_space_ra
 class _Search:
     """an object's device context + its weight field for kh_path_search"""
 
-    def __init__(self, field):
+    def __init__(self, field, voxel_graph=None):
         eng = engine()
         self.eng = eng
         self.host_shape = np.asarray(field).shape
         f = _f3(field, np.float32)
         self.shape = f.shape
-        self.ctx = eng.single_object(np.isfinite(f), (1, 1, 1))
+        self.graph = voxel_graph is not None
+        self.ctx = eng.single_object(np.isfinite(f), (1, 1, 1), voxel_graph=voxel_graph)
         t = eng.torch
         self.d_field = t.from_numpy(np.ascontiguousarray(f.reshape(-1, order="F"))).to(eng.device)
         self.d_dist = t.full((f.size,), float("inf"), dtype=t.float32, device=eng.device)
@@ -234,7 +237,7 @@ class _Search:
         sx, sy, sz = self.shape
         _abi.check(eng.lib.kh_path_search(P(ctx["d_task"]), mode, P(ctx["d_lists"]), P(ctx["d_nbr"]), sx, sy, sz, 1.0, 1.0, 1.0,
                                           P(self.d_field), P(self.d_dist), P(ctx["d_qstate"]), P(ctx["d_queues"]), int(source),
-                                          int(target), P(d_path), cap, P(d_n), eng.stream()))
+                                          int(target), P(d_path), cap, P(d_n), int(self.graph), eng.stream()))
         status = int(ctx["d_task"].cpu().numpy().view(_abi.LABEL_T)["status"][0])
         if status:
             raise _abi.KimiHipError("kh_path_search: %s" % _abi.describe_status(status))
@@ -245,9 +248,7 @@ class _Search:
 def railroad(field, source, voxel_graph=None):
     """dijkstra3d.railroad(field, source) as called at kimimaro/trace.py:240-242: the path from `source` to the nearest
     zero-weight voxel, rail end first, as an (n, 3) array."""
-    if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph")
-    s = _Search(field)
+    s = _Search(field, voxel_graph)
     return s.run(0, _loc(source, s.shape))
 
 
@@ -258,9 +259,7 @@ class _Parents(_Search):
 def parental_field(field, source, voxel_graph=None):
     """dijkstra3d.parental_field(field, source) as called at kimimaro/trace.py:155.  The result is opaque to the caller
     (the reference only hands it to path_from_parents): here the distance field of the search, resident on the device."""
-    if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph")
-    p = _Parents(field)
+    p = _Parents(field, voxel_graph)
     p.source = _loc(source, p.shape)
     p.run(1, p.source)
     return p
@@ -276,9 +275,7 @@ def dijkstra(field, source, target, voxel_graph=None):
     from `source` to `target` where entering a voxel costs its field value, as an (n, 3) array source first.  The same
     search as parental_field + path_from_parents (one weighted Dijkstra from the source, predecessor walk from the
     target); ties between equally cheap paths follow the canonical predecessor rule of DESIGN.md 3.3."""
-    if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph")
-    return path_from_parents(parental_field(field, source), target)
+    return path_from_parents(parental_field(field, source, voxel_graph), target)
 
 
 def first_label(labels):

@@ -15,8 +15,6 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
           pdrf_scale=5000, pdrf_exponent=16, soma_invalidation_scale=0.5, soma_invalidation_const=0,
           fix_branching=True, manual_targets_before=None, manual_targets_after=None, root=None,
           max_paths=None, voxel_graph=None, return_paths=False, _engine=None, _return_raw=False):
-    if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph is not supported on the HIP path")
     eng = _engine or Engine()
     labels = np.asarray(labels)
     while labels.ndim < 3:
@@ -35,6 +33,17 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     mta = [loc(p) for p in (manual_targets_after or [])]
     dmax = np.float32(dbf_max[1])
     soma_mode = False
+    d_graph = None
+    if voxel_graph is not None:
+        # trace.py:139-145,155,167,240-242,257: the graph goes to every dijkstra3d search and to the invalidation
+        vg = np.asarray(voxel_graph)
+        while vg.ndim < 3:
+            vg = vg[..., np.newaxis]
+        if tuple(vg.shape) != tuple(shape):
+            raise ValueError("voxel_graph must have the shape of the labels")
+        if dmax > soma_detection_threshold:
+            raise NotImplementedError("voxel_graph together with the soma branch (its re-EDT would need edt(voxel_graph=))")
+        d_graph = eng.to_device(np.asfortranarray(vg.astype(np.uint32)))
     if dmax > soma_detection_threshold:  # kimimaro/trace.py:108-119
         # fill_voids.fill (kh_fill_voids, row f3) + crop re-EDT, both on the GPU
         d_filled, nfilled = eng.fill_voids((d_cc != 0).to(eng.torch.uint8), shape)
@@ -64,7 +73,7 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     params.update(scale=scale, const=const, pdrf_scale=pdrf_scale, pdrf_exponent=pdrf_exponent)
     res = eng.run_labels(d_cc, 4, d_dbf, shape, anisotropy, 1, [1], counts[1:2], dbf_max[1:2], first_index[1:2],
                          xmin[1:2], xmax[1:2], [r], [mtb], [mta], params, fix_branching=fix_branching, max_paths=max_paths,
-                         return_fields=_return_raw, soma=soma)
+                         return_fields=_return_raw, soma=soma, voxel_graph=d_graph)
     if _return_raw:
         return res
     paths = paths_of(res, 0, shape)

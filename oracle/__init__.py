@@ -10,6 +10,7 @@ from oracle/kimi_oracle.c).  All volumes are Fortran ordered, coordinates are
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 
@@ -33,6 +34,8 @@ def lib():
         L.ko_edt.argtypes = [vp, C.c_int, i64, i64, i64, f32, f32, f32, C.c_int, vp]
         L.ko_edt_nd.argtypes = [vp, C.c_int, C.c_int, i64, i64, i64, f32, f32, f32, C.c_int, vp]
         L.ko_edf.argtypes = [vp, i64, i64, i64, f32, f32, f32, u64, f32, vp, vp, vp]
+        L.ko_set_voxel_graph.argtypes = [vp]
+        L.ko_set_voxel_graph.restype = None
         L.ko_pdrf.argtypes = [vp, vp, i64, f32, C.c_int, f32, f32, vp]
         L.ko_target_order.argtypes = [vp, vp, i64, vp]
         L.ko_target_order.restype = i64
@@ -118,6 +121,23 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False):
     _check(lib().ko_edt_nd(_p(lab), lab.dtype.itemsize, max(1, min(nd, 3)), lab.shape[0], lab.shape[1], lab.shape[2],
                            an[0], an[1], an[2], int(bool(black_border)), _p(out)))
     return out.reshape(labels.shape, order="F") if nd < 3 else out
+
+
+@contextlib.contextmanager
+def voxel_graph(graph):
+    """voxel_graph= of the dijkstra3d calls (kimimaro/trace.py:139-145,155,240-242): inside the block every search of this module
+    (euclidean_distance_field, railroad, field_distances / parental_field and the predecessor walks) steps from a voxel only in the
+    directions its word allows (cc3d's bit layout, the word of the voxel being expanded -- ko_edge in kimi_oracle.c).  None = no
+    graph.  dijkstra3d's source is absent: PARITY UNPINNED by reference code."""
+    if graph is None:
+        yield
+        return
+    g = _f3(graph, np.uint32)
+    lib().ko_set_voxel_graph(_p(g))
+    try:
+        yield
+    finally:
+        lib().ko_set_voxel_graph(None)
 
 
 def euclidean_distance_field(mask, source, anisotropy=(1, 1, 1), free_space_radius=0):

@@ -43,6 +43,23 @@ static const int8_t KO_DIR[26][3] = {
   {-1,-1,-1},{1,-1,-1},{-1,1,-1},{-1,-1,1},{1,1,-1},{1,-1,1},{-1,1,1},{1,1,1}
 };
 
+/* voxel_graph= of the dijkstra3d calls (kimimaro/trace.py:139-145,155,240-242; third-party source absent, PARITY UNPINNED): a
+ * uint32 per voxel, bit ko_vg_bit[i] = "a step from THIS voxel in direction i is allowed" (the layout cc3d writes and
+ * dijkstra_invalidation.hpp:152-190 reads).  Restated the way the invalidation reads it: the word of the voxel being EXPANDED
+ * gates the step, so an asymmetric graph gives one-way edges; a predecessor u of v needs the edge u -> v.  Set for the
+ * duration of a call by the Python wrappers (test infrastructure: single threaded). */
+static const int ko_vg_bit[26] = {1, 0, 3, 2, 5, 4,   9, 7, 8, 6,   17, 13, 16, 12,   15, 11, 14, 10,
+                                  25, 24, 23, 21, 22, 20, 19, 18};
+static const uint32_t* ko_vg = 0;
+void ko_set_voxel_graph(const uint32_t* g) { ko_vg = g; }
+static inline int ko_edge(uint64_t u, int dir) { return ko_vg == 0 || ((ko_vg[u] >> ko_vg_bit[dir]) & 1u); }
+static int ko_opp(int dir) {   /* the direction with the negated offset */
+  for (int j = 0; j < 26; j++)
+    if (KO_DIR[j][0] == -KO_DIR[dir][0] && KO_DIR[j][1] == -KO_DIR[dir][1] && KO_DIR[j][2] == -KO_DIR[dir][2]) return j;
+  return dir;
+}
+
+
 /* centre-to-centre edge lengths, float arithmetic, no contraction
  * (dijkstra_invalidation.hpp:45-52 `_s`, `_c`). */
 void ko_weights26(float wx, float wy, float wz, float* w) {
@@ -245,7 +262,7 @@ int ko_edf(const uint8_t* mask, int64_t sx, int64_t sy, int64_t sz,
       int64_t nx = x + KO_DIR[i][0], ny = y + KO_DIR[i][1], nz = z + KO_DIR[i][2];
       if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
       int64_t q = nx + sx * ny + sxy * nz;
-      if (!mask[q]) continue;
+      if (!mask[q] || !ko_edge(t.v, i)) continue;
       float nd = t.k + w26[i];
       if (nd < out[q]) { out[q] = nd; if (ko_hpush(&h, nd, (uint64_t)q)) { free(h.a); return KO_ENOMEM; } }
     }
@@ -335,7 +352,7 @@ static int ko_pred(const float* f, const float* d, int64_t sx, int64_t sy, int64
     if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
     uint64_t u = (uint64_t)(nx + sx * ny + sxy * nz);
     float du = d[u];
-    if (du == INFINITY) continue;
+    if (du == INFINITY || !ko_edge(u, ko_opp(i))) continue;
     if (rails_absorb && f[u] == 0.0f) continue; /* rails never expand; the source is never a rail here */
     float c = du + fv;
     if (c != dv) continue;
@@ -372,7 +389,7 @@ static int ko_field_sssp(const float* f, int64_t sx, int64_t sy, int64_t sz, uin
       if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
       int64_t q = nx + sx * ny + sxy * nz;
       float fq = f[q];
-      if (fq == INFINITY) continue;
+      if (fq == INFINITY || !ko_edge(t.v, i)) continue;
       float nd = t.k + fq;
       if (nd < d[q]) { d[q] = nd; if (ko_hpush(&h, nd, (uint64_t)q)) { free(h.a); return KO_ENOMEM; } }
     }
@@ -401,7 +418,7 @@ static int ko_pred_strict(const float* f, const float* d, int64_t sx, int64_t sy
     if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
     uint64_t u = (uint64_t)(nx + sx * ny + sxy * nz);
     float du = d[u];
-    if (du == INFINITY) continue;
+    if (du == INFINITY || !ko_edge(u, ko_opp(i))) continue;
     if (rails_absorb && f[u] == 0.0f) continue;
     if (du + fv != dv) continue;
     if (!allow_equal && !(du < dv)) continue;
@@ -447,7 +464,7 @@ static int ko_walk(const float* f, const float* d, int64_t sx, int64_t sy, int64
         int64_t nx = xx + KO_DIR[i][0], ny = xy + KO_DIR[i][1], nz = xz + KO_DIR[i][2];
         if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy || nz >= sz) continue;
         uint64_t w = (uint64_t)(nx + sx * ny + sxy * nz);
-        if (seen[w] || d[w] != d[x]) continue;
+        if (seen[w] || d[w] != d[x] || !ko_edge(w, ko_opp(i))) continue;
         if (rails_absorb && f[w] == 0.0f) continue;
         if (d[w] + f[x] != d[x]) continue;
         seen[w] = 1; q[tail] = w; par[tail] = head; tail++;

@@ -45,10 +45,16 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
           pdrf_scale=5000, pdrf_exponent=16,
           soma_invalidation_scale=0.5, soma_invalidation_const=0,
           fix_branching=True, manual_targets_before=None, manual_targets_after=None,
-          root=None, max_paths=None, voxel_graph=None, stats=None, return_paths=False):
-    """kimimaro/trace.py:36-194."""
+          root=None, max_paths=None, voxel_graph=None, stats=None, return_paths=False, _vcg=None):
+    """kimimaro/trace.py:36-194.  voxel_graph (uint32 per voxel, cc3d's bit layout): handed to every dijkstra3d search and to the
+    invalidation as the reference does (trace.py:139-145,155,167,240-242,257); the soma branch's re-EDT ignores it here (edt's
+    voxel_graph semantics are not restated: source absent), so a graph together with a filled soma is outside the restatement."""
     if voxel_graph is not None:
-        raise NotImplementedError("voxel_graph is not restated in the oracle")
+        voxel_graph = np.asfortranarray(voxel_graph, dtype=np.uint32)
+        with K.voxel_graph(voxel_graph):
+            return trace(labels, DBF, scale, const, anisotropy, soma_detection_threshold, soma_acceptance_threshold, pdrf_scale,
+                         pdrf_exponent, soma_invalidation_scale, soma_invalidation_const, fix_branching, manual_targets_before,
+                         manual_targets_after, root, max_paths, None, stats, return_paths, _vcg=voxel_graph)
     manual_targets_before = list(manual_targets_before or [])
     manual_targets_after = list(manual_targets_after or [])
     dbf_max = np.max(DBF)
@@ -96,13 +102,13 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
 
     if soma_mode:  # trace.py:160-168
         _, labels = K.roll_invalidation_ball_inside_component(
-            labels, DBF, soma_invalidation_scale, soma_invalidation_const, anisotropy, [root])
+            labels, DBF, soma_invalidation_scale, soma_invalidation_const, anisotropy, [root], voxel_connectivity_graph=_vcg)
     elif len(manual_targets_before) == 0:  # :171-172
         manual_targets_before.append(target)
 
     paths = compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
                           fix_branching, manual_targets_before, manual_targets_after,
-                          max_paths, stats, soma_mode=soma_mode, soma_radius=soma_radius)
+                          max_paths, stats, soma_mode=soma_mode, soma_radius=soma_radius, vcg=_vcg)
     if return_paths:
         return paths
 
@@ -151,7 +157,7 @@ def find_soma_root(DBF, dbf_max):
 
 def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
                   fix_branching, manual_targets_before, manual_targets_after, max_paths, stats=None,
-                  soma_mode=False, soma_radius=0.0):
+                  soma_mode=False, soma_radius=0.0, vcg=None):
     """kimimaro/trace.py:196-267."""
     paths = []
     valid_labels = int(np.count_nonzero(labels))
@@ -181,7 +187,7 @@ def compute_paths(root, labels, DBF, finder, parents, scale, const, anisotropy,
         ops = 0
         if valid_labels > 0:
             invalidated, labels, ops = K.roll_invalidation_ball_inside_component(
-                labels, DBF, scale, const, anisotropy, path, return_stats=True)
+                labels, DBF, scale, const, anisotropy, path, return_stats=True, voxel_connectivity_graph=vcg)
             valid_labels -= invalidated
         if fix_branching:
             parents[path[:, 0], path[:, 1], path[:, 2]] = 0.0  # :261-263

@@ -645,3 +645,81 @@ def test_function_level_mirrors_match_oracle(eng):
     want = scipy.ndimage.binary_fill_holes(h)
     assert n == int(want.sum()) - int(h.sum()) and n > 0
     np.testing.assert_array_equal(filled.astype(bool), want)
+
+
+def _random_graph(shape, rng, drop, symmetric):
+    """a voxel_graph of cc3d's layout with a fraction of the direction bits cleared; symmetric: an edge is cleared both ways"""
+    class D:   # the 26 directions in the order of dijkstra_invalidation.hpp:60-124 and the bit of each in cc3d's layout (:152-190)
+        DIRS = [(-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1), (-1, -1, 0), (-1, 1, 0), (1, -1, 0), (1, 1, 0),
+                (0, -1, -1), (0, -1, 1), (0, 1, -1), (0, 1, 1), (-1, 0, -1), (-1, 0, 1), (1, 0, -1), (1, 0, 1),
+                (-1, -1, -1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1), (1, 1, -1), (1, -1, 1), (-1, 1, 1), (1, 1, 1)]
+        GRAPH_BIT = [1, 0, 3, 2, 5, 4, 9, 7, 8, 6, 17, 13, 16, 12, 15, 11, 14, 10, 25, 24, 23, 21, 22, 20, 19, 18]
+    full = (1 << 26) - 1
+    g = np.full(shape, full, dtype=np.uint32, order="F")
+    for i in range(26):
+        cut = np.asfortranarray(rng.random(shape) < drop)
+        g[cut] &= np.uint32(~(1 << D.GRAPH_BIT[i]) & 0xFFFFFFFF)
+        if symmetric:
+            # the neighbour in direction i loses the opposite bit
+            dx, dy, dz = D.DIRS[i]
+            j = D.DIRS.index((-dx, -dy, -dz))
+            src = np.argwhere(cut)
+            dst = src + np.array([dx, dy, dz])
+            ok = np.all((dst >= 0) & (dst < np.array(shape)), axis=1)
+            dst = dst[ok]
+            g[dst[:, 0], dst[:, 1], dst[:, 2]] &= np.uint32(~(1 << D.GRAPH_BIT[j]) & 0xFFFFFFFF)
+    return g
+
+
+@pytest.mark.parametrize("seed,an,symmetric,fix_branching", [(41, (1, 1, 1), True, True), (42, (16, 16, 40), False, True),
+                                                             (43, (2, 2, 3), False, False), (44, (1, 1, 1), False, True),
+                                                             (45, (16, 16, 40), True, False), (46, (4, 4, 40), False, True)])
+def test_trace_with_voxel_graph_matches_oracle(eng, seed, an, symmetric, fix_branching):
+    """kimimaro.trace.trace(..., voxel_graph=) (kimimaro/trace.py:139-145,155,167,240-242,257): the graph gates every search
+    (root, DAF, railroad / parental field, the predecessor walks -- one-way edges when it is asymmetric) and the invalidation.
+    dijkstra3d's source is absent, so this pins HIP == oracle restatement (unpinned by reference code)."""
+    import oracle as K
+    from oracle import pipeline as P
+    from kimimaro_amd.trace import trace
+    rng = np.random.default_rng(seed)
+    m = biggest_component(random_walk_tube((44, 40, 36), seed, steps=34, step=2.6, radius=(2.0, 4.5)))
+    dbf = K.edt(m, an, black_border=False)
+    g = _random_graph(m.shape, rng, 0.08, symmetric)
+    kw = dict(scale=3.0, const=2.0 * an[0], anisotropy=an, pdrf_scale=5000, pdrf_exponent=4, fix_branching=fix_branching)
+    want = P.trace(m, dbf, return_paths=True, voxel_graph=g, **kw)
+    got = trace(m, dbf, return_paths=True, voxel_graph=g, _engine=eng, **kw)
+    assert len(got) == len(want) and len(want) > 0
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    plain = P.trace(m, dbf, return_paths=True, **kw)
+    # (the graph matters on at least some of the cases: different paths than without it)
+    test_trace_with_voxel_graph_matches_oracle.changed = getattr(test_trace_with_voxel_graph_matches_oracle, "changed", 0) + int(
+        len(plain) != len(want) or any(not np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(plain, want)))
+
+
+def test_search_mirrors_with_voxel_graph_match_oracle(eng):
+    """dijkstra3d.euclidean_distance_field / railroad / dijkstra with voxel_graph= through the function-level mirrors"""
+    import oracle as K
+    from kimimaro_amd import ops
+    ops._engine = eng
+    try:
+        rng = np.random.default_rng(7)
+        m = biggest_component(random_walk_tube((36, 36, 30), 77, steps=30, step=2.5, radius=(2.0, 4.0)))
+        an = (16, 16, 40)
+        g = _random_graph(m.shape, rng, 0.15, False)
+        src = tuple(int(v) for v in np.argwhere(m)[0])
+        with K.voxel_graph(g):
+            want, wloc = K.euclidean_distance_field(m, src, an)
+        got, gloc = ops.euclidean_distance_field(m, src, an, voxel_graph=g, return_max_location=True)
+        np.testing.assert_array_equal(got, want)
+        assert tuple(gloc) == tuple(wloc)
+        plain, _ = K.euclidean_distance_field(m, src, an)
+        assert not np.array_equal(plain, want)            # the graph really lengthens some routes
+        field = np.where(m != 0, rng.uniform(1.0, 9.0, m.shape), np.inf).astype(np.float32, order="F")
+        rail = tuple(int(v) for v in np.argwhere(m)[-1])
+        field[rail] = 0.0
+        with K.voxel_graph(g):
+            wpath = K.railroad(field, src)
+        np.testing.assert_array_equal(ops.railroad(field, src, voxel_graph=g), wpath)
+    finally:
+        ops._engine = None
