@@ -71,8 +71,10 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
                 "soma_scale": [np.float32(soma_invalidation_scale)], "soma_const": [np.float32(soma_invalidation_const)]}
     params = dict(TRACE_DEFAULTS)
     params.update(scale=scale, const=const, pdrf_scale=pdrf_scale, pdrf_exponent=pdrf_exponent)
+    # the reference runs on the array it is given: the x faces of THAT array are where its neighbour enumeration degenerates
+    # (dijkstra_invalidation.hpp:116-123), not the object's own extent (skeletonize crops every label to its box first)
     res = eng.run_labels(d_cc, 4, d_dbf, shape, anisotropy, 1, [1], counts[1:2], dbf_max[1:2], first_index[1:2],
-                         xmin[1:2], xmax[1:2], [r], [mtb], [mta], params, fix_branching=fix_branching, max_paths=max_paths,
+                         [0], [shape[0] - 1], [r], [mtb], [mta], params, fix_branching=fix_branching, max_paths=max_paths,
                          return_fields=_return_raw, soma=soma, voxel_graph=d_graph)
     if _return_raw:
         return res
