@@ -351,17 +351,6 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
         // when the bound is crossed inside a group.  All values are >= +0, so min is taken on the bit patterns.
         int kn = 1;  // first step this lane has not probed yet
         float tx = tsq[3];  // (w*k)^2 of the group's first step; the next group's arrives with this group's reads
-        if constexpr (KH_EDT_H <= 8) {
-          // the axis with the coarse voxel pitch: 1.7 steps per voxel on the bench volume (oracle counter), so a wave-uniform loop
-          // of SINGLE steps -- no group of four whose last probes are wasted, no tail -- does less work
-          for (int k = 1;; k++) {
-            const float tk = tsq[k + 2];
-            const bool can = (k <= kb) && (tk < best);
-            if (!__builtin_amdgcn_ballot_w64(can)) break;
-            if (can) best = minpos(best, minpos(pc[-k * 64], pc[k * 64]) + tk);
-          }
-          kn = kb + 1;     // (a lane stopped by the bound gains nothing from the steps it skipped)
-        } else
         for (int k = 1;; k += 4) {
           const bool can = (k + 3 <= kb) && (tx < best);  // once false it stays false
           if (!__builtin_amdgcn_ballot_w64(can)) break;
