@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
       LT Lp = 0;
       if (x < sx && pbeg - 1 >= 0 && pbeg - 1 < n) Lp = lab[base + (int64_t)(pbeg - 1) * astride];
       unsigned int cm = 0, bm = 0;
-#pragma unroll 4
+#ifndef KH_EDT_STAGE_UNROLL
+#define KH_EDT_STAGE_UNROLL 4
+#endif
+#pragma unroll KH_EDT_STAGE_UNROLL
       for (int j = 0; j < KH_EDT_ROWS / 4; j++) {
         const int pos = pbeg + j;
         const bool valid = x < sx && pos >= 0 && pos < n;
