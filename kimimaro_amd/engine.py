@@ -28,12 +28,20 @@ def _torch():
     return torch
 
 
+# per-label scratch of the path loop as plan_launches books it: work lists 16 B per voxel, heap 24, event arena ~24, voxel list and DAF
+# 8, ghost journal 8, path buffers and saved rail weights ~6 = 86 B, booked as 110; + the fixed parts of a small label (a 32 768-node
+# heap, the arena's level chunks, 64 Ki path slots).  Round 2 booked 300 B per voxel (28 GB of event arena per c3 volume then):
+# c5 ran as three launches one after the other, 12.4 s of paths; as one launch it is 91 -> ~200 GB of HBM and half the time.
+SCRATCH_BYTES_PER_VOXEL = 110
+SCRATCH_BYTES_PER_LABEL = 2 << 20
+
+
 def plan_launches(counts, budget):
     """Groups of label positions for successive launches of the path loop: largest labels first, a group is closed when the
-    next label's scratch (about 300 B per voxel + 1 MiB) would take it over `budget` bytes; a label larger than the budget
-    gets a launch of its own.  One group = everything fits."""
+    next label's scratch (SCRATCH_BYTES_PER_VOXEL per voxel + SCRATCH_BYTES_PER_LABEL) would take it over `budget` bytes; a label
+    larger than the budget gets a launch of its own.  One group = everything fits."""
     counts = np.asarray(counts, dtype=np.int64)
-    need = counts * 300 + (1 << 20)
+    need = counts * SCRATCH_BYTES_PER_VOXEL + SCRATCH_BYTES_PER_LABEL
     if int(need.sum()) <= budget:
         return [list(range(len(counts)))]
     groups, cur, acc = [], [], 0
@@ -143,10 +151,10 @@ class Engine:
         self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
         self.arena_divisor = 1              # tests: shrink the sweep's event arena (a call that runs out falls back to the heap)
         self.window_cap = 0                 # tests: cap the level window (an event beyond it abandons the call to the heap)
-        # Per-label scratch (heap, work lists, event arena, path buffers: ~300 B per voxel of a label) of ONE path-loop
+        # Per-label scratch (heap, work lists, event arena, path buffers: SCRATCH_BYTES_PER_VOXEL per voxel of a label) of ONE path-loop
         # launch.  Labels beyond it go to further launches of the same call, largest labels first (callers that consume
         # results incrementally only); the whole-volume fields (~40 B per voxel of the volume) are not counted.
-        self.scratch_budget = int(float(os.environ.get("KH_SCRATCH_BUDGET_GB", "120")) * 1e9)
+        self.scratch_budget = int(float(os.environ.get("KH_SCRATCH_BUDGET_GB", "150")) * 1e9)
 
     # -- plumbing -----------------------------------------------------------
     def stream(self):

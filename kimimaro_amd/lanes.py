@@ -169,12 +169,13 @@ class Lanes:
 def lanes_for(shape, free_bytes, most=12, share=1.0):
     """how many volumes of `shape` to keep in flight on a GPU with `free_bytes` of HBM free: a lane holds the whole-volume
     fields of its volume (56 B per voxel at 512^3 scale: ids, DBF, neighbour masks, PDRF, search scratch, the sweep's per-voxel
-    words) and the per-label scratch of the components it traces (82 B per voxel when the volume is all foreground; `share` =
-    the fraction of them this process traces), measured 17.9 GB at 512^3; 80 % of the free memory at most, `most` lanes at most."""
+    words) and the per-label scratch of the components it traces (91 B per voxel when the volume is all foreground -- since round 5
+    incl. the ghost journal, 8 B, and the saved rail weights; `share` = the fraction of them this process traces), measured
+    19.7 GB at 512^3 (197 GB with ten lanes); 80 % of the free memory at most, `most` lanes at most."""
     nvox = 1
     for v in shape:
         nvox *= int(v)
-    per_lane = (56.0 + 82.0 * float(share)) * nvox
+    per_lane = (56.0 + 91.0 * float(share)) * nvox
     return int(max(1, min(int(most), (0.80 * float(free_bytes)) // per_lane)))
 
 

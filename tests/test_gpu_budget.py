@@ -25,7 +25,7 @@ def test_small_budget_splits_the_labels_and_changes_nothing():
     whole = kimimaro_amd.skeletonize(lab, params, _engine=eng, **kw)
     n_all = len(eng.last_tasks)
     eng2 = Engine()
-    eng2.scratch_budget = 40 << 20           # ~130 k voxels of labels per launch
+    eng2.scratch_budget = 24 << 20           # a few labels per launch
     split = kimimaro_amd.skeletonize(lab, params, _engine=eng2, **kw)
     assert len(eng2.last_tasks) == n_all
     want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=300, fix_borders=True, fix_branching=True)
@@ -37,4 +37,5 @@ def test_small_budget_splits_the_labels_and_changes_nothing():
             np.testing.assert_allclose(got.radii, want[k].radii, rtol=1e-4)
     # the budget really forced more than one launch
     counts = np.bincount(__import__("oracle").connected_components(lab)[0].ravel())[1:]
-    assert int((counts[counts > 300] * 300 + (1 << 20)).sum()) > eng2.scratch_budget
+    from kimimaro_amd.engine import SCRATCH_BYTES_PER_VOXEL, SCRATCH_BYTES_PER_LABEL
+    assert int((counts[counts > 300] * SCRATCH_BYTES_PER_VOXEL + SCRATCH_BYTES_PER_LABEL).sum()) > eng2.scratch_budget

@@ -213,9 +213,9 @@ def test_precomputed_bytes_from_the_format_specification():
 
 def test_plan_launches_groups_labels_under_the_scratch_budget():
     """Engine.scratch_budget: labels sorted by size, groups closed at the budget, an oversized label alone."""
-    from kimimaro_amd.engine import plan_launches
-    counts = np.array([10, 5000, 200, 90000, 3000, 70000])
-    need = counts * 300 + (1 << 20)
+    from kimimaro_amd.engine import plan_launches, SCRATCH_BYTES_PER_VOXEL, SCRATCH_BYTES_PER_LABEL
+    counts = np.array([10, 5000, 200, 90000, 3000, 70000]) * 3
+    need = counts * SCRATCH_BYTES_PER_VOXEL + SCRATCH_BYTES_PER_LABEL
     assert plan_launches(counts, int(need.sum())) == [list(range(6))]            # everything fits: one launch, caller order
     groups = plan_launches(counts, 30 << 20)
     flat = [i for g in groups for i in g]
@@ -223,7 +223,7 @@ def test_plan_launches_groups_labels_under_the_scratch_budget():
     assert flat == [3, 5, 1, 4, 2, 0]                                             # largest first
     for g in groups:
         assert len(g) == 1 or int(need[g].sum()) <= (30 << 20)
-    assert groups[0] == [3]                                                       # 90000 voxels: 28 MB, alone under 30 MB
+    assert groups[0] == [3]                                                       # 270000 voxels: 30 MB + 2 MB, alone
     assert plan_launches(counts, 1) == [[3], [5], [1], [4], [2], [0]]             # nothing fits: one label per launch
 
 
