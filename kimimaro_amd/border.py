@@ -85,12 +85,10 @@ def compute_border_targets(cc_labels, anisotropy, eng=None, edt2d=None, faces=No
             dt_plane = dt_plane.cpu().numpy().reshape(cc_plane.shape, order="F")
         plane_targets = find_border_targets(dt_plane, cc_plane, wx, wy, n)
         # get_mapping(plane, cc_plane): cc id -> label of the 3-D component on this face
-        flat_cc = cc_plane.reshape(-1, order="F")
-        idx = np.flatnonzero(flat_cc)
-        uniq, first_idx = np.unique(flat_cc[idx], return_index=True)
-        lab_of = dict(zip(uniq.tolist(), plane.reshape(-1, order="F")[idx[first_idx]].tolist()))
+        lab_of = np.zeros(n + 1, dtype=plane.dtype)       # (every pixel of a component holds the same label: any write wins)
+        lab_of[cc_plane.reshape(-1, order="F")] = plane.reshape(-1, order="F")
         for label, pt in plane_targets.items():
-            target_list[lab_of[label]].add(rotatefn(int(pt[0]), int(pt[1])))
+            target_list[int(lab_of[label])].add(rotatefn(int(pt[0]), int(pt[1])))
     none = np.array([], np.uint32)      # (shared: a label without targets is looked up per component, thousands of times per volume)
     none.setflags(write=False)
     out = defaultdict(lambda: none)

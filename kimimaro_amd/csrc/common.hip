@@ -102,8 +102,11 @@ int64_t ccl26(const LT* lab, int64_t sx, int64_t sy, int64_t sz, uint32_t* out) 
     while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }
     return i;
   };
-  static const int8_t back[13][3] = {{-1, 0, 0}, {-1, -1, 0}, {0, -1, 0}, {1, -1, 0}, {-1, -1, -1}, {0, -1, -1}, {1, -1, -1},
-                                     {-1, 0, -1}, {0, 0, -1}, {1, 0, -1}, {-1, 1, -1}, {0, 1, -1}, {1, 1, -1}};
+  auto unite = [&](uint32_t i, uint32_t j) {
+    const uint32_t a = find(i), b = find(j);
+    if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; }
+  };
+  static const int8_t below[9][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {0, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
   for (int64_t z = 0; z < sz; z++)
     for (int64_t y = 0; y < sy; y++)
       for (int64_t x = 0; x < sx; x++) {
@@ -111,13 +114,21 @@ int64_t ccl26(const LT* lab, int64_t sx, int64_t sy, int64_t sz, uint32_t* out) 
         parent[i] = (uint32_t)i;
         const LT L = lab[i];
         if (L == 0) continue;
-        for (int k = 0; k < 13; k++) {
-          const int64_t nx = x + back[k][0], ny = y + back[k][1], nz = z + back[k][2];
-          if (nx < 0 || ny < 0 || nz < 0 || nx >= sx || ny >= sy) continue;
-          const int64_t j = nx + sx * ny + sxy * nz;
-          if (lab[j] != L) continue;
-          const uint32_t a = find((uint32_t)i), b = find((uint32_t)j);
-          if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; }
+        // the four visited neighbours of the plane, without the links that earlier pixels have made already: (x, y-1) touches
+        // the other three; (x-1, y) touches (x-1, y-1)  [the faces of the volume are planes: this is the whole job there]
+        const bool has_up = y > 0, has_l = x > 0, has_r = x + 1 < sx;
+        if (has_up && lab[i - sx] == L) unite((uint32_t)i, (uint32_t)(i - sx));
+        else {
+          if (has_l && lab[i - 1] == L) unite((uint32_t)i, (uint32_t)(i - 1));
+          else if (has_l && has_up && lab[i - sx - 1] == L) unite((uint32_t)i, (uint32_t)(i - sx - 1));
+          if (has_r && has_up && lab[i - sx + 1] == L) unite((uint32_t)i, (uint32_t)(i - sx + 1));
+        }
+        if (z == 0) continue;
+        for (int k = 0; k < 9; k++) {
+          const int64_t nx = x + below[k][0], ny = y + below[k][1];
+          if (nx < 0 || ny < 0 || nx >= sx || ny >= sy) continue;
+          const int64_t j = nx + sx * ny + sxy * (z - 1);
+          if (lab[j] == L) unite((uint32_t)i, (uint32_t)j);
         }
       }
   int64_t next = 0;

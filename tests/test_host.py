@@ -296,3 +296,22 @@ def test_plan_arena_shapes():
     s0, c0 = plan_arena(cnt, nlev, False, win)
     assert (s0 >= shift).all() and ((c0 << s0) >= (chunks << shift)).all()          # the unfiltered arena is never smaller
     assert int(chunks[0]) < 2500 and int(chunks[2]) < 12000                              # bounded by the window, not by nlev
+
+
+def test_host_ccl_equals_the_oracle_components():
+    """kh_host_ccl26 (the faces of the volume in compute_border_targets; 3-D on request) skips the in-plane links that earlier
+    pixels have made already: same components, same first-appearance numbering as the oracle's cc3d restatement"""
+    from kimimaro_amd import border, intake
+    from oracle import pipeline as P
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        shp = tuple(int(v) for v in rng.integers(1, 14, 3))
+        lab = np.asfortranarray(rng.integers(0, rng.integers(2, 5), shp).astype([np.uint8, np.uint16, np.uint32, np.uint64][t % 4]))
+        got, n, remap = intake.compute_cc_labels(lab)
+        want, remap_o = P.compute_cc_labels(lab)
+        np.testing.assert_array_equal(got, want)
+        assert remap == remap_o and n == len(remap_o)
+        plane = np.asfortranarray(lab[:, :, 0])
+        cc, m = border._ccl2d(plane)
+        want2, _ = P.compute_cc_labels(plane[:, :, None])
+        np.testing.assert_array_equal(cc, want2[:, :, 0])
