@@ -190,13 +190,19 @@ def volume_step(e, st):
     from collections import defaultdict
     from kimimaro_amd import intake
     lab = st["lab"]
+    log = st.get("phase_log")          # developer knob KIMI_BENCH_LANE_PHASES=1: where a volume's time goes UNDER LOAD
+    tm = [("begin", time.perf_counter())] if log is not None else None
     d_cc, nlabels, rep_ = e.ccl_device(st["d_lab"], lab.dtype.itemsize, lab.shape)
     orig = st["flat"][rep_[1:].astype(np.int64)]
     remapping = {i + 1: orig[i].item() for i in range(nlabels)}
     cc = intake.LazyVolume(e, d_cc, lab.shape)
     empty = defaultdict(list)
-    return intake.skeletonize_cc(e, cc, nlabels, remapping, st["params"], st["an"], st["dust"], True, st["fix_borders"],
-                                 empty, empty, black_border=False, rank=st["shard"][0], world=st["shard"][1], d_cc=d_cc)
+    out = intake.skeletonize_cc(e, cc, nlabels, remapping, st["params"], st["an"], st["dust"], True, st["fix_borders"],
+                                empty, empty, black_border=False, rank=st["shard"][0], world=st["shard"][1], d_cc=d_cc, timings=tm)
+    if log is not None:
+        tm.append(("end", time.perf_counter()))
+        log.append(tm)
+    return out
 
 
 def _lane_setup(eng, index, path, an, params, dust, fix_borders, shard):
@@ -427,10 +433,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         state["gather_s"] = 0.0
+        if os.environ.get("KIMI_BENCH_LANE_PHASES") == "1" and width > 1 and plane["obj"] is None:
+            state["phase_log"] = []        # (every mark of the log is a stream synchronisation of its lane: a diagnostic run)
         t0 = time.perf_counter()
         run_steps(steps, width)
         torch.cuda.synchronize()
         own = time.perf_counter() - t0      # this rank's own steps (before it waits for the slowest rank)
+        if state.get("phase_log"):
+            acc, first = {}, min(tm[0][1] for tm in state["phase_log"])
+            for tm in state["phase_log"]:
+                for (_, a), (name, b) in zip(tm[:-1], tm[1:]):
+                    acc.setdefault(name, []).append(b - a)
+            state["phases_under_load"] = {"mean_s": {k: round(float(np.mean(v)), 4) for k, v in acc.items()},
+                                          "max_s": {k: round(float(np.max(v)), 4) for k, v in acc.items()},
+                                          "volume_s": [round(tm[-1][1] - tm[0][1], 3) for tm in state["phase_log"]],
+                                          "start_s": [round(tm[0][1] - first, 3) for tm in state["phase_log"]]}
+        state["phase_log"] = None
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -680,6 +698,7 @@ def main():
                    "volumes_in_flight": inflight},
         "skeletons": nskel, "labels_per_s_by_label_count": round(nskel * (world if args.scaling == "weak" else 1) / (ms_per_step / 1e3), 3),
         "preamble_s": round(preamble_s, 3), "phases_s": phases, "sweep": sweep, "chains": chain_info, "chains_under_load": loaded,
+        "phases_under_load": state.get("phases_under_load"),
         "roofline": roofline, "roofline_edt": roofline_edt, "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
         "speedup_latency": speedup_latency, "speedup_throughput": speedup_throughput,

@@ -927,7 +927,10 @@ struct GhostState {
 };
 
 template <bool PROF, int TOPL>
-__global__ __launch_bounds__(256, 3) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
+#ifndef KH_TRACE_WAVES_PER_EU
+#define KH_TRACE_WAVES_PER_EU 3   /* 168 VGPRs; 4 -> 128 VGPRs with 66 of them spilled */
+#endif
+__global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
                                                           const float* __restrict__ list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,

@@ -137,6 +137,9 @@ class Engine:
         # the launch of the largest labels (second stream, single-volume mode) keeps two chunks of the invalidation heap in LDS
         # (128 KiB per workgroup, one workgroup per CU): every pop of a heap emulation saves one of its two L2 round trips
         self.big_lds_heap = os.environ.get("KH_BIG_LDS_HEAP", "1") != "0"
+        # how many of the largest labels get such a workgroup: None = all of the second-stream launch in single-volume mode
+        # (256 threads per label), none with 64 / 128 threads; a number = that many, whatever the thread count (the lanes)
+        self.big_lds_labels = int(os.environ["KH_BIG_LDS_LABELS"]) if os.environ.get("KH_BIG_LDS_LABELS") else None
         # threads per label in the path loop (64, 128 or 256).  256 serves one volume best (its searches are 4 x as wide);
         # with volumes in flight 64 does: a label whose call runs on the heap emulation -- one wave for seconds -- then holds a
         # twelfth of a CU instead of a third, and the sweep's levels hold tens of events, not hundreds (kimimaro_amd.lanes
@@ -192,6 +195,10 @@ class Engine:
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
+
+    def sync_stream(self):
+        """wait for the calling thread's current stream only (the phase marks: another lane's kernels are not this volume's)"""
+        self.torch.cuda.current_stream(self.device).synchronize()
 
     # -- f1: connected components on the device ---------------------------------
     def ccl(self, labels):
@@ -579,7 +586,7 @@ class Engine:
 
         def mark(name):
             if timings is not None:
-                self.sync()
+                self.sync_stream()
                 import time
                 timings.append((name, time.perf_counter()))
 
@@ -645,6 +652,8 @@ class Engine:
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
         # are consumed incrementally they go to a second stream and the others are collected while they still run
         n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
+        if self.big_lds_labels is not None:
+            n_large = min(n_large, int(self.big_lds_labels))
         # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 / _128
         # ... | KH_TRACE_NO_GHOSTS | KH_TRACE_GHOST_PARANOID
         prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0) | \
@@ -655,7 +664,8 @@ class Engine:
 
         def launch(first, count, stream, tstream=None, big=False):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
-            flags = prof | (64 if big and self.big_lds_heap and self.trace_threads == 256 else 0)   # KH_TRACE_BIG_LDS_HEAP
+            big_ok = self.trace_threads == 256 if self.big_lds_labels is None else True
+            flags = prof | (64 if big and self.big_lds_heap and big_ok else 0)   # KH_TRACE_BIG_LDS_HEAP
             if timings is not None:
                 tstream = tstream if tstream is not None else t.cuda.current_stream(self.device)
                 ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)

@@ -246,7 +246,7 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
 
     def _mark(name):
         if timings is not None:
-            eng.sync()
+            eng.sync_stream()
             timings.append((name, _time.perf_counter()))
 
     _mark("start")

@@ -17,7 +17,7 @@ cert_fn.restype = C.c_int64
 cert_fn.argtypes = [C.c_void_p] + [C.c_int64] * 3 + [C.c_float] * 3 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
 orig = K.roll_invalidation_ball_inside_component
 state = dict(amask=None, ahead=0, need_exact=0, calls=0, ghost_calls=0, ghosts_made=0, unsound=0, hard_bail=0)
-def hooked(labels, DBF, scale, const, anisotropy, path, return_stats=False):
+def hooked(labels, DBF, scale, const, anisotropy, path, return_stats=False, **kw):
     lab = labels.view(np.uint8)
     if state['amask'] is None:
         state['amask'] = lab.copy(order='F'); state['ahead'] = 0
