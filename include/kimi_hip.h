@@ -163,7 +163,8 @@ typedef struct kh_label_t {
  * (two membership bits per voxel keep every work list bounded by the label size).
  * mode 0: source = task.source.
  * mode 1 (find_root, trace.py:291-308): only tasks with root == 0xFFFFFFFF run; afterwards
- *         task.root = max_loc.   mode 2 (DAF, trace.py:139-145): source = task.root.         */
+ *         task.root = max_loc.   mode 2 (DAF, trace.py:139-145): source = task.root.
+ * Bits 8.. of `mode`: threads per label (a multiple of 64 up to 1024; 0 = 512).                  */
 int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint32_t* lists, const uint32_t* nbrmask,
                  int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                  float* field, uint8_t* qstate, uint32_t* queues, void* stream);

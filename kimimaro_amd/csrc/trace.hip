@@ -1376,13 +1376,21 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
   if (ntasks <= 0) return KH_OK;
   if (sx * sy * sz >= (1ll << 32)) { set_error("kh_edf_batch: volume must have < 2^32 voxels"); return KH_EINVAL; }
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_edf_batch: qstate must be 4-byte aligned"); return KH_EINVAL; }
+  const int nthreads = (mode >> 8) ? (mode >> 8) : 512;
+  mode &= 0xFF;
+  if (mode < 0 || mode > 2 || nthreads < 64 || nthreads > 1024 || (nthreads & 63)) {
+    set_error("kh_edf_batch: mode must be 0, 1 or 2 (+ threads per label << 8: a multiple of 64 up to 1024)");
+    return KH_EINVAL;
+  }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
   float mn = wx < wy ? wx : wy;
   if (wz < mn) mn = wz;
   const float delta_floor = 2.0f * mn;
   // 512 threads per label: measured 0.176 / 0.135 / 0.131 s for the two runs at c3 with 256 / 512 / 1024 threads
-  hipLaunchKernelGGL(edf_batch_kernel, dim3(ntasks), dim3(512), 0, (hipStream_t)stream, tasks, mode, lists, nbrmask, g, field,
+  // (one volume alone; with volumes in flight the lanes ask for fewer: a workgroup needs all its waves' slots on one CU at
+  // once, and next to thousands of one-wave path workgroups eight free slots rarely come together)
+  hipLaunchKernelGGL(edf_batch_kernel, dim3(ntasks), dim3(nthreads), 0, (hipStream_t)stream, tasks, mode, lists, nbrmask, g, field,
                      qstate, queues, delta_floor);
   KH_LAUNCH_CHECK();
   return KH_OK;

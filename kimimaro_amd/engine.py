@@ -145,6 +145,8 @@ class Engine:
         # twelfth of a CU instead of a third, and the sweep's levels hold tens of events, not hundreds (kimimaro_amd.lanes
         # sets it for its engines; measured at c3, 8 lanes: 784 vs 1134 ms per step)
         self.trace_threads = int(os.environ.get("KH_TRACE_THREADS", "256"))
+        # threads per label of the two distance-field searches before the path loop (kh_edf_batch; 512 serves one volume best)
+        self.edf_threads = int(os.environ.get("KH_EDF_THREADS", "512"))
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
         # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
@@ -601,9 +603,9 @@ class Engine:
             _abi.check(lib.kh_apply_voxel_graph(P(d_nbr), P(voxel_graph), nvox, P(d_gate), st))
         mark("lists+nbrmask")
         # find_root (trace.py:291-308) then DAF (trace.py:139-145)
-        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1 | (self.edf_threads << 8), P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
         mark("edf_root")
-        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2, P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
+        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2 | (self.edf_threads << 8), P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
         mark("edf_daf")
         d_ldaf = self.empty(max(total, 1), t.float32)
         _abi.check(lib.kh_gather_f32(P(d_field), P(d_lists), total, P(d_ldaf), st))
