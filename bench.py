@@ -74,6 +74,8 @@ WORKLOADS = {
     # c2 with a soma in its middle: an ellipsoid of 1400 nm radius (~1.1e6 voxels, DBF max above soma_detection_threshold)
     # with a small internal void, so that the label takes the soma branch of kimimaro/trace.py:108-134 (row f3)
     "c2soma": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
+    # the same with TWO such somas (256 voxels apart in x): they are traced side by side (Engine.soma_lanes)
+    "c2soma2": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
     "mini": ((128, 128, 64), 40, 8, 4, (16, 16, 40)),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -112,13 +114,14 @@ def make_volume(name):
         q = np.concatenate([base, np.full((base.shape[0], 1), z * anf[2])], axis=1)
         _, idx = tree.query(q, workers=-1)
         lab[:, :, z] = ids[owner[idx]].reshape(shape[0], shape[1], order="F")
-    if name == "c2soma":
-        c = (shp - 1) / 2.0
+    if name in ("c2soma", "c2soma2"):
+        centres = [(shp - 1) / 2.0] if name == "c2soma" else [(shp - 1) / 2.0 - np.array([128.0, 0, 0]), (shp - 1) / 2.0 + np.array([128.0, 0, 0])]
         gz = np.arange(shape[2])
-        d2 = (((gx - c[0]) * anf[0]) ** 2 + ((gy - c[1]) * anf[1]) ** 2)[:, :, None] + (((gz - c[2]) * anf[2]) ** 2)[None, None, :]
-        lab[d2 <= 1400.0 ** 2] = np.uint32(999999)
-        v = c + np.array([20.0, -12.0, 4.0])       # the void: a 5 x 5 x 3 box of background off the centre
-        lab[int(v[0]) - 2:int(v[0]) + 3, int(v[1]) - 2:int(v[1]) + 3, int(v[2]) - 1:int(v[2]) + 2] = 0
+        for k, c in enumerate(centres):
+            d2 = (((gx - c[0]) * anf[0]) ** 2 + ((gy - c[1]) * anf[1]) ** 2)[:, :, None] + (((gz - c[2]) * anf[2]) ** 2)[None, None, :]
+            lab[d2 <= 1400.0 ** 2] = np.uint32(999999 - k)
+            v = c + np.array([20.0, -12.0, 4.0])       # the void: a 5 x 5 x 3 box of background off the centre
+            lab[int(v[0]) - 2:int(v[0]) + 3, int(v[1]) - 2:int(v[1]) + 3, int(v[2]) - 1:int(v[2]) + 2] = 0
     if cache:
         os.makedirs(cache, exist_ok=True)
         np.save(path, lab)
@@ -418,12 +421,15 @@ def main():
         if latency:
             # one volume alone on an otherwise idle GPU, the way kimimaro_amd.skeletonize() runs it (default engine: 256 threads
             # per label, the largest labels on a second stream): its latency, untimed; twice, the first call fills the pool
+            eng.time_kernels = True        # HIP events around the path-loop launches of these PRODUCTION calls (-> roofline)
             for _ in range(2):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 step()
                 torch.cuda.synchronize()
                 state["single_ms"] = (time.perf_counter() - t1) * 1e3
+                state["production_kernel_ms"] = list(getattr(eng, "last_path_kernel_ms", None) or [])
+            eng.time_kernels = False
             torch.cuda.empty_cache()
         open_process_lanes(width)
         if width > 1:
@@ -561,23 +567,24 @@ def main():
     pass_bytes = np.array([(L + 4) * nvox, (L + 8) * nvox, (L + 8) * nvox], dtype=np.float64)
     k = int(np.argmax(pass_ms))
     lt = {2: "uint16", 4: "uint32"}[L]
-    names = ["edt_x_kernel<%s>" % lt, "edt_axis_kernel<%s> (y pass)" % lt, "edt_axis_kernel<%s> (z pass)" % lt]
+    names = ["edt_x_rows_kernel<%s> (x pass)" % lt, "edt_axis_kernel<%s> (y pass)" % lt, "edt_axis_kernel<%s> (z pass)" % lt]
     achieved = pass_bytes[k] / (pass_ms[k] * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs, gfx950 x2 FETCH correction calibrated on the x pass): profiles/r02_c3_edt_pmc.json.  Only valid for c3.
+    # runs, gfx950 x2 FETCH correction calibrated on the x pass): the newest profiles/rNN_c3_edt_pmc.json.  Only valid for c3.
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_c3_edt_pmc.json", "r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
                 if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(pmc):
         kern = json.load(open(pmc))["kernels"]
         lts = {2: "unsigned short", 4: "unsigned int"}[L]
-        tag = ["edt_x_kernel", "edt_axis_kernel<%s, false" % lts, "edt_axis_kernel<%s, true" % lts][k]
+        tag = ["edt_x_", "edt_axis_kernel<%s, false" % lts, "edt_axis_kernel<%s, true" % lts][k]
         hit = [v for name, v in kern.items() if tag in name]
         if hit:
             traffic = hit[0]["hbm_bytes_corrected"]
     roofline_edt = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/%s (rocprofv3 --pmc pass of an earlier run of the same kernels: edt.hip is unchanged since; not live)" % os.path.basename(pmc) if traffic else None,
+                "traffic_source": "profiles/%s (rocprofv3 --pmc passes of tools/edt_only.py on the same volume%s; not live)"
+                                  % (os.path.basename(pmc), "" if "r05_" in pmc else "; STALE: measured before round 5's x pass") if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
@@ -621,7 +628,9 @@ def main():
                           % (os.path.basename(tpmc), stale))
     # the dominant kernel (97 % of the GPU time): its launches of ONE volume overlap on two streams (the largest labels on the
     # second one), so the duration that counts is the span of the path phase; the HIP events of each launch are listed beside it
-    kms = state.get("path_kernel_ms") or []
+    # (production_kernel_ms: the launches of the single_volume_ms call -- the shipped kernels; path_kernel_ms: the one launch of
+    # the instrumented pass below, the profile build, which is where the cycle counters of `chains` come from)
+    kms = state.get("production_kernel_ms") or state.get("path_kernel_ms") or []
     span_s = max([m for _, m in kms], default=float("nan")) / 1e3 if kms else tr_s
     roofline = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / span_s / 1e9, 3),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / span_s / 1e9 / HBM_PEAK_GBS, 6),
@@ -629,7 +638,10 @@ def main():
                 "ms_per_launch": round(span_s * 1e3, 3),
                 "launches": [{"labels": int(c), "ms": round(float(m), 3)} for c, m in kms],
                 "launch_note": "algorithmic bytes of ONE volume (SURVEY 8d, all its labels) / the longest of the volume's overlapped "
-                               "path-loop launches, HIP events on each launch's own stream (one volume alone on the GPU)",
+                               "path-loop launches (the 256 largest labels run as trace_paths_kernel<false, 2> on a second stream, the "
+                               "rest as <false, 1>), HIP events on each launch's own stream, taken during the single_volume_ms call "
+                               "(one volume alone on the GPU, production kernels)",
+                "instrumented_launch_ms": [round(float(m), 3) for _, m in (state.get("path_kernel_ms") or [])],
                 "phase_seconds": tr_s, "heap_pushes": int(tk["stat_heap_pushes"].astype(np.int64).sum()),
                 "note": "latency bound: level-synchronous sweep per label; the wall clock is the largest label whose call "
                         "needed the exact heap emulation"}

@@ -147,6 +147,13 @@ class Engine:
         self.trace_threads = int(os.environ.get("KH_TRACE_THREADS", "256"))
         # threads per label of the two distance-field searches before the path loop (kh_edf_batch; 512 serves one volume best)
         self.edf_threads = int(os.environ.get("KH_EDF_THREADS", "512"))
+        # soma labels of one volume traced side by side (kimimaro_amd.intake._trace_soma_labels): host threads with an Engine
+        # and a stream each; 1 = one after the other.  The lanes set 1 for their engines (the other volumes fill the GPU).
+        self.soma_lanes = int(os.environ.get("KH_SOMA_LANES", "4"))
+        # HIP events around every launch of the path loop, on the launch's own stream, also without the phase marks
+        # (bench.py: the production launches of one volume -> last_path_kernel_ms)
+        self.time_kernels = False
+        self._soma_pool = None
         self.sweep_table_limit = 1 << 24    # largest level table (entries)
         # Level words of a label stay in LDS up to this many levels (4 B each), beyond in HBM.  This sizes the LDS of the
         # path kernel's workgroups: 8192 -> 39 KiB, which leaves the registers (3 workgroups per CU) as the occupancy limit
@@ -197,6 +204,21 @@ class Engine:
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
+
+    def soma_lane_pool(self, width):
+        """the lanes of the soma labels (made once per Engine): engines of the single-volume kind on streams of their own"""
+        from .lanes import Lanes, _StreamScope
+        if self._soma_pool is None or self._soma_pool.width < width:
+            if self._soma_pool is not None:
+                self._soma_pool.close()
+
+            def make():
+                e = Engine(self.device)
+                e.soma_lanes = 1
+                return e
+            self._soma_pool = Lanes(width, device=self.device, engine_factory=make,
+                                    stream_factory=lambda e: _StreamScope(self.torch, e))
+        return self._soma_pool
 
     def sync_stream(self):
         """wait for the calling thread's current stream only (the phase marks: another lane's kernels are not this volume's)"""
@@ -668,7 +690,7 @@ class Engine:
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
             big_ok = self.trace_threads == 256 if self.big_lds_labels is None else True
             flags = prof | (64 if big and self.big_lds_heap and big_ok else 0)   # KH_TRACE_BIG_LDS_HEAP
-            if timings is not None:
+            if timings is not None or self.time_kernels:
                 tstream = tstream if tstream is not None else t.cuda.current_stream(self.device)
                 ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 ev0.record(tstream)
@@ -679,7 +701,7 @@ class Engine:
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
                                           P(d_cstate), self.optr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
                                           self.optr(d_gate), flags | (128 if d_gate is not None else 0), int(bool(fix_branching)), stream))
-            if timings is not None:
+            if timings is not None or self.time_kernels:
                 kernel_events[-1][3].record(kernel_events[-1][4])
 
         def kernel_times():
@@ -772,7 +794,7 @@ class Engine:
                     self._side.synchronize()
             big = collect(0, n_large)
             mark("paths")
-            if timings is not None:
+            if timings is not None or self.time_kernels:
                 kernel_times()
             consume(big)
             mark("d2h")
@@ -780,9 +802,9 @@ class Engine:
             return None
         launch(0, nl, st)
         mark("paths")
-        if timings is not None:
+        res = collect(0, nl)                  # (its device -> host copies wait for the launch)
+        if timings is not None or self.time_kernels:
             kernel_times()
-        res = collect(0, nl)
         mark("d2h")
         if consume is not None:
             consume(res)

@@ -318,25 +318,40 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
 def _trace_soma_labels(eng, jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out):
     """Labels that enter the soma branch of kimimaro/trace.py:108-134 (internal voids to fill, or DBF max above
     soma_acceptance_threshold) leave the shared-volume batch -- filling voids changes which voxels belong to
-    the label -- and are traced one at a time on their bounding-box crop, exactly like intake.py:450-517."""
+    the label -- and are traced on their bounding-box crop, exactly like intake.py:450-517.  The reference gives every
+    label a process of its pool (intake.py:344-408); here several somas of one volume run side by side, each on a host
+    thread with an Engine and a HIP stream of its own (`Engine.soma_lanes`, kimimaro_amd.lanes.Lanes); the skeletons are
+    merged in the order of the labels either way."""
     from .trace import trace as trace_one
     sx, sy = shape[0], shape[1]
     an = np.asarray(anisotropy, dtype=np.float32)
     unloc = lambda l: (l % sx, (l // sx) % sy, l // (sx * sy))
-    for segid, root, mtb, mta in jobs:
+    kw = {k: params[k] for k in ("scale", "const", "pdrf_scale", "pdrf_exponent", "soma_detection_threshold",
+                                 "soma_acceptance_threshold", "soma_invalidation_scale", "soma_invalidation_const")}
+
+    def one(e, i):
+        segid, root, mtb, mta = jobs[i]
         lo, hi = bbox(segid)
         minpt = np.array(lo, dtype=np.int64)
-        labels = eng.crop(d_cc, shape, lo, hi) == segid
-        dbf = np.where(labels, eng.crop(d_dbf, shape, lo, hi, np.float32), 0.0).astype(np.float32)
+        labels = e.crop(d_cc, shape, lo, hi) == segid
+        dbf = np.where(labels, e.crop(d_dbf, shape, lo, hi, np.float32), 0.0).astype(np.float32)
         tr = lambda ls: [tuple(int(v) for v in (np.array(unloc(l)) - minpt)) for l in ls]
-        kw = {k: params[k] for k in ("scale", "const", "pdrf_scale", "pdrf_exponent", "soma_detection_threshold",
-                                     "soma_acceptance_threshold", "soma_invalidation_scale", "soma_invalidation_const")}
         skel = trace_one(labels, dbf, anisotropy=an, fix_branching=fix_branching, manual_targets_before=tr(mtb),
                          manual_targets_after=tr(mta), root=(None if root == NONE32 else tr([root])[0]),
-                         max_paths=params.get("max_paths"), _engine=eng, **kw)
+                         max_paths=params.get("max_paths"), _engine=e, **kw)
+        if not skel.empty():
+            skel.vertices += minpt.astype(skel.vertices.dtype)
+        return skel
+
+    width = min(int(getattr(eng, "soma_lanes", 1)), len(jobs))
+    if width > 1:
+        eng.sync_stream()              # the component volume and its EDT are complete before another stream reads them
+        results = (skel for _, skel in eng.soma_lane_pool(width).run(one, len(jobs), width=width))
+    else:
+        results = (one(eng, i) for i in range(len(jobs)))
+    for (segid, _, _, _), skel in zip(jobs, results):
         if skel.empty():
             continue
-        skel.vertices += minpt.astype(skel.vertices.dtype)
         orig = remapping[segid]
         skel.id = orig
         skel.vertices = np.multiply(skel.vertices, an, dtype=np.float32)

@@ -71,6 +71,7 @@ class Lanes:
                 e = Engine(device)
                 if "KH_TRACE_THREADS" not in os.environ:
                     e.trace_threads = LANE_THREADS
+                e.soma_lanes = 1        # (no lanes inside a lane: the other volumes are what fills the GPU)
                 return e
 
             def stream_factory(eng):

@@ -169,6 +169,36 @@ def test_skeletonize_with_a_soma_label(eng):
         np.testing.assert_array_equal(got[k].edges, want[k].edges)
 
 
+def test_skeletonize_with_two_soma_labels_side_by_side(eng):
+    """two soma labels in one volume are traced side by side (Engine.soma_lanes: a host thread, an Engine and a stream each);
+    the skeletons are the oracle's, and the same as with one after the other"""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    from shapes import soma_shape
+    vol = np.zeros((160, 64, 64), np.uint32, order="F")
+    vol[:64][soma_shape(hole=True) > 0] = 5
+    vol[96:][soma_shape(hole=False)[::-1] > 0] = 7
+    vol[70:90, 10:50, 20:30] = 9
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params.update(const=2, soma_detection_threshold=6, soma_acceptance_threshold=10,
+                  soma_invalidation_scale=1.0, soma_invalidation_const=1.0)
+    assert eng.soma_lanes > 1
+    got = kimimaro_amd.skeletonize(vol, params, dust_threshold=100, fix_borders=False, _engine=eng)
+    assert eng._soma_pool is not None and eng._soma_pool.width == 2
+    want = P.skeletonize(vol, params, dust_threshold=100, fix_borders=False)
+    assert sorted(got) == sorted(want) == [5, 7, 9]
+    eng.soma_lanes, keep = 1, eng.soma_lanes
+    try:
+        serial = kimimaro_amd.skeletonize(vol, params, dust_threshold=100, fix_borders=False, _engine=eng)
+    finally:
+        eng.soma_lanes = keep
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_array_equal(got[k].vertices, serial[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, serial[k].edges)
+
+
 @pytest.mark.parametrize("fix_branching", [True, False])
 def test_float_absorption_plateau(eng, fix_branching):
     """A 6000-voxel stick accumulates ~4.5e8 of PDRF (ulp 32) before it reaches the ball, whose centre has
