@@ -412,6 +412,8 @@ def main():
         want = os.environ.get("KIMI_BENCH_STAGGER")
         on = (n >= 4 * width) if want is None else (want == "1" and n > width)
         stagger = state.get("single_ms", 0.0) / 1e3 / width if on else 0.0
+        if os.environ.get("KIMI_BENCH_STAGGER_S"):           # developer knob: seconds between the lanes' first jobs
+            stagger = float(os.environ["KIMI_BENCH_STAGGER_S"]) if n > width else 0.0
         for _, local in lanes.run(lambda e, k: local_step(e), n, width=width, stagger=stagger):
             finish(local)
 
@@ -476,12 +478,16 @@ def main():
         omode = "weak" if args.scaling == "strong" else "strong"
         prepare(omode)
         osteps = max(1, min(args.steps, 4))
-        oel = measure(omode, 1, osteps, latency=False)
-        close_process_lanes()
+        try:
+            oel = measure(omode, 1, osteps, latency=False)
+        finally:
+            close_process_lanes()          # (also removes the /dev/shm copy of the volume when the measurement raised)
         other = {"mode": omode, "elapsed": oel, "steps": osteps, "skeletons": len(result["skels"])}
     preamble_s = prepare(args.scaling)
-    elapsed = measure(args.scaling, args.warmup, args.steps)
-    close_process_lanes()                  # (their HBM goes back before the instrumented pass of this process)
+    try:
+        elapsed = measure(args.scaling, args.warmup, args.steps)
+    finally:
+        close_process_lanes()              # (their HBM goes back before the instrumented pass of this process)
     # what the lanes' last volumes looked like UNDER LOAD (thread lanes: the engines are still there): the longest chain of
     # each and the cycle sums, to be read against the solo pass below (`chains`)
     loaded = None
