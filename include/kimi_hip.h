@@ -358,6 +358,19 @@ int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t s
 int64_t kh_host_find_border_targets(const float* dt, const uint32_t* cc, int64_t sx, int64_t sy,
                                     float wx, float wy, int64_t nlab, float* out_xy, int32_t* order);
 
+/* ---- row a12 (host side): the merge of a label's components into one skeleton, kimimaro/intake.py:587-593
+ * (Skeleton.simple_merge(...).consolidate() per original label) for ALL labels of a volume in one call, outside the
+ * interpreter.  The components of a label are disjoint voxel sets whose vertices are sorted lexicographically by
+ * (x, y, z) already (kimimaro_amd.intake.consolidate_paths_batch), so consolidate() is a re-sort on integer keys.
+ * Parts are given label by label, in component order: part_of_label[l] .. part_of_label[l+1] are label l's parts;
+ * vstart / estart [nparts+1]: first vertex / edge of every part in verts [N,3] (voxel coordinates as f32) / radii [N] /
+ * edges [M,2] (indices local to the part).  Output, label by label at the same offsets: out_verts = sorted vertices
+ * times (ax, ay, az) in f32 (intake.py:513), out_radii, out_edges [M,2] = rows (lo, hi) sorted lexicographically, indices
+ * local to the LABEL.  Returns 0, -1 on allocation failure.                                                         */
+int64_t kh_host_merge_components(int64_t nlabels, const int64_t* part_of_label, const int64_t* vstart, const int64_t* estart,
+                                 const float* verts, const float* radii, const uint32_t* edges, int64_t sy, int64_t sz,
+                                 float ax, float ay, float az, float* out_verts, float* out_radii, uint32_t* out_edges);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,11 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <new>
+#include <utility>
+#include <vector>
+
 namespace kh {
 
 static thread_local char g_err[512] = {0};
@@ -150,6 +155,89 @@ extern "C" int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx
     case 8: return ccl26((const uint64_t*)labels, sx, sy, sz, out);
     default: kh::set_error("kh_host_ccl26: label_bytes must be 1, 2, 4 or 8"); return -1;
   }
+}
+
+// ---- row a12 (host side): kimimaro/intake.py:587-593 for every label of a volume (see kimi_hip.h)
+extern "C" int64_t kh_host_merge_components(int64_t nlabels, const int64_t* part_of_label, const int64_t* vstart, const int64_t* estart,
+                                            const float* verts, const float* radii, const uint32_t* edges, int64_t sy, int64_t sz,
+                                            float ax, float ay, float az, float* out_verts, float* out_radii, uint32_t* out_edges) {
+  std::vector<std::pair<int64_t, uint32_t>> keyed;       // (vertex key, position in the label's concatenation)
+  std::vector<uint32_t> rank;
+  std::vector<uint64_t> rows;
+  std::vector<uint32_t> first, placed;
+  try {
+    for (int64_t l = 0; l < nlabels; l++) {
+      const int64_t p0 = part_of_label[l], p1 = part_of_label[l + 1];
+      if (p1 <= p0) continue;
+      const int64_t v0 = vstart[p0], v1 = vstart[p1], e0 = estart[p0], e1 = estart[p1];
+      const int64_t n = v1 - v0;
+      if (p1 - p0 == 1) {                                 // one component: sorted already, indices local already
+        for (int64_t i = v0; i < v1; i++) {
+          out_verts[3 * i] = verts[3 * i] * ax; out_verts[3 * i + 1] = verts[3 * i + 1] * ay; out_verts[3 * i + 2] = verts[3 * i + 2] * az;
+          out_radii[i] = radii[i];
+        }
+        for (int64_t j = 2 * e0; j < 2 * e1; j++) out_edges[j] = edges[j];
+        continue;
+      }
+      keyed.resize((size_t)n);
+      for (int64_t i = 0; i < n; i++) {
+        const float* v = verts + 3 * (v0 + i);
+        keyed[(size_t)i] = {((int64_t)v[0] * sy + (int64_t)v[1]) * sz + (int64_t)v[2], (uint32_t)i};
+      }
+      // every part is sorted already (consolidate_paths_batch): merge the runs; anything else is sorted from scratch
+      // (keys are distinct: the components are disjoint voxel sets)
+      bool runs = true;
+      for (int64_t p = p0; p < p1 && runs; p++)
+        runs = std::is_sorted(keyed.begin() + (vstart[p] - v0), keyed.begin() + (vstart[p + 1] - v0));
+      if (runs) for (int64_t p = p0 + 1; p < p1; p++)
+        std::inplace_merge(keyed.begin(), keyed.begin() + (vstart[p] - v0), keyed.begin() + (vstart[p + 1] - v0));
+      else std::sort(keyed.begin(), keyed.end());
+      rank.resize((size_t)n);
+      for (int64_t i = 0; i < n; i++) {
+        const int64_t src = v0 + keyed[(size_t)i].second, dst = v0 + i;
+        rank[keyed[(size_t)i].second] = (uint32_t)i;
+        out_verts[3 * dst] = verts[3 * src] * ax; out_verts[3 * dst + 1] = verts[3 * src + 1] * ay; out_verts[3 * dst + 2] = verts[3 * src + 2] * az;
+        out_radii[dst] = radii[src];
+      }
+      // rows (lo, hi) sorted lexicographically: a counting sort on lo (a vertex starts a handful of edges), then the few
+      // rows of each lo by hi
+      const int64_t m = e1 - e0;
+      rows.resize((size_t)m);
+      first.assign((size_t)n + 1, 0u);
+      {
+        int64_t r = 0;
+        for (int64_t p = p0; p < p1; p++) {
+          const uint32_t base = (uint32_t)(vstart[p] - v0);
+          for (int64_t j = estart[p]; j < estart[p + 1]; j++, r++) {
+            uint32_t a = rank[base + edges[2 * j]], b = rank[base + edges[2 * j + 1]];
+            if (a > b) { const uint32_t t = a; a = b; b = t; }
+            rows[(size_t)r] = ((uint64_t)a << 32) | b;
+            first[a + 1]++;
+          }
+        }
+      }
+      for (int64_t i = 0; i < n; i++) first[(size_t)i + 1] += first[(size_t)i];
+      placed.assign(first.begin(), first.end() - 1);
+      for (int64_t r = 0; r < m; r++) {
+        const uint32_t a = (uint32_t)(rows[(size_t)r] >> 32);
+        const int64_t at = e0 + (int64_t)placed[a]++;
+        out_edges[2 * at] = a;
+        out_edges[2 * at + 1] = (uint32_t)rows[(size_t)r];
+      }
+      for (int64_t i = 0; i < n; i++) {                    // insertion sort of every lo's rows by hi
+        const int64_t lo = e0 + first[(size_t)i], hi = e0 + first[(size_t)i + 1];
+        for (int64_t a = lo + 1; a < hi; a++) {
+          const uint32_t x = out_edges[2 * a + 1];
+          int64_t b = a;
+          while (b > lo && out_edges[2 * (b - 1) + 1] > x) { out_edges[2 * b + 1] = out_edges[2 * (b - 1) + 1]; b--; }
+          out_edges[2 * b + 1] = x;
+        }
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return -1;
+  }
+  return 0;
 }
 
 // ---- row f2 (host side): skeletontricks.find_border_targets (skeletontricks.pyx:591-647, with compute_centroids

@@ -491,36 +491,42 @@ class Assembler:
             segid = int(tasks["segid"][slot])
             self.skeletons[self.remapping[segid]].append((segid, verts, edges, radii))
 
-    def _skeleton(self, orig, verts, edges, radii):
-        return Skeleton.wrap(np.multiply(verts, self.an, dtype=np.float32), edges, radii, orig,  # intake.py:513
-                             self.transform.copy(), "physical")
-
     def finish(self):
         """one Skeleton per original label.  The components of a label are disjoint voxel sets, so
         Skeleton.simple_merge(...).consolidate() (intake.py:587-593) is a concatenation re-sorted lexicographically by
-        vertex: done on integer keys here (same result as np.unique(vertices, axis=0) + edge remap, much cheaper)."""
+        vertex: done on integer keys for all labels in ONE native call outside the interpreter (kh_host_merge_components;
+        same result as np.unique(vertices, axis=0) + edge remap per label -- which was a dozen numpy calls for each of
+        thousands of labels on the host thread of the lane)."""
+        import ctypes as C
+        from . import _abi
         sx, sy, sz = self.shape
+        origs = list(self.skeletons.keys())                       # (insertion order = the order of the returned dict)
+        if not origs:
+            return {}
+        parts, part_of_label = [], [0]
+        for orig in origs:
+            parts.extend(sorted(self.skeletons[orig], key=lambda p: p[0]))      # component order of intake.py:444
+            part_of_label.append(len(parts))
+        nv = np.fromiter((p[1].shape[0] for p in parts), dtype=np.int64, count=len(parts))
+        ne = np.fromiter((p[2].shape[0] for p in parts), dtype=np.int64, count=len(parts))
+        vstart = np.concatenate([[0], np.cumsum(nv)]).astype(np.int64)
+        estart = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
+        V = np.ascontiguousarray(np.concatenate([p[1] for p in parts]), dtype=np.float32)
+        R = np.ascontiguousarray(np.concatenate([p[3] for p in parts]), dtype=np.float32)
+        E = np.ascontiguousarray(np.concatenate([p[2] for p in parts]), dtype=np.uint32)
+        pol = np.asarray(part_of_label, dtype=np.int64)
+        oV, oR, oE = np.empty_like(V), np.empty_like(R), np.empty_like(E)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        if _abi.lib().kh_host_merge_components(len(origs), P(pol), P(vstart), P(estart), P(V), P(R), P(E), int(sy), int(sz),
+                                               np.float32(self.an[0]), np.float32(self.an[1]), np.float32(self.an[2]),
+                                               P(oV), P(oR), P(oE)) != 0:
+            raise MemoryError("kh_host_merge_components failed")
         merged = {}
-        for orig, parts in self.skeletons.items():
-            if len(parts) == 1:
-                _, verts, edges, radii = parts[0]
-                # edges / radii are slices of arrays that cover a whole result group (thousands of labels): a copy, so that
-                # one kept Skeleton does not pin the group's buffers and the public arrays own their memory
-                merged[orig] = self._skeleton(orig, verts, edges.copy(), radii.copy())
-                continue
-            parts = sorted(parts, key=lambda p: p[0])        # component order of intake.py:444
-            verts = np.concatenate([p[1] for p in parts])
-            radii = np.concatenate([p[3] for p in parts])
-            offs = np.cumsum([0] + [p[1].shape[0] for p in parts[:-1]])
-            edges = np.concatenate([p[2].astype(np.int64) + o for p, o in zip(parts, offs)])
-            v = verts.astype(np.int64)
-            order = np.argsort((v[:, 0] * sy + v[:, 1]) * sz + v[:, 2], kind="stable")
-            rank = np.empty(order.size, dtype=np.int64)
-            rank[order] = np.arange(order.size)
-            e = rank[edges]
-            e.sort(axis=1)
-            e = e[np.argsort(e[:, 0] * order.size + e[:, 1], kind="stable")]
-            merged[orig] = self._skeleton(orig, verts[order], e.astype(np.uint32), radii[order])
+        va, ea = vstart[pol], estart[pol]                         # first vertex / edge of every label
+        for li, orig in enumerate(origs):
+            # copies: the public arrays own their memory (a kept Skeleton does not pin the volume's buffers)
+            merged[orig] = Skeleton.wrap(oV[va[li]:va[li + 1]].copy(), oE[ea[li]:ea[li + 1]].copy(), oR[va[li]:va[li + 1]].copy(),
+                                         orig, self.transform.copy(), "physical")
         return merged
 
 

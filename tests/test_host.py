@@ -315,3 +315,36 @@ def test_host_ccl_equals_the_oracle_components():
         cc, m = border._ccl2d(plane)
         want2, _ = P.compute_cc_labels(plane[:, :, None])
         np.testing.assert_array_equal(cc, want2[:, :, 0])
+
+
+def test_native_component_merge_equals_simple_merge_consolidate_on_many_labels():
+    """kh_host_merge_components (Assembler.finish: every label of a volume in one native call -- runs of sorted vertices merged,
+    edge rows counting-sorted) against Skeleton.simple_merge(components).consolidate() (kimimaro/intake.py:587-593) on 300
+    labels with one to six disjoint components each, random forests as edges"""
+    from kimimaro_amd.intake import Assembler
+    from kimimaro_amd.skeleton import Skeleton
+    rng = np.random.default_rng(11)
+    shape = (64, 48, 40)
+    an = np.float32([16, 16, 40])
+    ncomp = 900
+    remap = {i + 1: int(rng.integers(1, 301)) for i in range(ncomp)}
+    asm = Assembler(shape, an, remap)
+    pool, pos = rng.permutation(int(np.prod(shape))), 0
+    for segid in rng.permutation(np.arange(1, ncomp + 1)):          # arrival order != component order
+        n = int(rng.integers(2, 120))
+        key = np.sort(pool[pos:pos + n])
+        pos += n
+        verts = np.stack([key // (48 * 40), (key // 40) % 48, key % 40], 1).astype(np.float32)
+        par = np.array([rng.integers(0, i) for i in range(1, n)])
+        e = np.stack([par, np.arange(1, n)], 1)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))].astype(np.uint32)
+        asm.skeletons[remap[int(segid)]].append((int(segid), verts, e, rng.random(n).astype(np.float32)))
+    out = asm.finish()
+    assert list(out) == list(asm.skeletons)
+    for orig, parts in asm.skeletons.items():
+        sk = [Skeleton(np.multiply(v, an, dtype=np.float32), e, radii=r, segid=orig) for _, v, e, r in sorted(parts, key=lambda p: p[0])]
+        want = Skeleton.simple_merge(sk).consolidate()
+        np.testing.assert_array_equal(out[orig].vertices, want.vertices)
+        np.testing.assert_array_equal(out[orig].edges, want.edges)
+        np.testing.assert_array_equal(out[orig].radii, want.radii)
+        assert out[orig].id == orig and out[orig].vertices.flags.owndata and out[orig].edges.dtype == np.uint32
