@@ -140,6 +140,7 @@ class Engine:
         # how many of the largest labels get such a workgroup: None = all of the second-stream launch in single-volume mode
         # (256 threads per label), none with 64 / 128 threads; a number = that many, whatever the thread count (the lanes)
         self.big_lds_labels = int(os.environ["KH_BIG_LDS_LABELS"]) if os.environ.get("KH_BIG_LDS_LABELS") else None
+        self.big_threads = int(os.environ.get("KH_BIG_THREADS", "0"))     # threads per label of that launch (0: trace_threads)
         # threads per label in the path loop (64, 128 or 256).  256 serves one volume best (its searches are 4 x as wide);
         # with volumes in flight 64 does: a label whose call runs on the heap emulation -- one wave for seconds -- then holds a
         # twelfth of a CU instead of a third, and the sweep's levels hold tens of events, not hundreds (kimimaro_amd.lanes
@@ -676,8 +677,8 @@ class Engine:
         # tasks are sorted by size, so the biggest labels (the tail of the run) are dispatched first; when the results
         # are consumed incrementally they go to a second stream and the others are collected while they still run
         n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
-        if self.big_lds_labels is not None:
-            n_large = min(n_large, int(self.big_lds_labels))
+        if self.big_lds_labels is not None:     # (also in a lane, whose split_slots is 0: the lane then uses a second stream)
+            n_large = int(min(self.big_lds_labels, np.count_nonzero(cnt >= self.split_min_voxels)))
         # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 / _128
         # ... | KH_TRACE_NO_GHOSTS | KH_TRACE_GHOST_PARANOID
         prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0) | \
@@ -690,6 +691,8 @@ class Engine:
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
             big_ok = self.trace_threads == 256 if self.big_lds_labels is None else True
             flags = prof | (64 if big and self.big_lds_heap and big_ok else 0)   # KH_TRACE_BIG_LDS_HEAP
+            if big and self.big_threads:          # the second-stream launch with a thread count of its own
+                flags = (flags & ~12) | {64: 4, 128: 8}.get(self.big_threads, 0)
             if timings is not None or self.time_kernels:
                 tstream = tstream if tstream is not None else t.cuda.current_stream(self.device)
                 ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
