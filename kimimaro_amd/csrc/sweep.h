@@ -116,6 +116,9 @@ typedef const KH_AS_LDS Sweep& SweepRef;   // the workgroup's record (LDS)
 #define SW_G_OR(p, v) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SW_G_AND(p, v) __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SW_G_MIN(p, v) __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#ifndef KH_SWEEP_LOOK
+#define KH_SWEEP_LOOK 1     /* sweep_claim13 reads sched[q] before its atomicMin (0: the atomic straight away, rounds 4-5) */
+#endif
 template <class T>
 __device__ __forceinline__ T sw_g_cas(KH_AS_GLOBAL T* p, T expect, T want) {      // returns the old value like atomicCAS
   __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -360,6 +363,34 @@ template <int K0>
 __device__ __forceinline__ uint32_t sweep_claim13(KH_AS_GLOBAL uint32_t* sched, int cb, int sx, int sxy, uint32_t v, uint32_t want,
                                                   const uint32_t (&rk)[13], uint32_t code) {
   uint32_t old[13];
+#if KH_SWEEP_LOOK
+  // A look before the atomic.  A voxel is handed the same deadline by about a dozen dying neighbours and only the first atomicMin
+  // lowers its word; the others are read-modify-writes that leave the line dirty for nothing (the path kernel wrote 138 GB per c3
+  // volume, a third of its traffic).  The words only go down within a call, so a coherent (L2) read that already shows a value <=
+  // ours decides like the atomic's return value would ("identical" and "a deadline at an earlier level" stay true whatever happens
+  // to the word later).  A read that shows a larger value is followed by the atomic WITHOUT return: two neighbours that die in the
+  // same level both push then -- an identical event is a no-op of the machine, only its slot is spent.
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    const int k = K0 + j;
+    int dx, dy, dz;
+    dir_delta(k, dx, dy, dz);
+    old[j] = 0u;
+    if ((want >> k) & 1u) old[j] = sweep_ld(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)]);
+  }
+  uint32_t keep = 0;
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    const int k = K0 + j;
+    int dx, dy, dz;
+    dir_delta(k, dx, dy, dz);
+    const uint32_t val = (rk[j] << cb) | code;
+    const bool lower = ((want >> k) & 1u) && val < old[j];
+    if (lower) (void)SW_G_MIN(&sched[v + (uint32_t)(dx + sx * dy + sxy * dz)], val);
+    keep |= (uint32_t)(lower || ((old[j] >> cb) == rk[j] && old[j] != val)) << k;
+  }
+  return keep & want;
+#else
 #pragma unroll
   for (int j = 0; j < 13; j++) {
     const int k = K0 + j;
@@ -375,6 +406,7 @@ __device__ __forceinline__ uint32_t sweep_claim13(KH_AS_GLOBAL uint32_t* sched, 
     keep |= (uint32_t)(val < old[j] || ((old[j] >> cb) == rk[j] && old[j] != val)) << (K0 + j);
   }
   return keep & want;
+#endif
 }
 
 // ---- candidate spill.  Four possible owners per voxel are the rule; a voxel near the bisector planes of several path vertices
