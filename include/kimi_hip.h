@@ -286,6 +286,22 @@ int kh_path_search(kh_label_t* task, int mode, const uint32_t* lists, const uint
                    uint64_t source, uint64_t target, uint32_t* path, int64_t path_capacity, uint32_t* path_length,
                    int voxel_graph, void* stream);
 
+/* ---- a7 as ARRAYS: dijkstra3d.parental_field(field, source) -> parents and dijkstra3d.path_from_parents(parents, target)
+ * (kimimaro/trace.py:155, 244).  The reference's caller edits the parents array between the two calls
+ * (`parents[tuple(root)] = 0`, trace.py:220), so it has to be a plain array the caller owns.
+ * kh_parental_field: the search of kh_path_search mode 1 (distances left in `dist`; task / lists / nbrmask / qstate / queues as
+ *   there) followed by the canonical predecessor rule on every voxel of the object (oracle ko_parental_field):
+ *   parents[v] = linear index of pred(v) + 1, 0 = none (the source, unreachable voxels, everything outside the object).
+ *   parents: u32 [sx*sy*sz], zeroed by the call.  A voxel whose achieving neighbours all lie at its own distance (float
+ *   absorption plateau) cannot be expressed as a pointer: task.status gets KH_ST_PLATEAU (like the oracle's KO_EPLATEAU).
+ * kh_path_from_parents: the pointer chase target -> ... -> a voxel whose entry is 0, written source first; *path_length = 0
+ *   when path_capacity is too small (or the caller's edits made a cycle).                                               */
+int kh_parental_field(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz,
+                      const float* field, float* dist, uint8_t* qstate, uint32_t* queues, uint64_t source,
+                      uint32_t* parents, int voxel_graph, void* stream);
+int kh_path_from_parents(const uint32_t* parents, int64_t nvox, uint64_t target, uint32_t* path, int64_t path_capacity,
+                         uint32_t* path_length, void* stream);
+
 /* ---- a3 / a5 / a6 as stand-alone operations (the path loop has them fused: kh_pdrf, kh_trace_paths) ----------------
  * kh_zero2inf / kh_inf2zero: skeletontricks.zero2inf / inf2zero (skeletontricks.pyx:177-224), in place.
  * kh_pdrf_field: compute_pdrf (kimimaro/trace.py:315-356) on every element: out = ((1 - dbf*M)^(2^log2_exponent)) * scale

@@ -826,9 +826,11 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
       sweep_stats[3] += sw->sh->events;
 #ifdef KH_SWEEP_PROBE
       if (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 1000 || blockIdx.x == 2500)
-        printf("SWCYC blk=%u nf=%u ok=%d lev=%u ev=%u commit=%llu next=%llu A=%llu cascA=%llu B=%llu cascB=%llu pairs=%llu\n", blockIdx.x, nf, (int)ok,
+        printf("SWCYC blk=%u nf=%u ok=%d lev=%u ev=%u commit=%llu next=%llu A=%llu cascA=%llu B=%llu cascB=%llu pairs=%llu "
+               "dn=%llu d_own=%llu d_alive=%llu d_rank=%llu d_sched=%llu d_casc=%llu d_push=%llu\n", blockIdx.x, nf, (int)ok,
                sw->sh->levels, sw->sh->events, sw->sh->cyc[0], sw->sh->cyc[1], sw->sh->cyc[2], sw->sh->cyc[3], sw->sh->cyc[6],
-               sw->sh->cyc[4], sw->sh->cyc[5]);
+               sw->sh->cyc[4], sw->sh->cyc[5], sw->sh->cyd[7], sw->sh->cyd[0], sw->sh->cyd[1], sw->sh->cyd[2], sw->sh->cyd[3],
+               sw->sh->cyd[4], sw->sh->cyd[5]);
 #endif
       if (!ok) { sweep_stats[1]++; sweep_stats[4] |= sw->sh->bail; sw->sh->nkg = 0u; sw->sh->nghost = 0u; }
       if (sw->sh->maxnev > task->cyc_pop) task->cyc_pop = sw->sh->maxnev;   // diagnostic: busiest level
@@ -1320,6 +1322,82 @@ __global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// a7 as arrays: dijkstra3d.parental_field(field, source) returns a parents ARRAY (linear index of the predecessor + 1, 0 = none)
+// which trace.py edits (`parents[tuple(root)] = 0`, kimimaro/trace.py:220) and hands to path_from_parents (:244).
+// parents_kernel: after the search of path_search_kernel mode 1 has left the distances in `dist`, one thread per voxel of the
+// object applies the canonical predecessor rule (oracle ko_pred: the neighbour u with fl(d[u] + f[v]) == d[v] minimising
+// (d[u], index of u)).  A voxel all of whose achieving neighbours lie at ITS OWN distance (a float-absorption plateau) has no
+// parent that a pointer chase could follow without cycles: KH_ST_PLATEAU, like the oracle's KO_EPLATEAU (the fused path loop and
+// kh_path_search mode 2 cross such plateaus by a breadth-first search; a parents array cannot say that).
+__global__ __launch_bounds__(256) void parents_kernel(kh_label_t* task, const uint32_t* __restrict__ lists,
+                                                      const uint32_t* __restrict__ nbrmask, Geometry g,
+                                                      const float* __restrict__ field, const float* __restrict__ dist,
+                                                      uint32_t source, uint32_t* parents, int graph) {
+  const uint32_t nf = task->count;
+  const uint32_t* list = lists + task->list_offset;
+  const uint32_t sx = (uint32_t)g.sx, sxy = (uint32_t)g.sxy;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
+    const uint32_t v = list[i];
+    const float dv = dist[v];
+    if (v == source || dv == KH_INF) { parents[v] = 0u; continue; }
+    const float fv = field[v];
+    const uint32_t nm = nbrmask[v];
+    const uint32_t z = v / sxy, r = v - z * sxy, y = r / sx, x = r - y * sx;
+    unsigned long long best = NONE64;
+    for (int k = 0; k < 26; k++) {
+      int dx, dy, dz;
+      sweep_dir(k, dx, dy, dz);
+      const int nx = (int)x + dx, ny = (int)y + dy, nz = (int)z + dz;
+      if (nx < 0 || ny < 0 || nz < 0 || nx >= g.sx || ny >= g.sy || nz >= g.sz) continue;
+      const uint32_t u = v + (uint32_t)(dx + (int)sx * dy + (int)sxy * dz);
+      bool edge;
+      if (!graph) {
+        edge = ((nm >> k) & 1u) != 0u;           // symmetric masks: v's own word serves
+      } else {
+        int opp = 0;                              // the step u -> v is gated by u's word (one-way edges)
+        for (int j = 0; j < 26; j++) {
+          int ex, ey, ez;
+          sweep_dir(j, ex, ey, ez);
+          if (ex == -dx && ey == -dy && ez == -dz) opp = j;
+        }
+        edge = ((nbrmask[u] >> opp) & 1u) != 0u;
+      }
+      if (!edge) continue;
+      const float du = dist[u];
+      if (du == KH_INF || du + fv != dv) continue;
+      const unsigned long long key = pack(du, u);
+      if (key < best) best = key;
+    }
+    if (best == NONE64) { parents[v] = 0u; continue; }
+    if (!(__uint_as_float((uint32_t)(best >> 32)) < dv)) { atomicOr(&task->status, KH_ST_PLATEAU); parents[v] = 0u; continue; }
+    parents[v] = (uint32_t)best + 1u;
+  }
+}
+
+// dijkstra3d.path_from_parents(parents, target) (kimimaro/trace.py:244): a pointer chase target -> source, returned source first.
+// One wave: lane 0 chases (a chain of dependent loads by nature), the wave reverses.
+__global__ __launch_bounds__(64) void path_from_parents_kernel(const uint32_t* __restrict__ parents, uint32_t nvox, uint32_t target,
+                                                               uint32_t* out, uint32_t cap, uint32_t* out_n) {
+  __shared__ uint32_t n_sh;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    uint32_t n = 0, v = target;
+    for (;;) {
+      if (n >= cap) { n = 0; break; }             // no room (or a cycle in a caller-edited array): empty path
+      out[n++] = v;
+      const uint32_t p = parents[v];
+      if (p == 0u || p > nvox) break;
+      v = p - 1u;
+    }
+    n_sh = n;
+  }
+  __syncthreads();
+  const uint32_t n = n_sh;
+  for (uint32_t i = lane; i < n / 2; i += 64) { const uint32_t a = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = a; }
+  if (lane == 0) *out_n = n;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a10: roll_invalidation_cube.  One workgroup per path vertex; bytes are cleared with a 32-bit
 // atomicAnd so each voxel is counted exactly once however many boxes overlap.
 __global__ __launch_bounds__(256) void invalidate_cube_kernel(uint8_t* mask, const float* __restrict__ dbf, int sx, int sy,
@@ -1572,6 +1650,42 @@ extern "C" int kh_invalidate_cube(uint8_t* mask, const float* dbf, int64_t sx, i
   if (npath <= 0) return KH_OK;
   hipLaunchKernelGGL(invalidate_cube_kernel, dim3((unsigned)npath), dim3(256), 0, st, mask, dbf, (int)sx, (int)sy, (int)sz, wx,
                      wy, wz, path, scale, constant, (unsigned long long*)invalidated);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_parental_field(kh_label_t* task, const uint32_t* lists, const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz,
+                                 const float* field, float* dist, uint8_t* qstate, uint32_t* queues, uint64_t source,
+                                 uint32_t* parents, int voxel_graph, void* stream) {
+  if (int rc2 = require_device()) return rc2;
+  if (!task || !lists || !nbrmask || !field || !dist || !qstate || !queues || !parents || sx * sy * sz >= (1ll << 32) ||
+      source >= (uint64_t)(sx * sy * sz) || ((uintptr_t)qstate & 3) != 0) {
+    set_error("kh_parental_field: bad arguments");
+    return KH_EINVAL;
+  }
+  Geometry g;
+  make_geometry(g, sx, sy, sz, 1.0f, 1.0f, 1.0f);     // (field costs: the edge lengths are not used)
+  hipStream_t st = (hipStream_t)stream;
+  KH_HIP_CHECK(hipMemsetAsync(parents, 0, (size_t)(sx * sy * sz) * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(path_search_kernel, dim3(1), dim3(256), 0, st, task, 1, lists, nbrmask, g, field, dist, qstate, queues,
+                     (uint32_t)source, 0u, (uint32_t*)nullptr, 0u, parents /* out_n: overwritten below */, voxel_graph);
+  KH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(parents_kernel, dim3(256), dim3(256), 0, st, task, lists, nbrmask, g, field, dist, (uint32_t)source, parents,
+                     voxel_graph);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_path_from_parents(const uint32_t* parents, int64_t nvox, uint64_t target, uint32_t* path, int64_t path_capacity,
+                                    uint32_t* path_length, void* stream) {
+  if (int rc2 = require_device()) return rc2;
+  if (!parents || !path || !path_length || nvox <= 0 || nvox >= (1ll << 32) || target >= (uint64_t)nvox || path_capacity <= 0 ||
+      path_capacity >= (1ll << 32)) {
+    set_error("kh_path_from_parents: bad arguments");
+    return KH_EINVAL;
+  }
+  hipLaunchKernelGGL(path_from_parents_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, parents, (uint32_t)nvox, (uint32_t)target,
+                     path, (uint32_t)path_capacity, path_length);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

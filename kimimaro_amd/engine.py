@@ -76,7 +76,7 @@ def plan_arena(cnt, nlev, filtered, window=None):
     if window is not None:
         window = np.asarray(window, dtype=np.int64)
         levels = np.where(window > 0, np.minimum(levels, window), levels)
-    chunks = np.minimum(levels + levels // 2 + ((per_voxel * cnt) >> shift) + 320, (1 << 22) - 2)
+    chunks = np.minimum(levels + levels // 2 + ((per_voxel * cnt) >> shift) + 320, (1 << 20) - 2)    # 20-bit chunk ids (SW_NOCHUNK)
     return shift, chunks
 
 

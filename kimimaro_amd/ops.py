@@ -252,22 +252,39 @@ def railroad(field, source, voxel_graph=None):
     return s.run(0, _loc(source, s.shape))
 
 
-class _Parents(_Search):
-    pass
-
-
 def parental_field(field, source, voxel_graph=None):
-    """dijkstra3d.parental_field(field, source) as called at kimimaro/trace.py:155.  The result is opaque to the caller
-    (the reference only hands it to path_from_parents): here the distance field of the search, resident on the device."""
-    p = _Parents(field, voxel_graph)
-    p.source = _loc(source, p.shape)
-    p.run(1, p.source)
-    return p
+    """dijkstra3d.parental_field(field, source) as called at kimimaro/trace.py:155: the parents ARRAY of the weighted Dijkstra
+    from `source` (uint32, the field's shape, Fortran order; entry = linear index of the predecessor + 1, 0 = none), which the
+    caller may edit (`parents[tuple(root)] = 0`, trace.py:220) before handing it to path_from_parents (kh_parental_field)."""
+    s = _Search(field, voxel_graph)
+    eng, ctx, t, P = s.eng, s.ctx, s.eng.torch, s.eng.ptr
+    sx, sy, sz = s.shape
+    d_par = eng.empty(sx * sy * sz, t.int32)
+    _abi.check(eng.lib.kh_parental_field(P(ctx["d_task"]), P(ctx["d_lists"]), P(ctx["d_nbr"]), sx, sy, sz, P(s.d_field), P(s.d_dist),
+                                         P(ctx["d_qstate"]), P(ctx["d_queues"]), _loc(source, s.shape), P(d_par), int(s.graph),
+                                         eng.stream()))
+    status = int(ctx["d_task"].cpu().numpy().view(_abi.LABEL_T)["status"][0])
+    if status:
+        raise _abi.KimiHipError("kh_parental_field: %s" % _abi.describe_status(status))
+    return d_par.cpu().numpy().view(np.uint32).reshape(s.shape, order="F").reshape(s.host_shape, order="F")
 
 
 def path_from_parents(parents, target):
-    """dijkstra3d.path_from_parents(parents, target) as called at kimimaro/trace.py:244: source -> target, (n, 3)."""
-    return parents.run(2, parents.source, _loc(target, parents.shape))
+    """dijkstra3d.path_from_parents(parents, target) as called at kimimaro/trace.py:244: the pointer chase from `target`
+    to the voxel whose entry is 0, returned source -> target as an (n, 3) array (kh_path_from_parents)."""
+    eng = engine()
+    t, P = eng.torch, eng.ptr
+    par = _f3(parents, np.uint32)
+    shape = par.shape
+    d_par = t.from_numpy(np.ascontiguousarray(par.reshape(-1, order="F")).view(np.int32)).to(eng.device)
+    cap = par.size
+    d_path = eng.empty(cap, t.int32)
+    d_n = t.zeros(1, dtype=t.int32, device=eng.device)
+    _abi.check(eng.lib.kh_path_from_parents(P(d_par), par.size, _loc(target, shape), P(d_path), cap, P(d_n), eng.stream()))
+    n = int(d_n.item())
+    if n == 0:
+        raise _abi.KimiHipError("kh_path_from_parents: the parents of the target do not lead to a voxel without a parent")
+    return _pts(d_path[:n].cpu().numpy().view(np.uint32), shape)
 
 
 def dijkstra(field, source, target, voxel_graph=None):
@@ -275,7 +292,10 @@ def dijkstra(field, source, target, voxel_graph=None):
     from `source` to `target` where entering a voxel costs its field value, as an (n, 3) array source first.  The same
     search as parental_field + path_from_parents (one weighted Dijkstra from the source, predecessor walk from the
     target); ties between equally cheap paths follow the canonical predecessor rule of DESIGN.md 3.3."""
-    return path_from_parents(parental_field(field, source, voxel_graph), target)
+    s = _Search(field, voxel_graph)
+    src = _loc(source, s.shape)
+    s.run(1, src)                                   # (the predecessor WALK crosses float-absorption plateaus, which a
+    return s.run(2, src, _loc(target, s.shape))     # parents array cannot express: DESIGN.md 3.3)
 
 
 def first_label(labels):

@@ -95,6 +95,43 @@ def test_trace_no_fix_branching_matches_oracle(eng, seed, an):
         np.testing.assert_array_equal(a, np.asarray(b, dtype=np.int64))
 
 
+@pytest.mark.parametrize("seed,an,params", TUBES)
+def test_parental_field_array_matches_oracle(eng, seed, an, params):
+    """dijkstra3d.parental_field as an ARRAY (kh_parental_field; SURVEY 8b, kimimaro/trace.py:155): parents = index + 1, 0 = none,
+    equal to the oracle's ko_parental_field word for word; the reference's own edit `parents[tuple(root)] = 0` (trace.py:220)
+    works on it, and path_from_parents (kh_path_from_parents, trace.py:244) chases it like the oracle's pointer chase."""
+    import oracle
+    from kimimaro_amd import ops
+    ops._engine = eng
+    m = biggest_component(random_walk_tube((48, 44, 40), 2000 + seed, steps=60, step=3.0, radius=(1.2, 5.0)))
+    dbf = oracle.edt(m, an)
+    src = oracle.first_label(m)
+    daf, far = oracle.euclidean_distance_field(m, src, an)
+    daf = oracle.inf2zero(daf.copy(order="F"))
+    pdrf = oracle.compute_pdrf(np.max(dbf), params["pdrf_scale"], params["pdrf_exponent"], oracle.zero2inf(dbf.copy(order="F")),
+                               daf, daf[far])
+    want = oracle.parental_field(pdrf, far)
+    got = ops.parental_field(pdrf, far)
+    assert isinstance(got, np.ndarray) and got.dtype == np.uint32 and got.shape == pdrf.shape
+    np.testing.assert_array_equal(got, want)
+    assert got[tuple(far)] == 0 and int((got != 0).sum()) == int(m.sum()) - 1
+    got[tuple(far)] = 0                                  # kimimaro/trace.py:220
+    idx = np.flatnonzero(m.ravel(order="F"))
+    rng = np.random.default_rng(seed)
+    for loc in rng.choice(idx, size=6, replace=False).tolist() + [int(oracle.loc_of(src, m.shape))]:
+        tgt = tuple(int(v) for v in oracle.locs_to_pts([loc], m.shape)[0])
+        a = ops.path_from_parents(got, tgt)
+        np.testing.assert_array_equal(a, oracle.path_from_parents(want, tgt))
+        assert tuple(a[0]) == tuple(far) and tuple(a[-1]) == tgt
+    # an edit by the caller is honoured: cutting the chain at a vertex makes that vertex the path's first point
+    tgt = tuple(int(v) for v in oracle.locs_to_pts([int(idx[-1])], m.shape)[0])
+    full = ops.path_from_parents(got, tgt)
+    if len(full) > 3:
+        cut = tuple(int(v) for v in full[len(full) // 2])
+        got[cut] = 0
+        np.testing.assert_array_equal(ops.path_from_parents(got, tgt), full[len(full) // 2:])
+
+
 def test_manual_targets_and_root(eng):
     """border-style forced root + extra targets before/after (intake.py:486-492, trace.py:225-228)."""
     import oracle
