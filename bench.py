@@ -524,8 +524,7 @@ def main():
             tk = ieng.last_tasks
             dump = os.environ.get("KIMI_BENCH_DUMP_TASKS")      # tools/strong_scaling_model.py reads this (per-label voxels and cycles)
             if dump and tk is not None:
-                np.savez_compressed(dump, **{k: tk[k] for k in ("segid", "count", "n_paths", "cyc_target", "cyc_rail", "cyc_inval",
-                                                                  "stat_heap_pushes", "stat_sweep_bails", "stat_rollbacks")})
+                np.savez_compressed(dump, **{k: tk[k] for k in tk.dtype.names})      # the whole task records (kh_label_t)
             state["retries"] = getattr(ieng, "last_retries", 0)
             state["path_kernel_ms"] = list(getattr(ieng, "last_path_kernel_ms", []))
             del i_cc

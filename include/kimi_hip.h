@@ -215,8 +215,14 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
  * gets in LDS (<= KH_SWEEP_LDS_LEVELS): a task keeps its words there when its lev_window (if non-zero) or else its nlev fits;
  * a task for which neither does runs all its invalidations as the heap emulation.  A task's arena = the candidate-spill table,
  * a free stack of ev_chunks u32 (each rounded up to 256 bytes), then the chunks.  level_rank == NULL switches the sweep off.
- * sched (nullable) = one u32 per voxel, 0xFFFFFFFF on entry for every voxel that is alive (and again on exit): the sweep's
- * pending-deadline filter (csrc/sweep.h) -- with it a voxel is handed ~1.3 events per call instead of ~13; NULL = unfiltered.
+ * sched = one u32 per voxel, 0xFFFFFFFF on entry: the sweep's filter words (csrc/sweep.h) -- the pending deadline of a live voxel
+ * (with it a voxel is handed ~1.3 events per call instead of ~13), 0 once the voxel is dead (the sweep reads its neighbours' state
+ * from these words, nine rows of three per event: the word BEFORE sched[0] and the word behind the last one must be readable).
+ * NULL switches the sweep off.
+ * Integer levels (round 6): level_rank == NULL and ra > 0 selects them -- (ra, rb, rc) = (wx^2, wy^2, wz^2) / gcd for an integral
+ * anisotropy whose squared distances stay exact in float over the balls' reach (kimimaro_amd.engine.int_key_mode checks it): the
+ * level of a key is then the integer key^2 / gcd itself, no table, no float operation per neighbour; task.nlev / lev_window count
+ * such integers.  level_rank == NULL and ra == 0: no sweep.
  * Ghosts: journal (nullable) = u32 scratch, 2 * q_capacity entries per task at 2 * q_offset; rail_save (nullable)
  * = f32 scratch laid out like path_vertices.  With both, a call of the sweep that leaves voxels undecided goes on with them as
  * "ghosts" instead of running the heap emulation at once; the label rolls back to that call and redoes it exactly only if a
@@ -237,6 +243,11 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
                                        call filled (NULL without a graph) */
 #define KH_TRACE_BIG_LDS_HEAP 64    /* two chunks (8191 nodes, 128 KiB) of every label's invalidation heap live in LDS: one workgroup
                                        per CU, for a launch of the few largest labels whose heap emulation sets the wall clock */
+#define KH_TRACE_SCRATCH_POOL 256   /* heap_nodes is ONE pool for the launch instead of a slice per label: node 0 = {u32 nodes handed out so
+                                       far (the caller sets 1), u32 nodes in the pool, -, -}; a label takes its heap (heap_capacity nodes) when
+                                       it first runs the heap emulation and its ghost journal ((2 * q_capacity + 3) / 4 nodes) when it first
+                                       makes a ghost; `journal` is ignored, heap_offset too.  A label the pool cannot serve ends with
+                                       KH_ST_HEAP_OVERFLOW (trace it again with a slice of its own) or goes on without ghosts. */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
 int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
                    const uint32_t* nbrmask,

@@ -59,6 +59,7 @@ struct Ctl {
   uint32_t red_cnt[16];
   float T;
   uint32_t u0, u1, u2, u3;
+  uint32_t pool_base;
   unsigned long long cyc3[3];
   Geometry g;  // the 26 offsets / edge lengths are indexed per lane: keep them in LDS, not in SGPRs
 };
@@ -535,10 +536,13 @@ __device__ __forceinline__ void heap_pop_wave(H& h, int lane) {
 
 // wave 0 only.  Returns the number of voxels invalidated.  PROF adds the pop / push / neighbour-test
 // cycle split (s_memtime waits on the scalar memory counter, so the production kernel leaves it out).
+// Out of line, the heap record by value: the emulation is ONE chain of dependent operations per call and every instruction the
+// register allocator adds to its loops (a reloaded pointer, a lane written to a spill register) is on that chain; as a function of
+// its own it is allocated for itself (inlined, 47 spilled VGPRs of the kernel cost it 8 %).
 template <bool PROF, class H>
-__device__ __forceinline__ uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
+__device__ __attribute__((noinline)) uint32_t invalidate_ball(const Geometry& g, const kh_label_t* task, const uint32_t* __restrict__ nbrmask,
                                     const float* __restrict__ dbf, uint8_t* alive, const uint32_t* path, uint32_t npath,
-                                    float scale, float constant, H& h, uint32_t* status, uint32_t* pushes,
+                                    float scale, float constant, H h, uint32_t* status, uint32_t* pushes,
                                     unsigned long long* cyc3, const uint8_t* __restrict__ corner_gate = nullptr) {
   const int lane = threadIdx.x & 63;
   unsigned long long c_pop = 0, c_push = 0, c_fire = 0, tt = 0;
@@ -785,7 +789,9 @@ __device__ __attribute__((noinline)) uint32_t backtrack(const Geometry& g, const
 
 // everything the order-free sweep needs besides the per-label task record
 struct SweepGlobal {
-  const uint32_t* rank;         // level table [ra * rb * rc], nullptr = sweep disabled
+  uint32_t on;                  // 0 = sweep disabled (every invalidation runs as the heap emulation)
+  uint32_t gq, gx, gy, gz;      // integer mode (sweep.h): key^2 = gq * (gx a^2 + gy b^2 + gz c^2); gq == 0: table mode
+  const uint32_t* rank;         // table mode: level table [ra * rb * rc]
   int ra, rb, rc;
   unsigned long long* cstate;   // one word per voxel, all zero on entry and on exit
   uint32_t* sched;              // one word per voxel (sweep.h, pending-deadline filter), SW_SCHED_NONE for live voxels; nullable
@@ -793,6 +799,30 @@ struct SweepGlobal {
   uint32_t lds_levels;          // labels with more levels keep their level words in the arena instead of LDS
   uint32_t heap_prio;           // != 0: the wave that runs the heap emulation raises its issue priority (s_setprio 3)
 };
+
+// Scratch on demand (round 6).  The heap of the exact emulation (16 B x 1.5 nodes per voxel) and the ghosts' journal (8 B per voxel)
+// were reserved for every label of a launch; 141 of c3's 3 402 labels ever run the emulation and 360 ever hold a ghost -- 4.6 GB per
+// volume in flight for 0.4 GB of use, and the volumes in flight are bounded by memory.  With KH_TRACE_SCRATCH_POOL `heap_nodes` is
+// ONE pool for the launch: node 0 = {nodes handed out so far (starts at 1), nodes in the pool}; a label takes what it needs when it
+// first needs it (one atomic add by one thread).  A label the pool cannot serve ends with KH_ST_HEAP_OVERFLOW (heap) -- the host
+// traces it again with scratch of its own, like every other overflow -- or goes on without ghosts (journal).
+// Whole workgroup; returns nullptr when the pool is exhausted.
+__device__ __forceinline__ hnode_t* pool_take(hnode_t* pool, uint32_t nodes, Ctl* ctl) {
+  if (threadIdx.x == 0) {
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(pool);
+    const uint32_t cap = hdr[1];
+    uint32_t base = 0u;
+    if (nodes != 0u && nodes < cap) {
+      base = atomicAdd(&hdr[0], nodes);
+      if (base + nodes > cap || base + nodes < base) base = 0u;
+    }
+    ctl->pool_base = base;
+  }
+  __syncthreads();
+  const uint32_t b = ctl->pool_base;
+  __syncthreads();
+  return b ? pool + b : nullptr;
+}
 
 // One invalidation call by the whole workgroup: the order-free sweep when the label has a level table and the sweep
 // certifies the call, the heap emulation (wave 0) otherwise.  Returns the number of voxels invalidated (ghosts that were killed
@@ -808,7 +838,7 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
                                                float scale, float constant, H& heap, const uint32_t* list, uint32_t nf,
                                                uint32_t* sweep_stats, uint32_t heap_prio, uint32_t* kill_log,
                                                bool allow_ghosts = false, bool force_heap = false, bool heap_ok = true,
-                                               const uint8_t* __restrict__ corner_gate = nullptr) {
+                                               const uint8_t* __restrict__ corner_gate = nullptr, hnode_t* pool = nullptr) {
   const int tid = threadIdx.x;
   bool ok = false;
   if (tid == 0) {
@@ -817,9 +847,10 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
     ctl->u0 = 0u;
   }
   __syncthreads();
-  if (!force_heap && sw->rank != nullptr && npath > 0 && npath <= 32766u && npath <= nf) {
-    uint32_t cnt = 0;
-    ok = sweep_ball(*(const KH_AS_LDS Sweep*)sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, &cnt, allow_ghosts);
+  if (!force_heap && sw->nlev != 0u && npath > 0 && npath <= 32766u && npath <= nf) {
+    const long long got = sweep_ball(*(const KH_AS_LDS Sweep*)sw, path, npath, dbf, scale, constant, task->sweep_rmax, list, nf, allow_ghosts);
+    ok = got >= 0;
+    const uint32_t cnt = ok ? (uint32_t)got : 0u;
     if (tid == 0) {
       sweep_stats[0]++;
       sweep_stats[2] += sw->sh->levels;
@@ -845,6 +876,15 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
     __syncthreads();
     return 0u;
   }
+  if (!ok && heap.node == nullptr) {
+    // the label's first call of the heap emulation: its heap comes out of the launch's pool now
+    heap.node = pool != nullptr ? pool_take(pool, heap.cap, ctl) : nullptr;
+    if (heap.node == nullptr) {
+      if (tid == 0) { ctl->status |= KH_ST_HEAP_OVERFLOW; ctl->u1 = 0u; }
+      __syncthreads();
+      return 0u;
+    }
+  }
   if (!ok) {
     __syncthreads();
     if (tid < 64) {
@@ -857,6 +897,12 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
       if (heap_prio) __builtin_amdgcn_s_setprio(0);
       if (tid == 0) ctl->u1 = c;
     }
+    // the sweep reads "dead" from the filter words: bring them in line with the mask the heap emulation has edited (a pass over the
+    // label's voxels by the whole workgroup, once per such call -- a store per kill inside the emulation would sit on its chain)
+    if (sw->sched != nullptr && sw->nlev != 0u) {
+      __syncthreads();
+      sweep_reset_words(*(const KH_AS_LDS Sweep*)sw, list, nf);
+    }
   }
   __syncthreads();
   const uint32_t c = ctl->u1;
@@ -867,48 +913,54 @@ __device__ __forceinline__ uint32_t invalidate(Ctl* ctl, Sweep* sw, kh_label_t* 
 // thread 0: fill the workgroup's Sweep record for `task` (LDS carve-out `lds` = the dynamic shared memory).  The kernel's
 // pointers get their address spaces here (sweep.h works on typed pointers only).
 __device__ __forceinline__ void sweep_setup(Sweep& sw, SweepShared* swsh, Ctl* ctl, const SweepGlobal& sg, const kh_label_t* task,
-                                            const uint32_t* nbrmask, uint8_t* alive, hnode_t* heap_node, uint32_t* killed,
+                                            const uint32_t* nbrmask, uint8_t* alive, const Queues& q, uint32_t* killed,
                                             uint32_t nf, unsigned char* lds, const uint8_t* corner_gate = nullptr) {
   typedef KH_AS_GLOBAL unsigned char gbyte_t;
-  const uint32_t nlev = task->nlev;
+  uint32_t nlev = (sg.on && sg.sched != nullptr) ? task->nlev : 0u;
   sw.g = (const KH_AS_LDS Geometry*)&ctl->g;
   sw.nbrmask = (const KH_AS_GLOBAL uint32_t*)nbrmask;
   sw.alive = (KH_AS_GLOBAL uint8_t*)alive;
   sw.cstate = (KH_AS_GLOBAL unsigned long long*)sg.cstate;
   sw.sched = (KH_AS_GLOBAL uint32_t*)sg.sched;
-  sw.rank = nlev ? (const KH_AS_GLOBAL uint32_t*)sg.rank : nullptr;
+  sw.gq = sg.gq; sw.gx = sg.gx; sw.gy = sg.gy; sw.gz = sg.gz;
+  sw.rank = (const KH_AS_GLOBAL uint32_t*)sg.rank;
   sw.ra = sg.ra; sw.rb = sg.rb;
-  // the heap's HBM slice (>= 11 * nf / 8 + 1536 nodes of 16 bytes) is free while the sweep runs: source records
-  // (<= nf), then the three lists of the level being processed (nf / 4 + 1024 entries each; a list that runs over
-  // abandons the call, SW_BAIL_LIST)
-  gbyte_t* hp = (gbyte_t*)heap_node;
-  sw.srcs = (KH_AS_GLOBAL u32x4_t*)hp;
-  sw.ncap = nf / 4u + 1024u;
-  sw.wa = (KH_AS_GLOBAL unsigned long long*)(hp + (size_t)nf * 16u);
-  sw.np = sw.wa + sw.ncap;
-  sw.wb = (KH_AS_GLOBAL uint32_t*)(sw.np + sw.ncap);
+  // The searches' work lists (four of q.cap >= nf + 64 words) are free while an invalidation runs: the first is the kill log, the
+  // fourth (`touched`) holds the source records, the two between them the three lists of the level being processed (20 bytes per
+  // entry of each; a list that runs over abandons the call, SW_BAIL_LIST; so do more path vertices than records fit).  Round 5 kept
+  // all of this in the label's heap slice, which since round 6 only exists once the label needs the heap emulation.
+  {
+    const uintptr_t t0 = ((uintptr_t)q.touched + 15u) & ~(uintptr_t)15u;
+    sw.srcs = (KH_AS_GLOBAL u32x4_t*)(gbyte_t*)t0;
+    sw.srcs_cap = (uint32_t)(((uintptr_t)(q.touched + q.cap) - t0) / 16u);
+    const uintptr_t b0 = ((uintptr_t)q.b + 7u) & ~(uintptr_t)7u;
+    sw.ncap = (uint32_t)(((uintptr_t)(q.b + 2u * (size_t)q.cap) - b0) / 20u);
+    sw.wa = (KH_AS_GLOBAL unsigned long long*)(gbyte_t*)b0;
+    sw.np = sw.wa + sw.ncap;
+    sw.wb = (KH_AS_GLOBAL uint32_t*)(sw.np + sw.ncap);
+  }
   // level words + non-empty bitmap live in LDS: a window of them (kh_label_t.lev_window), or one per level when that fits the
   // launch's allotment; a label for which neither does runs without the sweep (heap emulation only)
   const uint32_t win = task->lev_window;
   const bool windowed = win >= 64u && (win & (win - 1u)) == 0u && win <= sg.lds_levels;   // round-robin words
-  if (!windowed && nlev > sg.lds_levels) sw.rank = nullptr;
+  if (!windowed && nlev > sg.lds_levels) nlev = 0u;
   sw.nslots = windowed ? win : nlev;
   sw.wmask = windowed ? win - 1u : 0xFFFFFFFFu;
-  // arena: [spill table: ev_spill keys (u32) + ev_spill candidate words (u64)][free stack: one u32 per chunk][chunks]
+  // arena: [spill table: ev_spill keys (u32) + ev_spill candidate words (u64)][(free stack of rounds 4-5: unused)][chunks]
   gbyte_t* fsp = (gbyte_t*)(sg.arena + (size_t)task->ev_offset * 256u);
   const uint32_t spcap = task->ev_spill;          // 0 or a power of two
   sw.spcap = (spcap & (spcap - 1u)) == 0u ? spcap : 0u;
   sw.spc = (KH_AS_GLOBAL unsigned long long*)fsp;
   sw.spk = (KH_AS_GLOBAL uint32_t*)(fsp + (size_t)sw.spcap * 8u);
   fsp += (((size_t)sw.spcap * 12u) + 255u) & ~(size_t)255u;
-  sw.fs = (KH_AS_GLOBAL uint32_t*)fsp;
   sw.chunks = (KH_AS_GLOBAL u32x2_t*)(fsp + ((((size_t)task->ev_chunks * 4u) + 255u) & ~(size_t)255u));
   sw.chcap = task->ev_chunks;
   sw.shift = (int)task->ev_shift;
   sw.killed = (KH_AS_GLOBAL uint32_t*)killed;              // the search work lists are free during an invalidation
-  sw.nlev = nlev;
+  sw.nlev = nlev;                                          // 0: this label's invalidations run as the heap emulation
   sw.chain = (KH_AS_LDS uint32_t*)lds;
-  sw.words = sw.chain + SW_CHAIN;
+  sw.fs = sw.chain + SW_CHAIN;
+  sw.words = sw.fs + SW_RING;
   sw.lvbits = sw.words + sw.nslots;
   sw.sh = (KH_AS_LDS SweepShared*)swsh;
   sw.gate = (const KH_AS_GLOBAL uint8_t*)corner_gate;
@@ -963,7 +1015,8 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
   Heap<TOPL> heap;
-  heap.node = heap_nodes + task->heap_offset;
+  hnode_t* const pool = (ghost_mode & 8u) ? heap_nodes : nullptr;      // KH_TRACE_SCRATCH_POOL: heap and journal on demand
+  heap.node = pool ? nullptr : heap_nodes + task->heap_offset;
   heap.top = (lds_hnode_t*)heap_top;
   heap.cap = task->heap_capacity;
   heap.n = 0;
@@ -971,7 +1024,8 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   uint32_t* pverts = path_vertices + task->path_offset;
   uint32_t* plens = path_lengths + task->path_offset;
   float* psave = rail_save ? rail_save + task->path_offset : nullptr;        // the weight a path vertex had before it became a rail
-  uint32_t* journal = journal_buf ? journal_buf + (uint64_t)task->q_offset * 2 : nullptr;   // 2 * q_capacity entries
+  uint32_t* journal = (journal_buf && !pool) ? journal_buf + (uint64_t)task->q_offset * 2 : nullptr;   // 2 * q_capacity entries; pool: on demand
+  bool journal_off = false;            // the pool could not serve this label's journal: its ghost calls are rolled back at once
   const uint32_t pcap = task->path_capacity;
   const uint32_t root = task->root;
   const uint32_t* before = manual_targets + task->tgt_offset;
@@ -984,7 +1038,8 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   uint32_t npaths = 0, nverts = 0;
   unsigned long long t_target = 0, t_rail = 0, t_inval = 0, t0 = 0;
   // ghost mode: bit 0 = on, bit 1 = every call that makes a ghost is rolled back at once (tests of the roll-back itself)
-  const bool ghosts_on = (ghost_mode & 1u) != 0u && journal != nullptr && (psave != nullptr || !fix_branching) && sg.rank != nullptr;
+  const bool ghosts_on = (ghost_mode & 1u) != 0u && (journal != nullptr || pool != nullptr) && (psave != nullptr || !fix_branching) &&
+                         sg.on != 0u && sg.sched != nullptr;
   const bool paranoid = (ghost_mode & 2u) != 0u;
   const bool graph = (ghost_mode & 4u) != 0u;     // the neighbour masks carry a voxel graph: predecessor edges are one-way
   GhostState gs = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -992,7 +1047,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   if (tid == 0) {
     ctl.status = 0; ctl.u2 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, q.a, nf, heap_top, corner_gate);
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, q, q.a, nf, heap_top, corner_gate);
   }
   __syncthreads();
   // the spill table of the sweep starts all-free (the arena is uninitialised memory)
@@ -1004,7 +1059,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     valid -= invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, pverts, 1, task->soma_scale, task->soma_const,
-                                          heap, list, nf, sweep_stats, sg.heap_prio, q.a, false, false, true, corner_gate);   // trace.py:211 counts what is left
+                                          heap, list, nf, sweep_stats, sg.heap_prio, q.a, false, false, true, corner_gate, pool);   // trace.py:211 counts what is left
   }
   const uint32_t max_paths = task->max_paths ? task->max_paths : valid;  // trace.py:214-215
   if (nb + na >= max_paths) {                           // trace.py:217-218
@@ -1155,19 +1210,37 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
         gs.jpos = 0; gs.paths = npaths; gs.verts = nverts; gs.valid = valid; gs.nb = nb; gs.na = na;
       }
       const bool go_ghost = ghosts_on && !redo;
+      // the call's kill log: the journal once it exists and a ghost is alive; else the first work list (a call that makes the
+      // FIRST ghost has its log copied to the journal below -- most labels never need one)
+      const bool to_journal = go_ghost && journal != nullptr;
       const uint32_t killed = invalidate<PROF, Heap<TOPL>>(&ctl, &sw, task, nbrmask, dbf, alive, out, plen, scale, constant, heap,
-                                                          list, nf, sweep_stats, sg.heap_prio, go_ghost ? journal + gs.jpos : q.a,
-                                                          go_ghost, redo, gs.nghost == 0, corner_gate);
+                                                          list, nf, sweep_stats, sg.heap_prio, to_journal ? journal + gs.jpos : q.a,
+                                                          go_ghost, redo, gs.nghost == 0, corner_gate, pool);
       if (ctl.u0 != 0u) {
         rollback = true;                                   // the sweep abandoned the call while ghosts exist
       } else {
         const uint32_t made = swsh.nghost, gkilled = swsh.nkg;
         valid -= killed + made;                            // the voxels that are certainly valid
         if (go_ghost) {
+          if (made != 0u && journal == nullptr) {
+            // the label's first ghost: its journal comes out of the pool now and takes this call's log over
+            const uint32_t nlog = killed + gkilled + made;
+            __syncthreads();
+            journal = reinterpret_cast<uint32_t*>(pool_take(pool, (2u * q.cap + 3u) / 4u, &ctl));
+            if (journal != nullptr) {
+              for (uint32_t i = tid; i < nlog; i += nthr) journal[i] = q.a[i];
+            } else {
+              journal = q.a;                               // no room: this call is rolled back at once, from its own log
+              journal_off = true;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+          }
           gs.nghost += made;
           gs.nghost -= gkilled;
           gs.jpos = gs.nghost ? gs.jpos + killed + gkilled + made : 0u;
           if (made) n_ghost_calls++;
+          if (journal_off && gs.nghost) rollback = true;
         }
       }
       __syncthreads();                                     // (swsh / ctl are rewritten by the next call)
@@ -1186,6 +1259,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
       __syncthreads();
       npaths = gs.paths; nverts = gs.verts; valid = gs.valid; nb = gs.nb; na = gs.na;
       gs.nghost = 0; gs.jpos = 0;
+      if (journal_off) journal = nullptr;
       n_rollbacks++;
       redo = true;
       continue;
@@ -1232,7 +1306,9 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
 // ------------------------------------------------------------------------------------------------
 // a9 on its own: roll_invalidation_ball_inside_component (skeletontricks.pyx:373-418) for ONE object, the same device
 // routine the path loop uses (order-free sweep, heap emulation as the fall-back).
-__global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, const uint32_t* __restrict__ lists,
+// (the same register bound as the path kernel: the sweep's out-of-line functions are shared, and they inherit the bound of their
+// callers only when every kernel that reaches them has it)
+__global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void invalidate_ball_kernel(kh_label_t* task, const uint32_t* __restrict__ lists,
                                                               const uint32_t* __restrict__ nbrmask, Geometry g,
                                                               const float* __restrict__ dbf, uint8_t* alive, uint32_t* queues,
                                                               hnode_t* heap_nodes, const uint32_t* __restrict__ path, uint32_t npath,
@@ -1254,10 +1330,18 @@ __global__ __launch_bounds__(256) void invalidate_ball_kernel(kh_label_t* task, 
   if (tid == 0) {
     ctl.status = 0; ctl.u1 = 0; ctl.u3 = 0; ctl.cyc3[0] = ctl.cyc3[1] = ctl.cyc3[2] = 0; ctl.g = g;
     for (int i = 0; i < 5; i++) sweep_stats[i] = 0;
-    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, heap.node, queues + (uint64_t)task->q_offset * 4, nf, heap_top, corner_gate);
+    Queues q;
+    q.cap = task->q_capacity;
+    q.a = queues + (uint64_t)task->q_offset * 4;
+    q.b = q.a + q.cap;
+    q.c = q.b + q.cap;
+    q.touched = q.c + q.cap;
+    sweep_setup(sw, &swsh, &ctl, sg, task, nbrmask, alive, q, q.a, nf, heap_top, corner_gate);
   }
   __syncthreads();
   for (uint32_t i = tid; i < sw.spcap; i += blockDim.x) { sw.spk[i] = 0u; sw.spc[i] = 0ull; }   // (the arena is uninitialised memory)
+  // the filter words say which voxels of the caller's mask are dead (kh_trace_paths keeps them up to date itself)
+  if (sw.sched != nullptr) sweep_reset_words(*(const KH_AS_LDS Sweep*)&sw, lists + task->list_offset, nf);
   __syncthreads();
   const uint32_t c = invalidate<false, Heap<1>>(&ctl, &sw, task, nbrmask, dbf, alive, path, npath, scale, constant, heap,
                                                lists + task->list_offset, nf, sweep_stats, sg.heap_prio,
@@ -1475,6 +1559,38 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
 }
 
 namespace kh {
+// dynamic LDS of a workgroup that runs the sweep with `nlev` level words: chunk chain, free-chunk stack, level words, bitmap
+static size_t sweep_lds_bytes(uint32_t nlev) {
+  return ((size_t)SW_CHAIN + SW_RING + nlev + (nlev >> 5) + 2) * 4;
+}
+// The sweep's launch-wide arguments from the entry points' (level_rank, ra, rb, rc): a table of ranks [ra, rb, rc], or --
+// level_rank == NULL and ra > 0 -- integer mode with (gx, gy, gz) = (ra, rb, rc): the squared voxel pitches divided by their
+// greatest common divisor gq (checked here against wx, wy, wz).  Returns false on inconsistent arguments.
+static bool sweep_global(SweepGlobal& sg, const uint32_t* level_rank, int64_t ra, int64_t rb, int64_t rc, float wx, float wy, float wz,
+                         uint64_t* cstate, uint32_t* sched, void* event_arena, int64_t max_nlev) {
+  sg.on = 0u; sg.gq = sg.gx = sg.gy = sg.gz = 0u;
+  sg.rank = level_rank;
+  sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
+  sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
+  sg.sched = sched;
+  sg.arena = reinterpret_cast<unsigned char*>(event_arena);
+  sg.lds_levels = (uint32_t)max_nlev;
+  sg.heap_prio = 0u;
+  if (level_rank == nullptr && ra <= 0) return true;                    // sweep off
+  if (!cstate || !sched || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
+      ((uintptr_t)event_arena & 255) != 0)
+    return false;
+  if (level_rank == nullptr) {
+    const double qx = (double)wx * wx, qy = (double)wy * wy, qz = (double)wz * wz;
+    const double gq = qx / (double)ra;
+    if (!(gq >= 1.0) || gq != (double)(uint32_t)gq || gq * (double)rb != qy || gq * (double)rc != qz || qx > 4.0e9 || qy > 4.0e9 ||
+        qz > 4.0e9)
+      return false;
+    sg.gq = (uint32_t)gq; sg.gx = (uint32_t)ra; sg.gy = (uint32_t)rb; sg.gz = (uint32_t)rc;
+  }
+  sg.on = 1u;
+  return true;
+}
 template <bool PROF, int TOPL = 1>
 static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
@@ -1484,13 +1600,13 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
                         float* rail_save, uint32_t ghost_mode, const uint8_t* corner_gate) {
   if (count <= 0) return KH_OK;
   size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
-  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
-  if (sg.rank && swl > lds) lds = swl;
+  const size_t swl = sweep_lds_bytes(max_nlev);
+  if (sg.on && swl > lds) lds = swl;
   {
     // More than 48 KiB of dynamic LDS has to be allowed per kernel.  The attribute belongs to the function, not to the
     // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
     // launch can ask for -- so that a concurrent caller never lowers it under somebody else's launch.
-    const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
+    const size_t lds_max = sweep_lds_bytes(KH_SWEEP_LDS_LEVELS);
     KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_paths_kernel<PROF, TOPL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }
@@ -1541,32 +1657,26 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128 | KH_TRACE_NO_GHOSTS |
-                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP | KH_TRACE_VOXEL_GRAPH)) ||
+                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP | KH_TRACE_VOXEL_GRAPH | KH_TRACE_SCRATCH_POOL)) ||
       ((flags & KH_TRACE_THREADS_64) && (flags & KH_TRACE_THREADS_128))) {
     set_error("kh_trace_paths: unknown flags");
     return KH_EINVAL;
   }
   const unsigned nthreads = (flags & KH_TRACE_THREADS_64) ? 64u : (flags & KH_TRACE_THREADS_128) ? 128u : 256u;
-  if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
-                     ((uintptr_t)event_arena & 255) != 0)) {
-    set_error("kh_trace_paths: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
-    return KH_EINVAL;
-  }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
   SweepGlobal sg;
-  sg.rank = level_rank;
-  sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
-  sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
-  sg.sched = sched;
-  sg.arena = reinterpret_cast<unsigned char*>(event_arena);
-  sg.lds_levels = (uint32_t)max_nlev;
+  if (!sweep_global(sg, level_rank, ra, rb, rc, wx, wy, wz, cstate, sched, event_arena, max_nlev)) {
+    set_error("kh_trace_paths: sweep arguments (level table or integer-mode factors, cstate, sched, a 256-byte aligned event arena, max_nlev)");
+    return KH_EINVAL;
+  }
   sg.heap_prio = (flags & KH_TRACE_HEAP_PRIO) ? 1u : 0u;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = (flags & KH_TRACE_PROFILE) != 0;
   // ghosts need the journal (and, with rails, the saved weights); bit 1: roll every ghost call back at once
-  const uint32_t ghost_mode = (journal && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u) |
-                              ((flags & KH_TRACE_VOXEL_GRAPH) ? 4u : 0u);
+  const bool use_pool = (flags & KH_TRACE_SCRATCH_POOL) != 0;
+  const uint32_t ghost_mode = ((journal || use_pool) && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u) |
+                              ((flags & KH_TRACE_VOXEL_GRAPH) ? 4u : 0u) | (use_pool ? 8u : 0u);
   if (flags & KH_TRACE_BIG_LDS_HEAP)
     return launch_trace<false, 2>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                   scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,
@@ -1591,27 +1701,19 @@ extern "C" int kh_invalidate_ball(kh_label_t* task, const uint32_t* lists, const
     set_error("kh_invalidate_ball: bad arguments");
     return KH_EINVAL;
   }
-  if (level_rank && (!cstate || !event_arena || ra <= 0 || rb <= 0 || rc <= 0 || max_nlev < 0 || max_nlev > KH_SWEEP_LDS_LEVELS ||
-                     ((uintptr_t)event_arena & 255) != 0)) {
-    set_error("kh_invalidate_ball: level table given without cstate / a 256-byte aligned event arena, or max_nlev out of range");
-    return KH_EINVAL;
-  }
   Geometry g;
   make_geometry(g, sx, sy, sz, wx, wy, wz);
   SweepGlobal sg;
-  sg.rank = level_rank;
-  sg.ra = (int)ra; sg.rb = (int)rb; sg.rc = (int)rc;
-  sg.cstate = reinterpret_cast<unsigned long long*>(cstate);
-  sg.sched = sched;
-  sg.arena = reinterpret_cast<unsigned char*>(event_arena);
-  sg.lds_levels = (uint32_t)max_nlev;
-  sg.heap_prio = 0u;
+  if (!sweep_global(sg, level_rank, ra, rb, rc, wx, wy, wz, cstate, sched, event_arena, max_nlev)) {
+    set_error("kh_invalidate_ball: sweep arguments (level table or integer-mode factors, cstate, sched, a 256-byte aligned event arena, max_nlev)");
+    return KH_EINVAL;
+  }
   size_t lds = (size_t)(Heap<1>::TOP + 3) * sizeof(hnode_t);
-  const size_t swl = (size_t)SW_CHAIN * 4 + (size_t)max_nlev * 4 + ((size_t)(max_nlev >> 5) + 2) * 4;
-  if (level_rank && swl > lds) lds = swl;
+  const size_t swl = sweep_lds_bytes((uint32_t)max_nlev);
+  if (sg.on && swl > lds) lds = swl;
   {
     // (constant value: see launch_trace)
-    const size_t lds_max = (size_t)SW_CHAIN * 4 + (size_t)KH_SWEEP_LDS_LEVELS * 4 + ((size_t)(KH_SWEEP_LDS_LEVELS >> 5) + 2) * 4;
+    const size_t lds_max = sweep_lds_bytes(KH_SWEEP_LDS_LEVELS);
     KH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&invalidate_ball_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max > lds ? lds_max : lds)));
   }

@@ -34,6 +34,10 @@ def _torch():
 # c5 ran as three launches one after the other, 12.4 s of paths; as one launch it is 91 -> ~200 GB of HBM and half the time.
 SCRATCH_BYTES_PER_VOXEL = 110
 SCRATCH_BYTES_PER_LABEL = 2 << 20
+# Round 6: heap and ghost journal come out of one pool per launch, on demand (KH_TRACE_SCRATCH_POOL): this fraction of what all
+# labels together could ask for (c3: 141 of 3 402 labels ever run the heap emulation -- 6 % of the nodes --, 360 ever hold a ghost);
+# a label the pool cannot serve is traced again with scratch of its own, like every other overflow
+SCRATCH_POOL_FRACTION = 0.2
 
 
 def plan_launches(counts, budget):
@@ -76,7 +80,14 @@ def plan_arena(cnt, nlev, filtered, window=None):
     if window is not None:
         window = np.asarray(window, dtype=np.int64)
         levels = np.where(window > 0, np.minimum(levels, window), levels)
-    chunks = np.minimum(levels + levels // 2 + ((per_voxel * cnt) >> shift) + 320, (1 << 20) - 2)    # 20-bit chunk ids (SW_NOCHUNK)
+    chunks = levels + levels // 2 + ((per_voxel * cnt) >> shift) + 320
+    if window is not None:
+        # Round 6, measured on c3 (`cyc_push` of the task records = most chunks a label ever had in use): 0.41 x the window on average,
+        # 0.94 x at the 99th percentile, 1.21 x at most -- the chunks of a level go back to the label's free stack when the level is
+        # done, so what is in use is what is PENDING, and that is bounded by the window, not by the label's size.  The arena was
+        # 6.9 GB per c3 volume for 0.55 GB of use, and the volumes in flight are bounded by memory.
+        chunks = np.where(window > 0, np.minimum(chunks, window + window // 2 + 384), chunks)
+    chunks = np.minimum(chunks, (1 << 20) - 2)    # 20-bit chunk ids (SW_NOCHUNK)
     return shift, chunks
 
 
@@ -111,6 +122,42 @@ def level_windows(keys, anisotropy, nlev, lds_levels):
     return np.where((nlev > 0) & (win <= int(lds_levels)), win, 0).astype(np.uint32)
 
 
+def int_key_mode(anisotropy, rmax):
+    """(gq, gx, gy, gz) of the sweep's INTEGER levels (csrc/sweep.h) for balls up to `rmax`, or None when the table of ranks
+    has to serve.  With an integral anisotropy the flood's key of an offset (a, b, c) is sqrtf of the exact integer
+    T = (wx a)^2 + (wy b)^2 + (wz c)^2 as long as T < 2^24 (every product and partial sum is an integer below 2^24: no rounding
+    before the square root), and T = gq * S with gq = gcd(wx^2, wy^2, wz^2), S = gx a^2 + gy b^2 + gz c^2.  sqrtf is monotone; two
+    values of T that differ lie at least gq apart, i.e. their roots gq / (2 sqrt T) apart, which exceeds an ulp of sqrt T
+    (<= sqrt T * 2^-23) while T < gq * 2^22 -- taken with a factor two of margin.  Then S orders the keys and tells equal ones exactly as
+    the floats do, for every offset the sweep evaluates: the voxels of a ball and their neighbours (one step further out)."""
+    w = [float(np.float32(a)) for a in anisotropy]
+    if any(v < 1.0 or v != int(v) or v > 4096.0 for v in w) or not np.isfinite(rmax) or rmax <= 0:
+        return None
+    q = [int(v) * int(v) for v in w]
+    gq = int(np.gcd.reduce(q))
+    step = float(np.sqrt(sum(q)))
+    tmax = (float(rmax) + step) ** 2 * (1.0 + 1e-6)
+    if tmax >= 2.0 ** 24 or tmax >= gq * 2.0 ** 21:
+        return None
+    return gq, q[0] // gq, q[1] // gq, q[2] // gq
+
+
+def int_levels(anisotropy, gq, rmax, lds_levels):
+    """per label (numpy arrays over `rmax`): the number of integer levels a ball of that radius can touch and the level window
+    (a power of two above the number of levels an event can lie ahead of the level being processed, 0 when that does not fit
+    `lds_levels` words).  An event's level is S of a 26-neighbour of the processed voxel from a source whose key of that voxel is
+    not above the current one: at most ((d + step)^2 - d^2) / gq levels ahead for d up to the radius."""
+    rmax = np.asarray(rmax, dtype=np.float64)
+    w = [float(np.float32(a)) for a in anisotropy]
+    step = float(np.sqrt(sum(v * v for v in w)))
+    ok = np.isfinite(rmax) & (rmax > 0)
+    r = np.where(ok, rmax, 0.0)
+    nlev = np.where(ok, np.floor(r * r * (1.0 + 1e-6) / gq) + 2, 0).astype(np.int64)
+    ahead = np.ceil((2.0 * r * step + step * step) * (1.0 + 1e-6) / gq) + 2
+    win = np.maximum(64, 2 ** np.ceil(np.log2(np.maximum(ahead, 1))).astype(np.int64))
+    return nlev, np.where(ok & (win <= int(lds_levels)), win, 0).astype(np.int64)
+
+
 class Engine:
     def __init__(self, device=None):
         self.lib = _abi.require_gpu()
@@ -127,7 +174,11 @@ class Engine:
         self.split_slots = int(os.environ.get("KH_SPLIT_SLOTS", "256"))   # labels that go to the second stream (one big-LDS workgroup per CU) when results are consumed incrementally
         self.split_min_voxels = 16384       # ... if they have at least this many voxels
         self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
-        self.sweep_filter = os.environ.get("KH_SWEEP_FILTER", "1") != "0"   # pending-deadline filter of the sweep (A/B knob)
+        self.sweep_filter = True            # (the pending-deadline filter of the sweep is no longer optional: its words also say "dead")
+        # integer levels (csrc/sweep.h) whenever the anisotropy allows them; False: always the table of ranks (tests, A/B runs)
+        self.int_keys = os.environ.get("KH_SWEEP_INT_KEYS", "1") != "0"
+        # heap and ghost journal of a launch's labels from one pool, on demand (False: a slice per label, rounds 1-5)
+        self.scratch_pool = os.environ.get("KH_SCRATCH_POOL", "1") != "0"
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
         # ghosts: a call of the sweep that leaves voxels undecided goes on with them as ghosts instead of running
@@ -196,12 +247,40 @@ class Engine:
         """pointer of an optional tensor (None -> NULL)"""
         return C.c_void_p(t.data_ptr() if t is not None else 0)
 
+    SCHED_PAD = 4      # words in front of (and behind) the volume's filter words: the sweep reads rows of three around a voxel
+
     def sched_volume(self, nvox):
-        """the pending-deadline words of the invalidation sweep (csrc/sweep.h): one u32 per voxel, all ones; None when the
-        filter is switched off (`Engine.sweep_filter`, KH_SWEEP_FILTER=0: every event is pushed, as in rounds 2-3)."""
-        if not self.sweep_filter:
+        """the filter words of the invalidation sweep (csrc/sweep.h): one u32 per voxel, all ones ("alive, no deadline pending"),
+        with SCHED_PAD readable words on either side; hand `sched_ptr(t)` to the library."""
+        return self.torch.full((int(nvox) + 2 * self.SCHED_PAD,), -1, dtype=self.torch.int32, device=self.device)
+
+    def sched_ptr(self, t):
+        return C.c_void_p(t.data_ptr() + 4 * self.SCHED_PAD if t is not None else 0)
+
+    def sweep_levels(self, shape, anisotropy, rmax_t, cnt):
+        """The sweep's level arguments for labels with largest ball radii `rmax_t` (f32 array) and voxel counts `cnt`:
+        dict(rank_ptr, rdims, nlev, win, ok) -- integer mode (rank_ptr NULL, rdims = (gx, gy, gz)) when the anisotropy allows it
+        (int_key_mode), else the table of ranks (level_table); None when no label can use the sweep."""
+        rmax_t = np.asarray(rmax_t, dtype=np.float32)
+        finite = rmax_t[np.isfinite(rmax_t)]
+        if not finite.size or float(finite.max()) <= 0:
             return None
-        return self.torch.full((int(nvox),), -1, dtype=self.torch.int32, device=self.device)
+        top = float(finite.max())
+        mode = int_key_mode(anisotropy, top) if self.int_keys else None
+        if mode is not None:
+            gq, gx, gy, gz = mode
+            nlev, win = int_levels(anisotropy, gq, rmax_t.astype(np.float64), self.sweep_lds_levels)
+            ok = np.isfinite(rmax_t) & (rmax_t > 0) & (nlev <= _abi.SWEEP_MAX_LEVELS)
+            if not self.sweep_window:
+                win = np.zeros_like(win)
+            return {"d_rank": None, "rdims": (gx, gy, gz), "nlev": np.where(ok, nlev, 0), "win": np.where(ok, win, 0), "ok": ok}
+        d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, top)
+        nlev = np.searchsorted(keys, rmax_t, side="left").astype(np.int64)   # keys below the radius: levels 0..nlev-1
+        ok = np.isfinite(rmax_t) & (rmax_t <= covered) & (nlev <= _abi.SWEEP_MAX_LEVELS) & (nlev > 0)
+        nlev = np.where(ok, nlev, 0)
+        win = level_windows(keys, anisotropy, nlev, self.sweep_lds_levels).astype(np.int64) if self.sweep_window \
+            else np.zeros(nlev.shape, dtype=np.int64)
+        return {"d_rank": d_rank, "rdims": rdims, "nlev": nlev, "win": win, "ok": ok}
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -414,26 +493,27 @@ class Engine:
                    d_heap=self.empty(2 * hcap, t.int64), d_qstate=t.zeros(nvox + 4, dtype=t.uint8, device=self.device))
         d_rank, rdims, max_nlev, ev_units = None, (0, 0, 0), 0, 0
         rmax = float(np.float32(rmax))
+        sweep_on = False
         if self.sweep and cnt > 0 and np.isfinite(rmax) and rmax > 0:
-            d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, rmax)
-            nlev = int(np.searchsorted(keys, np.float32(rmax), side="left"))
-            if 0 < nlev <= _abi.SWEEP_MAX_LEVELS and rmax <= covered:
-                win = int(level_windows(keys, anisotropy, [nlev], self.sweep_lds_levels)[0]) if self.sweep_window else 0
-                shift, chunks = (int(v) for v in plan_arena(cnt, nlev, self.sweep_filter, win))
+            lv = self.sweep_levels(shape, anisotropy, [rmax], [cnt])
+            if lv is not None and int(lv["nlev"][0]) > 0:
+                nlev, win = int(lv["nlev"][0]), int(lv["win"][0])
+                shift, chunks = (int(v) for v in plan_arena(cnt, nlev, True, win))
                 in_lds = win > 0 or nlev <= self.sweep_lds_levels       # else: heap emulation only (the kernel decides the same)
                 spill = int(plan_spill(cnt))
-                ev_units = int(arena_units(chunks, shift, spill))   # spill table, free stack, chunks
+                ev_units = int(arena_units(chunks, shift, spill))   # spill table, (unused stack), chunks
                 task["nlev"], task["sweep_rmax"], task["ev_chunks"], task["ev_shift"] = nlev, np.float32(rmax), chunks, shift
                 task["ev_spill"] = spill
                 task["lev_window"] = win
                 max_nlev = win if win > 0 else (nlev if in_lds else 0)
-            else:
-                d_rank = None
+                d_rank, rdims = lv["d_rank"], lv["rdims"]
+                sweep_on = True
         d_arena = self.empty(max(ev_units, 1) * 32 + 32, t.int64)
         ctx.update(d_rank=d_rank, rdims=rdims, max_nlev=max_nlev, d_arena=d_arena,
                    arena_ptr=C.c_void_p((d_arena.data_ptr() + 255) & ~255),
-                   d_cstate=t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device),
-                   d_sched=self.sched_volume(nvox) if d_rank is not None else None,
+                   sweep_on=sweep_on,
+                   d_cstate=t.zeros(nvox if sweep_on else 1, dtype=t.int64, device=self.device),
+                   d_sched=self.sched_volume(nvox) if sweep_on else None,
                    d_task=t.from_numpy(task.view(np.uint8).reshape(-1).copy()).to(self.device), task=task)
         return ctx
 
@@ -446,14 +526,12 @@ class Engine:
         d_path = t.from_numpy(np.asarray(path_locs, dtype=np.uint32).view(np.int32).copy()).to(self.device)
         d_cnt = t.zeros(1, dtype=t.int64, device=self.device)
         rank_ptr = P(ctx["d_rank"]) if ctx["d_rank"] is not None else C.c_void_p(0)
-        rd = ctx["rdims"]
-        if ctx["d_sched"] is not None:
-            ctx["d_sched"].fill_(-1)      # the caller's mask may revive voxels an earlier call on this context killed
+        rd = ctx["rdims"] if ctx["sweep_on"] else (0, 0, 0)       # (the kernel derives the filter words from the caller's mask)
         _abi.check(self.lib.kh_invalidate_ball(P(ctx["d_task"]), P(ctx["d_lists"]), P(ctx["d_nbr"]), shape[0], shape[1], shape[2],
                                                float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(ctx["d_dbf"]),
                                                P(d_alive), P(ctx["d_queues"]), P(ctx["d_heap"]), P(d_path), int(d_path.numel()),
                                                np.float32(scale), np.float32(const), rank_ptr, rd[0], rd[1], rd[2], ctx["max_nlev"],
-                                               P(ctx["d_cstate"]), self.optr(ctx["d_sched"]), ctx["arena_ptr"],
+                                               P(ctx["d_cstate"]), self.sched_ptr(ctx["d_sched"]), ctx["arena_ptr"],
                                                self.optr(ctx.get("d_gate")), P(d_cnt), self.stream()))
         task = ctx["d_task"].cpu().numpy().view(_abi.LABEL_T).copy()
         if int(task["status"][0]):
@@ -515,9 +593,13 @@ class Engine:
         # heap: 3 nodes per voxel for small labels, 1.5 per voxel + 4096 for the others (the deepest heap of c3's largest
         # label holds 0.7 nodes per voxel); never less than the sweep's lists need (11 / 8 nodes per voxel + 1536)
         hbase = np.maximum((3 * cnt) // 2 + 4096, np.minimum(3 * cnt + 2048, 32768))
-        hcap = np.maximum(hbase * scratch_scale // self.scratch_divisor, (11 * cnt) // 8 + 1536)
+        hcap = np.maximum(hbase * scratch_scale // self.scratch_divisor, 64)
         h_off = np.concatenate([[0], np.cumsum(hcap)[:-1]]).astype(np.int64)
-        pcap = np.maximum(np.maximum(cnt // 2 + 1024, np.minimum(4 * cnt, 65536)) * scratch_scale // self.scratch_divisor, 8)
+        # path buffers: c3's labels write 527 vertices at most, 3 % of their voxels at most (round 5 kept 64 Ki entries for every label
+        # above 16 Ki voxels: 2 GB per volume); a label that needs more is traced again with `scratch_scale` x 8
+        pcap = np.maximum((cnt // 16 + 2048) * scratch_scale // self.scratch_divisor, 8)
+        # first attempt: heap and journal from a pool (engine.SCRATCH_POOL_FRACTION); retries and test runs with shrunk scratch: slices
+        use_pool = self.scratch_pool and scratch_scale == 1 and self.scratch_divisor == 1 and nl > 8
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
         if max(total, int(qcap.sum()), int(hcap.sum()), int(pcap.sum())) >= 2 ** 32:
             raise ValueError("kimimaro_amd: scratch offsets exceed 32 bits; shard the labels")
@@ -547,24 +629,19 @@ class Engine:
         # order-free invalidation sweep: level table + per-label event arenas
         d_rank, rdims, max_nlev = None, (0, 0, 0), 0
         ev_total = 0
+        sweep_on = False
         if self.sweep and nl > 0:
             rmax_t = (np.float32(params["scale"]) * dm + np.float32(params["const"])).astype(np.float32)   # f32 ops as pyx:393-395
-            finite = rmax_t[np.isfinite(rmax_t)]
-            if finite.size and float(finite.max()) > 0:
-                d_rank, rdims, keys, covered = self.level_table(shape, anisotropy, float(finite.max()))
-                nlev = np.searchsorted(keys, rmax_t, side="left").astype(np.int64)   # keys below the radius: levels 0..nlev-1
-                ok = np.isfinite(rmax_t) & (rmax_t <= covered) & (nlev <= _abi.SWEEP_MAX_LEVELS) & (nlev > 0)
-                nlev = np.where(ok, nlev, 0)
-                # fixed-size event chunks, chained per level (csrc/sweep.h): one partly filled chunk per level that is
-                # ever used + about 12 events per voxel, with slack
-                win = level_windows(keys, anisotropy, nlev, self.sweep_lds_levels).astype(np.int64) if self.sweep_window \
-                    else np.zeros(nl, dtype=np.int64)
+            lv = self.sweep_levels(shape, anisotropy, rmax_t, cnt)
+            if lv is not None and int(lv["nlev"].max()) > 0:
+                nlev, win, ok = lv["nlev"], lv["win"], lv["ok"]
                 if self.window_cap:
                     win = np.where(win > 0, np.minimum(win, int(self.window_cap)), win)
-                shift, chunks = plan_arena(cnt, nlev, self.sweep_filter, win)
+                # fixed-size event chunks, chained per level (csrc/sweep.h): what is pending at one time
+                shift, chunks = plan_arena(cnt, nlev, True, win)
                 chunks = np.maximum(chunks // int(self.arena_divisor), 8)
                 in_lds = (win > 0) | (nlev <= self.sweep_lds_levels)   # the others: heap emulation only (the kernel decides the same)
-                # [spill table, 12 B per entry][free stack, 4 B per chunk][chunks]
+                # [spill table, 12 B per entry][(the free stack of rounds 4-5, 4 B per chunk: unused since round 6)][chunks]
                 spill = plan_spill(cnt)
                 units = np.where((nlev > 0) & in_lds, arena_units(chunks, shift, spill), 0)
                 ev_off = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.int64)
@@ -578,11 +655,11 @@ class Engine:
                 tasks["ev_chunks"] = np.where(nlev > 0, chunks, 0)
                 tasks["ev_shift"] = shift
                 tasks["ev_spill"] = np.where((nlev > 0) & in_lds, spill, 0)
-                if int(nlev.max()) == 0:
-                    d_rank = None
                 tasks["lev_window"] = win
                 in_words = np.where(win > 0, win, np.where(in_lds, nlev, 0))     # LDS words each label wants
                 max_nlev = int(in_words.max()) if in_words.size else 0
+                d_rank, rdims = lv["d_rank"], lv["rdims"]
+                sweep_on = True
         tgt = []
         tgt_off = np.zeros(nl, dtype=np.int64)
         for s, o in enumerate(order):
@@ -660,17 +737,24 @@ class Engine:
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
-        d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
-        d_cstate = t.zeros(nvox if d_rank is not None else 1, dtype=t.int64, device=self.device)
-        d_sched = self.sched_volume(nvox) if d_rank is not None else None
+        jnodes = (2 * qcap + 3) // 4                        # a label's ghost journal in 16-byte nodes
+        if use_pool:
+            pool_nodes = int(max(SCRATCH_POOL_FRACTION * float((hcap + jnodes).sum()), 2 * float((hcap + jnodes).max()))) + 1
+            pool_nodes = min(pool_nodes, 2 ** 32 - 2)
+            d_heap = self.empty(2 * pool_nodes, t.int64)   # 16-byte nodes; node 0 = {handed out, capacity}
+            d_heap[:2] = t.from_numpy(np.array([1, pool_nodes, 0, 0], dtype=np.uint32).view(np.int64)).to(self.device)
+        else:
+            d_heap = self.empty(2 * int(hcap.sum()), t.int64)  # 16-byte nodes
+        d_cstate = t.zeros(nvox if sweep_on else 1, dtype=t.int64, device=self.device)
+        d_sched = self.sched_volume(nvox) if sweep_on else None
         d_arena = self.empty(max(ev_total, 1) * 32 + 32, t.int64)   # units of 256 bytes, 256-byte aligned start
         arena_ptr = C.c_void_p((d_arena.data_ptr() + 255) & ~255)
         d_pverts = self.empty(int(pcap.sum()), t.int32)
         d_plens = self.empty(int(pcap.sum()), t.int32)
         # ghosts: the journal of the voxels that changed since the call that made the first ghost (2 entries per voxel of a
         # label at most: made a ghost, killed) and the weights the path vertices had before they became rails
-        use_ghosts = self.ghosts and d_rank is not None
-        d_journal = self.empty(2 * int(qcap.sum()), t.int32) if use_ghosts else None
+        use_ghosts = self.ghosts and sweep_on
+        d_journal = self.empty(2 * int(qcap.sum()), t.int32) if use_ghosts and not use_pool else None
         d_psave = self.empty(int(pcap.sum()), t.float32) if use_ghosts and fix_branching else None
         if use_ghosts and not fix_branching:
             d_psave = None
@@ -684,13 +768,15 @@ class Engine:
         prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0) | \
             (0 if use_ghosts else 16) | (32 if use_ghosts and self.ghost_paranoid else 0)
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
+        if not sweep_on:
+            rdims = (0, 0, 0)
 
         kernel_events = []     # (first, count, start, end): HIP events on the stream each path-loop launch went to (timings only)
 
         def launch(first, count, stream, tstream=None, big=False):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
             big_ok = self.trace_threads == 256 if self.big_lds_labels is None else True
-            flags = prof | (64 if big and self.big_lds_heap and big_ok else 0)   # KH_TRACE_BIG_LDS_HEAP
+            flags = prof | (64 if big and self.big_lds_heap and big_ok else 0) | (256 if use_pool else 0)   # KH_TRACE_BIG_LDS_HEAP, _SCRATCH_POOL
             if big and self.big_threads:          # the second-stream launch with a thread count of its own
                 flags = (flags & ~12) | {64: 4, 128: 8}.get(self.big_threads, 0)
             if timings is not None or self.time_kernels:
@@ -702,7 +788,7 @@ class Engine:
                                           P(d_dbf), P(d_pdrf), P(d_dist), P(d_alive), P(d_qstate), P(d_tgt),
                                           np.float32(params["scale"]), np.float32(params["const"]), P(d_queues), P(d_heap),
                                           P(d_pverts), P(d_plens), rank_ptr, rdims[0], rdims[1], rdims[2], max_nlev,
-                                          P(d_cstate), self.optr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
+                                          P(d_cstate), self.sched_ptr(d_sched), arena_ptr, self.optr(d_journal), self.optr(d_psave),
                                           self.optr(d_gate), flags | (128 if d_gate is not None else 0), int(bool(fix_branching)), stream))
             if timings is not None or self.time_kernels:
                 kernel_events[-1][3].record(kernel_events[-1][4])

@@ -319,10 +319,10 @@ def test_skeletonize_sweep_and_heap_paths(sweep, slots):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
-@pytest.mark.parametrize("variant", ["threads64", "threads128", "unfiltered", "no_window", "tiny_arena", "narrow_window"])
+@pytest.mark.parametrize("variant", ["threads64", "threads128", "table_keys", "no_window", "tiny_arena", "narrow_window"])
 def test_sweep_storage_variants_and_their_bails(variant):
     """Round-4 storage of the sweep (pending-deadline filter, level window, recycled chunks) and its knobs: one wave / two
-    waves per label, the filter off, the window off, an arena a 64th of its size (calls run out of chunks: SW_BAIL_ARENA) and a
+    waves per label, levels from the table of ranks (the fallback of round 6's integer levels), the window off, an arena a 64th of its size (calls run out of chunks: SW_BAIL_ARENA) and a
     window of 64 levels (events land beyond it: SW_BAIL_LEVEL).  A bail is a matter of speed: the skeletons are the oracle's."""
     import kimimaro_amd
     from kimimaro_amd.engine import Engine
@@ -332,8 +332,8 @@ def test_sweep_storage_variants_and_their_bails(variant):
         eng2.trace_threads = 64
     elif variant == "threads128":
         eng2.trace_threads = 128
-    elif variant == "unfiltered":
-        eng2.sweep_filter = False
+    elif variant == "table_keys":
+        eng2.int_keys = False             # the table of ranks instead of the integer levels an integral anisotropy allows
     elif variant == "no_window":
         eng2.sweep_window = False
     elif variant == "tiny_arena":

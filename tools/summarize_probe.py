@@ -8,6 +8,8 @@ for line in open(sys.argv[1]):
     if not line.startswith("SWCYC"):
         continue
     kv = dict(re.findall(r"(\w+)=(\d+)", line))
+    if "nf" not in kv or "d_casc" not in kv:      # (a line cut short by another writer)
+        continue
     b = (kv["blk"], kv["nf"])
     for k, v in kv.items():
         if k not in ("blk", "nf"):
@@ -19,4 +21,4 @@ for b, v in sorted(acc.items(), key=lambda x: int(x[0][0])):
     print("block", b, "calls", v["calls"], "certified", v["ok"], "levels", v["lev"], "events", v["ev"],
           "cycles/level:", {k: round(v[k] / lv) for k in ("commit", "next", "A", "cascA", "B", "cascB", "pairs")})
     print("      thread 0's deadline events", v["dn"], "cycles/event:",
-          {k: round(v[k] / dn) for k in ("d_own", "d_alive", "d_rank", "d_sched", "d_casc", "d_push")})
+          {k: round(v[k] / dn) for k in ("d_own", "d_alive", "d_rank", "d_sched", "d_casc")})
