@@ -61,7 +61,7 @@ import numpy as np
 
 # one hardware queue per lane stream (up to 12 lanes + RCCL): with the default of 4, a fifth stream shares a queue and its kernels wait for the
 # seconds-long path kernel queued before them (profiles/r02b_inflight_timeline.txt)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -199,9 +199,10 @@ def volume_step(e, st):
     orig = st["flat"][rep_[1:].astype(np.int64)]
     remapping = {i + 1: orig[i].item() for i in range(nlabels)}
     cc = intake.LazyVolume(e, d_cc, lab.shape)
+    del d_cc                           # (reached through `cc`, which lets go of the u32 ids as soon as the u16 copy serves)
     empty = defaultdict(list)
     out = intake.skeletonize_cc(e, cc, nlabels, remapping, st["params"], st["an"], st["dust"], True, st["fix_borders"],
-                                empty, empty, black_border=False, rank=st["shard"][0], world=st["shard"][1], d_cc=d_cc, timings=tm)
+                                empty, empty, black_border=False, rank=st["shard"][0], world=st["shard"][1], timings=tm)
     if log is not None:
         tm.append(("end", time.perf_counter()))
         log.append(tm)

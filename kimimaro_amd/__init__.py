@@ -7,7 +7,7 @@ MI355X raises HipUnavailableError (there is deliberately no CPU fallback).
 import os as _os
 
 # one hardware queue per stream of the lanes (kimimaro_amd/lanes.py): the HIP runtime reads this once, at its first call
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 from ._abi import HipUnavailableError, KimiHipError  # noqa: F401
 from .intake import DEFAULT_TEASAR_PARAMS, DimensionError, skeletonize  # noqa: F401

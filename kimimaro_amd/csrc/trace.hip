@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
     bool rollback = false;
     uint32_t plen = 0;
     uint32_t* out = pverts + nverts;
-    if (gs.nghost > 0 && (valid == 0 || paranoid)) rollback = true;   // nothing certainly valid is left, but ghosts are
+    if (gs.nghost > 0 && (valid == 0 || paranoid || journal_off)) rollback = true;   // nothing certainly valid is left, but ghosts are
     if (!rollback && !redo) {
       if (!(valid > 0 || nb > 0 || na > 0)) break;
       // ---- target selection, trace.py:225-230
@@ -1226,12 +1226,12 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
             // the label's first ghost: its journal comes out of the pool now and takes this call's log over
             const uint32_t nlog = killed + gkilled + made;
             __syncthreads();
-            journal = reinterpret_cast<uint32_t*>(pool_take(pool, (2u * q.cap + 3u) / 4u, &ctl));
+            journal = journal_off ? nullptr : reinterpret_cast<uint32_t*>(pool_take(pool, (2u * q.cap + 3u) / 4u, &ctl));
             if (journal != nullptr) {
               for (uint32_t i = tid; i < nlog; i += nthr) journal[i] = q.a[i];
             } else {
-              journal = q.a;                               // no room: this call is rolled back at once, from its own log
-              journal_off = true;
+              journal = q.a;                               // no room: this call is rolled back from its own log, at the top of the
+              journal_off = true;                          // next iteration (its path has to be on record first: plens[npaths])
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
@@ -1240,7 +1240,6 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
           gs.nghost -= gkilled;
           gs.jpos = gs.nghost ? gs.jpos + killed + gkilled + made : 0u;
           if (made) n_ghost_calls++;
-          if (journal_off && gs.nghost) rollback = true;
         }
       }
       __syncthreads();                                     // (swsh / ctl are rewritten by the next call)

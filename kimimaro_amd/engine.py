@@ -37,7 +37,7 @@ SCRATCH_BYTES_PER_LABEL = 2 << 20
 # Round 6: heap and ghost journal come out of one pool per launch, on demand (KH_TRACE_SCRATCH_POOL): this fraction of what all
 # labels together could ask for (c3: 141 of 3 402 labels ever run the heap emulation -- 6 % of the nodes --, 360 ever hold a ghost);
 # a label the pool cannot serve is traced again with scratch of its own, like every other overflow
-SCRATCH_POOL_FRACTION = 0.2
+SCRATCH_POOL_FRACTION = float(os.environ.get("KH_SCRATCH_POOL_FRACTION", "0.15"))
 
 
 def plan_launches(counts, budget):
@@ -86,7 +86,7 @@ def plan_arena(cnt, nlev, filtered, window=None):
         # 0.94 x at the 99th percentile, 1.21 x at most -- the chunks of a level go back to the label's free stack when the level is
         # done, so what is in use is what is PENDING, and that is bounded by the window, not by the label's size.  The arena was
         # 6.9 GB per c3 volume for 0.55 GB of use, and the volumes in flight are bounded by memory.
-        chunks = np.where(window > 0, np.minimum(chunks, window + window // 2 + 384), chunks)
+        chunks = np.where(window > 0, np.minimum(chunks, window + window // 4 + 320), chunks)
     chunks = np.minimum(chunks, (1 << 20) - 2)    # 20-bit chunk ids (SW_NOCHUNK)
     return shift, chunks
 
@@ -173,12 +173,13 @@ class Engine:
         self._side = None     # second stream: the biggest labels run there while the others are collected
         self.split_slots = int(os.environ.get("KH_SPLIT_SLOTS", "256"))   # labels that go to the second stream (one big-LDS workgroup per CU) when results are consumed incrementally
         self.split_min_voxels = 16384       # ... if they have at least this many voxels
-        self.sweep = True                   # False: every invalidation runs as the heap emulation (tests, comparisons)
+        self.sweep = os.environ.get("KH_SWEEP", "1") != "0"   # False: every invalidation runs as the heap emulation (tests, comparisons)
         self.sweep_filter = True            # (the pending-deadline filter of the sweep is no longer optional: its words also say "dead")
         # integer levels (csrc/sweep.h) whenever the anisotropy allows them; False: always the table of ranks (tests, A/B runs)
         self.int_keys = os.environ.get("KH_SWEEP_INT_KEYS", "1") != "0"
         # heap and ghost journal of a launch's labels from one pool, on demand (False: a slice per label, rounds 1-5)
         self.scratch_pool = os.environ.get("KH_SCRATCH_POOL", "1") != "0"
+        self.scratch_pool_fraction = SCRATCH_POOL_FRACTION      # tests: a pool too small for the labels that ask (they are traced again)
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
         # ghosts: a call of the sweep that leaves voxels undecided goes on with them as ghosts instead of running
@@ -341,7 +342,7 @@ class Engine:
     def narrow(self, d_cc):
         """(device label volume, bytes per label) to sweep over: the u16 copy kh_ccl26 made of `d_cc` when there is one."""
         nr = getattr(self, "_narrow", None)
-        if nr is not None and nr[0] is d_cc:
+        if nr is not None and nr[0] is d_cc and d_cc is not None:
             return nr[1], 2
         return d_cc, 4
 
@@ -599,7 +600,7 @@ class Engine:
         # above 16 Ki voxels: 2 GB per volume); a label that needs more is traced again with `scratch_scale` x 8
         pcap = np.maximum((cnt // 16 + 2048) * scratch_scale // self.scratch_divisor, 8)
         # first attempt: heap and journal from a pool (engine.SCRATCH_POOL_FRACTION); retries and test runs with shrunk scratch: slices
-        use_pool = self.scratch_pool and scratch_scale == 1 and self.scratch_divisor == 1 and nl > 8
+        use_pool = self.scratch_pool and scratch_scale == 1 and self.scratch_divisor == 1 and nl >= 4
         p_off = np.concatenate([[0], np.cumsum(pcap)[:-1]]).astype(np.int64)
         if max(total, int(qcap.sum()), int(hcap.sum()), int(pcap.sum())) >= 2 ** 32:
             raise ValueError("kimimaro_amd: scratch offsets exceed 32 bits; shard the labels")
@@ -739,7 +740,8 @@ class Engine:
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
         jnodes = (2 * qcap + 3) // 4                        # a label's ghost journal in 16-byte nodes
         if use_pool:
-            pool_nodes = int(max(SCRATCH_POOL_FRACTION * float((hcap + jnodes).sum()), 2 * float((hcap + jnodes).max()))) + 1
+            frac = float(self.scratch_pool_fraction)
+            pool_nodes = int(max(frac * float((hcap + jnodes).sum()), (2 if frac >= 0.05 else 0) * float((hcap + jnodes).max()))) + 1
             pool_nodes = min(pool_nodes, 2 ** 32 - 2)
             d_heap = self.empty(2 * pool_nodes, t.int64)   # 16-byte nodes; node 0 = {handed out, capacity}
             d_heap[:2] = t.from_numpy(np.array([1, pool_nodes, 0, 0], dtype=np.uint32).view(np.int64)).to(self.device)
@@ -770,6 +772,15 @@ class Engine:
         rank_ptr = P(d_rank) if d_rank is not None else C.c_void_p(0)
         if not sweep_on:
             rdims = (0, 0, 0)
+
+        if os.environ.get("KH_DEBUG_ALLOC") == "1":      # developer knob: where every array of this call lives (to place a fault address)
+            for name, tt in (("tasks", d_tasks), ("lists", d_lists), ("nbr", d_nbr), ("queues", d_queues), ("qstate", d_qstate),
+                             ("ldaf", d_ldaf), ("pdrf", d_pdrf), ("dist", d_dist), ("alive", d_alive), ("heap", d_heap),
+                             ("cstate", d_cstate), ("sched", d_sched), ("arena", d_arena), ("pverts", d_pverts), ("plens", d_plens),
+                             ("journal", d_journal), ("psave", d_psave), ("dbf", d_dbf), ("cc", d_cc), ("tgt", d_tgt)):
+                if tt is not None:
+                    print("KHALLOC %-8s %#x .. %#x (%d B)" % (name, tt.data_ptr(), tt.data_ptr() + tt.numel() * tt.element_size(),
+                                                             tt.numel() * tt.element_size()), file=sys.stderr, flush=True)
 
         kernel_events = []     # (first, count, start, end): HIP events on the stream each path-loop launch went to (timings only)
 

@@ -12,6 +12,8 @@ There is no CPU fallback: without libkimi_hip.so + an MI355X this raises HipUnav
 """
 from __future__ import annotations
 
+import os
+
 from collections import defaultdict
 
 import numpy as np
@@ -117,6 +119,12 @@ class LazyVolume:
         return (e.face(d, s, 2, 0), e.face(d, s, 2, s[2] - 1), e.face(d, s, 1, 0), e.face(d, s, 1, s[1] - 1),
                 e.face(d, s, 0, 0), e.face(d, s, 0, s[0] - 1))
 
+    def release_device(self):
+        """drop this object's reference to the u32 component volume in HBM (0.5 GB at 512^3): skeletonize_cc calls it once the u16
+        copy serves every remaining sweep and no soma label will ask for a crop -- the volumes in flight are bounded by memory.
+        Callers that want the memory back must not keep a reference of their own (pass the volume through this object only)."""
+        self.d = None
+
     def __getitem__(self, pt):
         if self._host is not None:
             return self._host[pt]
@@ -172,12 +180,13 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     if fill_holes:
         fill_all_holes_device(eng, d_cc, all_labels.shape, nlabels)              # intake.py:168-169
     cc = LazyVolume(eng, d_cc, all_labels.shape)
+    del d_cc                   # (the volume is reached through `cc` from here on, which lets go of it as soon as it can)
     before = _points_to_labels(extra_targets_before, cc)
     after = _points_to_labels(extra_targets_after, cc)
 
     return skeletonize_cc(eng, cc, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                           fix_branching, fix_borders, before, after, black_border=(minlabel == maxlabel),
-                          timings=_timings, d_cc=d_cc)
+                          timings=_timings)
 
 
 def fill_all_holes_device(eng, d_cc, shape, nlabels):
@@ -255,6 +264,8 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
     shape = cc_labels.shape
     label_bytes = 4
     if d_cc is None:
+        d_cc = cc_labels.d
+    if d_cc is None:
         d_cc = eng.to_device(cc_labels.host())
         cc_labels.d = d_cc
     d_lab, label_bytes = eng.narrow(d_cc)          # u16 ids when there are < 65536 components (utility.py:79 refit)
@@ -301,6 +312,12 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
         tb.append(mtb)
         ta.append(mta)
 
+    if not soma_jobs and label_bytes == 2 and d_lab is not d_cc and os.environ.get("KH_KEEP_CC", "0") != "1":
+        # nothing reads the u32 ids any more (the faces are taken, no soma crop will be asked for): the u16 copy serves from here on
+        d_cc = None
+        cc_labels.release_device()
+        if getattr(eng, "_narrow", None) is not None:
+            eng._narrow = (None, eng._narrow[1])
     sel = np.asarray(segids, dtype=np.int64)
     asm = Assembler(shape, anisotropy, remapping)
     eng.run_labels(d_lab, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],

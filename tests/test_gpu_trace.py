@@ -319,7 +319,7 @@ def test_skeletonize_sweep_and_heap_paths(sweep, slots):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
-@pytest.mark.parametrize("variant", ["threads64", "threads128", "table_keys", "no_window", "tiny_arena", "narrow_window"])
+@pytest.mark.parametrize("variant", ["threads64", "threads128", "table_keys", "no_window", "tiny_arena", "narrow_window", "tiny_pool", "no_pool"])
 def test_sweep_storage_variants_and_their_bails(variant):
     """Round-4 storage of the sweep (pending-deadline filter, level window, recycled chunks) and its knobs: one wave / two
     waves per label, levels from the table of ranks (the fallback of round 6's integer levels), the window off, an arena a 64th of its size (calls run out of chunks: SW_BAIL_ARENA) and a
@@ -340,6 +340,10 @@ def test_sweep_storage_variants_and_their_bails(variant):
         eng2.arena_divisor = 64
     elif variant == "narrow_window":
         eng2.window_cap = 64
+    elif variant == "tiny_pool":
+        eng2.scratch_pool_fraction = 0.001   # heap and journal on demand from a pool that serves nobody: ghost calls are rolled back at
+    elif variant == "no_pool":               # once, labels that need the heap emulation are traced again with scratch of their own
+        eng2.scratch_pool = False
     an = (16, 16, 40)
     lab = voronoi_labels((96, 96, 40), 7, seed=5, pts_per_label=3, step=12.0, anisotropy=an)
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
@@ -354,6 +358,9 @@ def test_sweep_storage_variants_and_their_bails(variant):
         assert why & 4 and bails > 0          # SW_BAIL_ARENA happened and the heap emulation took those calls
     elif variant == "narrow_window":
         assert why & 8 and bails > 0          # SW_BAIL_LEVEL (an event beyond the window)
+    elif variant == "tiny_pool":
+        # every label whose call went to the heap emulation was refused by the pool and traced again with scratch of its own
+        assert eng2.last_retries >= int(np.count_nonzero(tk["stat_heap_pushes"]))
     else:
         assert calls - bails > 0
     assert sorted(got.keys()) == sorted(want.keys()) and len(got) >= 4
