@@ -23,7 +23,7 @@ Engine.scratch_budget asks for).
 The reference's own volume (benchmarks/connectomics.npy.ckl.gz) cannot be decoded here,
 so the volume is synthetic: data = "synthetic".
 
-Steps in flight (--inflight F; default: as many as 80 % of the free HBM pays for -- 17.9 GB per 512^3 volume -- 12 at most, and no
+Steps in flight (--inflight F; default: as many as 85 % of the free HBM pays for -- 10.8 GB per 512^3 volume since round 6 -- 24 at most, and no
 more than fill the rounds of the run evenly): the wall clock of ONE volume is the chain of its largest component -- a handful of waves
 for seconds while the rest of the GPU idles.  The K timed steps are therefore issued from F lanes (host threads by
 default, --lanes process for processes), each with a HIP stream, an Engine and scratch of its own and one wave per label in its path
@@ -357,11 +357,12 @@ def main():
             return args.inflight
         # A lane costs HBM: the whole-volume fields of its volume (~7.5 GB at 512^3) + the per-label scratch of the components
         # it traces (~11 GB for all components of c3; a rank of the strong mode holds 1 / N of them).  As many lanes as 80 %
-        # of the memory that is free now pays for, 12 at most: the step time keeps falling up to there (one volume's chain
+        # of the memory that is free now pays for, 24 at most (round 6: twenty fit): the step time keeps falling up to there (one volume's chain
         # of ~3 s is overlapped by the others' GPU-filling phases; measured at c3: 4 / 8 lanes = 1220 / 784 ms per step).
         from kimimaro_amd.lanes import lanes_for
         share = 1.0 / world if (mode == "strong" and world > 1) else 1.0
-        most = lanes_for(WORKLOADS[args.workload][0], torch.cuda.mem_get_info()[0], most=12, share=share)
+        state["hbm_free_gb"] = round(torch.cuda.mem_get_info()[0] / 1e9, 1)
+        most = lanes_for(WORKLOADS[args.workload][0], torch.cuda.mem_get_info()[0], most=24, share=share)
         # K equal volumes started together stay in lock step, so a run of K steps is ceil(K / lanes) rounds: the fewest
         # rounds the memory allows, and no more lanes than fill them evenly (K = 20: 10 + 10 rather than 12 + 8)
         rounds = -(-max(args.steps, 1) // most)
@@ -703,6 +704,7 @@ def main():
         "volumes_in_flight": inflight, "single_volume_ms": round(state.get("single_ms", float("nan")), 3),
         "value_single_volume": round(ncomp / (single_ms / 1e3), 3) if single_ms == single_ms else None,
         "hbm_reserved_peak_gb": round((torch.cuda.max_memory_reserved() + plane["peak"]) / 1e9, 1),
+        "hbm_free_when_lanes_were_chosen_gb": state.get("hbm_free_gb"),
         "lanes": args.lanes if inflight > 1 else "none",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "

@@ -167,17 +167,18 @@ class Lanes:
                 th.join()
 
 
-def lanes_for(shape, free_bytes, most=12, share=1.0):
+def lanes_for(shape, free_bytes, most=24, share=1.0):
     """how many volumes of `shape` to keep in flight on a GPU with `free_bytes` of HBM free: a lane holds the whole-volume
-    fields of its volume (56 B per voxel at 512^3 scale: ids, DBF, neighbour masks, PDRF, search scratch, the sweep's per-voxel
-    words) and the per-label scratch of the components it traces (91 B per voxel when the volume is all foreground -- since round 5
-    incl. the ghost journal, 8 B, and the saved rail weights; `share` = the fraction of them this process traces), measured
-    19.7 GB at 512^3 (197 GB with ten lanes); 80 % of the free memory at most, `most` lanes at most."""
+    fields of its volume (34 B per voxel at 512^3 scale: u16 ids, DBF, neighbour masks, PDRF, search scratch, the sweep's per-voxel
+    words) and the per-label scratch of the components it traces (50 B per voxel when the volume is all foreground: voxel lists,
+    work lists, event arenas, the pool heap and journal are taken from, path buffers; `share` = the fraction of them this process
+    traces).  Measured in round 6: 10.8 GB per lane at 512^3 (216.7 GB reserved with twenty lanes; round 5: 19.7 GB, ten lanes);
+    85 % of the free memory at most, `most` lanes at most."""
     nvox = 1
     for v in shape:
         nvox *= int(v)
-    per_lane = (56.0 + 91.0 * float(share)) * nvox
-    return int(max(1, min(int(most), (0.80 * float(free_bytes)) // per_lane)))
+    per_lane = (34.0 + 50.0 * float(share)) * nvox
+    return int(max(1, min(int(most), (0.85 * float(free_bytes)) // per_lane)))
 
 
 def skeletonize_many(volumes, teasar_params=None, lanes=None, width=None, **kwargs):
