@@ -370,6 +370,11 @@ int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_
  * number of voxels that changed.                                                                    */
 int kh_fill_voids(const uint8_t* mask, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint8_t* open,
                   uint8_t* out, int64_t* filled, void* stream);
+/* the same for an array of `ndim` (1..3) dimensions, the axes beyond it having extent 1: they are not axes and have no faces -- the
+ * border of a 2-D image is its outline (fill_voids.fill on the six faces of a crop, kimimaro/intake.py:655-666, fix_avocados).
+ * kh_fill_voids == kh_fill_voids_nd(ndim = 3).                                                                      */
+int kh_fill_voids_nd(const uint8_t* mask, int ndim, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint8_t* open,
+                     uint8_t* out, int64_t* filled, void* stream);
 
 /* ---- kh_ccl26 on HOST memory (used for the 2-D faces of fix_borders and as a cross-check),
  * restating cc3d.connected_components as called at kimimaro/utility.py:74-77.

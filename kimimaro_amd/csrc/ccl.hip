@@ -264,11 +264,13 @@ __global__ __launch_bounds__(256) void fill_link_kernel(const uint8_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void fill_mark_open_kernel(uint32_t* parent, uint8_t* open, int sx, int sy, int sz) {
+// ndim: dimensionality of the caller's array -- an axis beyond it (extent 1) is not an axis and has no faces: a 2-D image's border
+// is its outline (fill_voids.fill on the six faces of a crop, kimimaro/intake.py:655-666)
+__global__ __launch_bounds__(256) void fill_mark_open_kernel(uint32_t* parent, uint8_t* open, int sx, int sy, int sz, int ndim) {
   const int64_t sxy = (int64_t)sx * sy, n = sxy * sz;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t z = i / sxy, r = i - z * sxy, y = r / sx, x = r - y * sx;
-    const bool face = x == 0 || y == 0 || z == 0 || x == sx - 1 || y == sy - 1 || z == sz - 1;
+    const bool face = x == 0 || x == sx - 1 || (ndim >= 2 && (y == 0 || y == sy - 1)) || (ndim >= 3 && (z == 0 || z == sz - 1));
     if (face && parent[i] != CCL_NONE) open[ccl_find(parent, (uint32_t)i)] = 1;
   }
 }
@@ -309,9 +311,15 @@ extern "C" int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t
 
 extern "C" int kh_fill_voids(const uint8_t* mask, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint8_t* open,
                              uint8_t* out, int64_t* filled, void* stream) {
+  return kh_fill_voids_nd(mask, 3, sx, sy, sz, parent, open, out, filled, stream);
+}
+
+extern "C" int kh_fill_voids_nd(const uint8_t* mask, int ndim, int64_t sx, int64_t sy, int64_t sz, uint32_t* parent, uint8_t* open,
+                                uint8_t* out, int64_t* filled, void* stream) {
   if (int rc = kh::require_device()) return rc;
-  if (!mask || !parent || !open || !out || !filled || sx <= 0 || sy <= 0 || sz <= 0 || sx * sy * sz >= (1ll << 32) - 1) {
-    kh::set_error("kh_fill_voids: bad arguments (null pointer, empty volume or >= 2^32-1 voxels)");
+  if (!mask || !parent || !open || !out || !filled || sx <= 0 || sy <= 0 || sz <= 0 || sx * sy * sz >= (1ll << 32) - 1 ||
+      ndim < 1 || ndim > 3 || (ndim < 3 && sz != 1) || (ndim < 2 && sy != 1)) {
+    kh::set_error("kh_fill_voids: bad arguments (null pointer, empty volume, >= 2^32-1 voxels, or an axis beyond ndim with extent > 1)");
     return KH_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -322,7 +330,7 @@ extern "C" int kh_fill_voids(const uint8_t* mask, int64_t sx, int64_t sy, int64_
   hipLaunchKernelGGL(kh::fill_link_kernel, dim3(kh::ccl_grid(ntiles, 1, 1 << 20)), dim3(256), 0, st, mask, parent, (int)sx,
                      (int)sy, (int)sz);
   hipLaunchKernelGGL(kh::fill_mark_open_kernel, dim3(kh::ccl_grid(n, 256)), dim3(256), 0, st, parent, open, (int)sx, (int)sy,
-                     (int)sz);
+                     (int)sz, ndim);
   hipLaunchKernelGGL(kh::fill_apply_kernel, dim3(kh::ccl_grid(n, 256)), dim3(256), 0, st, mask, parent, open, out, n,
                      (unsigned long long*)filled);
   KH_LAUNCH_CHECK();

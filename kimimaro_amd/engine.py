@@ -346,17 +346,18 @@ class Engine:
             return nr[1], 2
         return d_cc, 4
 
-    def fill_voids(self, d_mask, shape):
-        """kh_fill_voids (fill_voids.fill, kimimaro/trace.py:109) on a u8 mask resident in HBM.
-        Returns (filled u8 mask on the device, number of voxels that changed)."""
+    def fill_voids(self, d_mask, shape, ndim=3):
+        """kh_fill_voids (fill_voids.fill, kimimaro/trace.py:109) on a u8 mask resident in HBM; ndim < 3: a 2-D / 1-D image given as
+        shape (nx, ny, 1) / (nx, 1, 1), whose border is its outline.  Returns (filled u8 mask on the device, number of voxels that changed)."""
         t = self.torch
+        shape = tuple(int(v) for v in shape) + (1,) * (3 - len(shape))
         n = int(shape[0]) * int(shape[1]) * int(shape[2])
         d_parent = self.empty(n, t.int32)
         d_open = self.empty(n, t.uint8)
         d_out = self.empty(n, t.uint8)
         d_cnt = self.empty(1, t.int64)
-        _abi.check(self.lib.kh_fill_voids(self.ptr(d_mask), shape[0], shape[1], shape[2], self.ptr(d_parent), self.ptr(d_open),
-                                          self.ptr(d_out), self.ptr(d_cnt), self.stream()))
+        _abi.check(self.lib.kh_fill_voids_nd(self.ptr(d_mask), int(ndim), shape[0], shape[1], shape[2], self.ptr(d_parent),
+                                             self.ptr(d_open), self.ptr(d_out), self.ptr(d_cnt), self.stream()))
         return d_out, int(d_cnt.cpu().numpy()[0])
 
     def to_host_volume(self, d, shape, dtype=np.uint32):

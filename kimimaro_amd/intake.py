@@ -156,8 +156,6 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     one process drives one GPU; multi-GPU runs shard the connected components round robin over the
     ranks of torch.distributed (see kimimaro_amd.distributed).
     """
-    if fix_avocados:
-        raise NotImplementedError("fix_avocados: an optional pre-pass outside the MI355X hot-path scope (SURVEY.md section 8)")
     if voxel_graph is not None:
         # The searches and the invalidation take the graph (kimimaro_amd.trace.trace(voxel_graph=), the function-level mirrors of
         # kimimaro_amd.ops; kh_apply_voxel_graph).  What the whole-volume call still lacks is edt.edt(voxel_graph=) -- the walls of
@@ -179,6 +177,13 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     d_cc, nlabels, remapping = compute_cc_labels_device(eng, all_labels)  # row f1 on the GPU
     if fill_holes:
         fill_all_holes_device(eng, d_cc, all_labels.shape, nlabels)              # intake.py:168-169
+    avocado = None
+    if fix_avocados:
+        # kimimaro/intake.py:187-193 run BEFORE everything else that looks at the components: it edits them (and renumbers them)
+        d_cc, nlabels, remapping, d_dbf_av = engage_avocado_protection_device(
+            eng, d_cc, all_labels.shape, nlabels, remapping, anisotropy, bool(minlabel == maxlabel),
+            teasar_params.get("soma_detection_threshold", 0))
+        avocado = d_dbf_av
     cc = LazyVolume(eng, d_cc, all_labels.shape)
     del d_cc                   # (the volume is reached through `cc` from here on, which lets go of it as soon as it can)
     before = _points_to_labels(extra_targets_before, cc)
@@ -186,7 +191,120 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
 
     return skeletonize_cc(eng, cc, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                           fix_branching, fix_borders, before, after, black_border=(minlabel == maxlabel),
-                          timings=_timings)
+                          timings=_timings, d_dbf=avocado)
+
+
+def _avocado_fruit_from_lines(xl, yl, zl, cx, cy, cz, background=0):
+    """kimimaro.skeletontricks.find_avocado_fruit (skeletontricks.pyx:905-992) on the three axis-parallel lines of the label volume
+    through (cx, cy, cz) (host copies): six rays from the voxel, each ends at the background or at the first other label, which it
+    reports; the rays towards smaller coordinates stop BEFORE index 0 (`range(c, 0, -1)`).  Fewer than three reports: (label, label).
+    The most frequent report -- the smallest label among equally frequent ones (np.unique order) -- is the fruit if at most one
+    report disagrees with it (none when there are exactly three reports)."""
+    label = int(xl[cx])
+    rays = (xl[cx:], xl[cx:0:-1], yl[cy:], yl[cy:0:-1], zl[cz:], zl[cz:0:-1])
+    changes = []
+    for ray in rays:
+        stop = np.flatnonzero((ray == background) | (ray != label))
+        if stop.size and int(ray[stop[0]]) != background:
+            changes.append(int(ray[stop[0]]))
+    if len(changes) < 3:
+        return label, label
+    uniq, cts = np.unique(changes, return_counts=True)
+    k = int(np.argmax(cts))
+    if len(changes) - int(cts[k]) > (1 if len(changes) > 3 else 0):
+        return label, label
+    return label, int(uniq[k])
+
+
+def engage_avocado_protection_device(eng, d_cc, shape, nlabels, remapping, anisotropy, black_border, soma_detection_threshold):
+    """kimimaro/intake.py:600-704 (fix_avocados=True) on the component volume resident in HBM: a nucleus that carries a label of its
+    own inside its cell ("pit" in "fruit") is merged into the cell, holes filled, up to 20 passes for nested ones; then the
+    components are renumbered (fastremap.renumber: by first appearance) and mapped back to the original labels
+    (skeletontricks.get_mapping, skeletontricks.pyx:490-525).  Device work: the transforms (kh_edt), the bounding boxes
+    (kh_label_stats), the 2-D fills of the six faces of a crop and its 3-D fill (kh_fill_voids_nd); selections, arg-max and the
+    relabelling are device-side tensor plumbing; the host reads three lines of labels per candidate (find_avocado_fruit's rays)
+    and keeps the reference's sets -- INCLUDING their iteration order: the candidates of a pass are a Python set built from the
+    sorted unique labels, and the reference edits the volume in that set's order.
+    Returns (component volume u32 on the device, number of components, {component: original label}, its EDT)."""
+    t = eng.torch
+    sx, sy, sz = (int(v) for v in shape)
+    nvox = sx * sy * sz
+    d_cc = d_cc.clone()                      # (the caller's volume may be shared)
+    orig = d_cc.clone()
+    v = d_cc.view(sz, sy, sx)                # torch C order (z, y, x) == Fortran order (x, y, z)
+    eng._narrow = None                       # the u16 copy kh_ccl26 made no longer matches what is edited here
+    d_dbf = eng.edt(d_cc, 4, shape, anisotropy, black_border)
+    thr = float(np.float32(soma_detection_threshold / 2.5))     # numpy compares the f32 field with the scalar in float32
+    unchanged = set()
+    for _ in range(20):
+        vals = t.unique(d_cc[d_dbf > thr]).cpu().numpy().view(np.uint32)       # sorted, like fastremap.unique
+        candidates = set([0] + [int(x) for x in vals]) if bool((d_dbf <= thr).any()) else set(int(x) for x in vals)
+        candidates -= unchanged
+        candidates.discard(0)
+        order = [label for label in candidates if label != 0]
+        changed, unchanged_now = set(), set()          # (the sets of ONE pass, intake.py:650-651)
+        if order:
+            counts, _, _, xmin, xmax = eng.label_stats(d_cc, 4, d_dbf, shape, nlabels)
+            yz = eng.last_yz_extent
+            dv = d_dbf.view(sz, sy, sx)
+            for label in order:
+                lo = (int(xmin[label]), int(yz[label, 0]), int(yz[label, 2]))
+                hi = (int(xmax[label]) + 1, int(yz[label, 1]) + 1, int(yz[label, 3]) + 1)
+                sub = v[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+                binimg = (sub == label)
+                # paint_walls (:655-666): a 2-D fill on each of the six faces, in the reference's order
+                for face in ((-1, 0), (-1, -1), (1, 0), (1, -1), (2, 0), (2, -1)):      # (torch axis, index): z, z, y, y, x, x
+                    ax = 0 if face[0] == -1 else face[0]
+                    plane = binimg.select(ax, face[1])
+                    p2 = plane.to(t.uint8).contiguous()
+                    filled, nfill = eng.fill_voids(p2.view(-1), (p2.shape[1], p2.shape[0], 1), ndim=2)
+                    if nfill:
+                        plane.copy_(filled.view(p2.shape).bool())
+                prod = binimg * dv[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+                k = int(t.argmax(prod.reshape(-1)).item())            # first maximum in the raster (x fastest), like argmax(arr.T)
+                nx, ny = hi[0] - lo[0], hi[1] - lo[1]
+                cx, cy, cz = lo[0] + k % nx, lo[1] + (k // nx) % ny, lo[2] + k // (nx * ny)
+                lines = [a.cpu().numpy().view(np.uint32) for a in (v[cz, cy, :], v[cz, :, cx].contiguous(), v[:, cy, cx].contiguous())]
+                pit, fruit = _avocado_fruit_from_lines(lines[0], lines[1], lines[2], cx, cy, cz)
+                if pit == fruit and pit not in changed:
+                    unchanged_now.add(pit)
+                else:
+                    unchanged_now.discard(pit)
+                    unchanged_now.discard(fruit)
+                    changed.add(pit)
+                    changed.add(fruit)
+                    binimg |= (sub == fruit)
+                cshape = (hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2])
+                filled, _ = eng.fill_voids(binimg.to(t.uint8).contiguous().view(-1), cshape)
+                fb = filled.view(cshape[2], cshape[1], cshape[0]).bool()
+                sub[fb] = fruit                               # cc_labels[slc] *= ~binimg; cc_labels[slc] += fruit * binimg
+        unchanged |= unchanged_now
+        if len(changed) == 0:
+            break
+        d_dbf = eng.edt(d_cc, 4, shape, anisotropy, black_border)
+    # fastremap.renumber: 1..N by first appearance in memory; get_mapping: the LAST run start of a component in the raster names it
+    flat = d_cc.to(t.int64) & 0xFFFFFFFF
+    idx = t.arange(nvox, device=eng.device, dtype=t.int64)
+    top = int(flat.max().item()) + 1
+    first = t.full((top,), nvox, dtype=t.int64, device=eng.device).scatter_reduce(0, flat, idx, reduce="amin")
+    present = t.nonzero(first < nvox).reshape(-1)
+    present = present[present != 0]
+    by_first = present[t.argsort(first[present], stable=True)]
+    lut = t.zeros(top, dtype=t.int64, device=eng.device)
+    lut[by_first] = t.arange(1, by_first.numel() + 1, device=eng.device, dtype=t.int64)
+    new = lut[flat]
+    starts = t.ones(nvox, dtype=t.bool, device=eng.device)
+    starts[1:] = new[1:] != new[:-1]
+    sidx = t.nonzero(starts).reshape(-1)
+    n_new = int(by_first.numel())
+    last = t.full((n_new + 1,), -1, dtype=t.int64, device=eng.device).scatter_reduce(0, new[sidx], sidx, reduce="amax")
+    last_h = last.cpu().numpy()
+    src = (orig.to(t.int64) & 0xFFFFFFFF)[last.clamp(min=0)].cpu().numpy()
+    adjusted = {}
+    for new_cc in range(0, n_new + 1):
+        if last_h[new_cc] >= 0 and int(src[new_cc]) in remapping:
+            adjusted[new_cc] = remapping[int(src[new_cc])]
+    return new.to(t.int32), n_new, adjusted, d_dbf       # (renumbering does not move a voxel: the last transform stands)
 
 
 def fill_all_holes_device(eng, d_cc, shape, nlabels):
@@ -240,17 +358,17 @@ def shard_components(cc_segids, counts, rank, world):
 
 def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                    fix_branching, fix_borders, before, after, black_border, timings=None,
-                   rank=0, world=1, d_cc=None):
+                   rank=0, world=1, d_cc=None, d_dbf=None):
     """Everything after the connected components (intake.py:174-221 + skeletonize_subset :434-517)."""
     try:
         return _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold, fix_branching,
-                               fix_borders, before, after, black_border, timings, rank, world, d_cc)
+                               fix_borders, before, after, black_border, timings, rank, world, d_cc, d_dbf)
     finally:
         eng._narrow = None      # the u16 copy of this volume's ids (2 B / voxel of HBM) is not kept alive past the call
 
 
 def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
-                    fix_branching, fix_borders, before, after, black_border, timings, rank, world, d_cc):
+                    fix_branching, fix_borders, before, after, black_border, timings, rank, world, d_cc, d_dbf=None):
     import time as _time
 
     def _mark(name):
@@ -269,7 +387,8 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
         d_cc = eng.to_device(cc_labels.host())
         cc_labels.d = d_cc
     d_lab, label_bytes = eng.narrow(d_cc)          # u16 ids when there are < 65536 components (utility.py:79 refit)
-    d_dbf = eng.edt(d_lab, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
+    if d_dbf is None:         # (fix_avocados hands over the transform of the components it left behind)
+        d_dbf = eng.edt(d_lab, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
     counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_lab, label_bytes, d_dbf, shape, nlabels)
     yz = eng.last_yz_extent
     bbox = lambda sid: ((int(xmin[sid]), int(yz[sid, 0]), int(yz[sid, 2])),

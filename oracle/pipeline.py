@@ -10,7 +10,7 @@ Not restated (rows f2/f3 of SURVEY.md section 8 are handled where noted):
 The Skeleton operations and the border targets are restated in oracle/skeleton.py and oracle/border.py (nothing here
 imports the product).  soma mode is restated with a fill_voids stand-in (scipy.ndimage.binary_fill_holes) and a documented
 guess of dijkstra3d's free_space_radius (source absent); fill_holes is restated with the same stand-in;
-voxel_graph and fix_avocados raise
+voxel_graph raises
 NotImplementedError.
 """
 from __future__ import annotations
@@ -273,14 +273,128 @@ def fill_all_holes(cc_labels):
     return cc_labels
 
 
+def find_avocado_fruit(labels, cx, cy, cz, background=0):
+    """kimimaro.skeletontricks.find_avocado_fruit (skeletontricks.pyx:905-992): six rays from (cx, cy, cz) along the axes; each stops at
+    the background or reports the first other label it meets (the rays towards smaller coordinates never look at index 0:
+    `range(c, 0, -1)`).  Fewer than three reports: no decision.  The most frequent report (np.unique order breaks ties: the smallest
+    label) is the fruit if at most one report disagrees (none when there are exactly three).  Returns (pit, fruit)."""
+    sx, sy, sz = labels.shape[:3]
+    if cx >= sx or cy >= sy or cz >= sz:
+        raise ValueError("<{},{},{}> must be be contained within shape <{},{},{}>".format(cx, cy, cz, sx, sy, sz))
+    label = labels[cx, cy, cz]
+    lines = (labels[cx:sx, cy, cz], labels[cx:0:-1, cy, cz], labels[cx, cy:sy, cz], labels[cx, cy:0:-1, cz],
+             labels[cx, cy, cz:sz], labels[cx, cy, cz:0:-1])
+    changes = []
+    for line in lines:
+        for v in line:
+            if v == background:
+                break
+            if v != label:
+                changes.append(v)
+                break
+    if len(changes) < 3:
+        return (label, label)
+    allowed = 1 if len(changes) > 3 else 0
+    uniq, cts = np.unique(changes, return_counts=True)
+    k = int(np.argmax(cts))
+    if len(changes) - cts[k] > allowed:
+        return (label, label)
+    return (label, uniq[k])
+
+
+def _fill2d(img):
+    import scipy.ndimage
+    return scipy.ndimage.binary_fill_holes(img)
+
+
+def engage_avocado_protection_single_pass(cc_labels, all_dbf, candidates):
+    """kimimaro/intake.py:642-704 (fill_voids.fill stand-in: scipy.ndimage.binary_fill_holes, in 2-D on the six faces of the crop
+    and in 3-D on the crop).  `candidates`: an iterable in the order the reference's set iterates."""
+    import scipy.ndimage
+    candidates = [label for label in candidates if label != 0]
+    unchanged, changed = set(), set()
+    if len(candidates) == 0:
+        return cc_labels, unchanged, changed
+    slcs = find_objects(cc_labels)
+    for label in candidates:
+        slc = slcs[label - 1]
+        offset = np.array([s.start for s in slc], dtype=np.int64)
+        binimg = (cc_labels[slc] == label)
+        for face in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), 0, slice(None)),
+                     (slice(None), -1, slice(None)), (0, slice(None), slice(None)), (-1, slice(None), slice(None))):
+            binimg[face] = _fill2d(binimg[face])                                   # paint_walls, :655-666
+        prod = binimg * all_dbf[slc]
+        coord = np.array(np.unravel_index(np.argmax(prod.T), prod.shape, order="F")) + offset      # argmax, :596-599
+        pit, fruit = find_avocado_fruit(cc_labels, int(coord[0]), int(coord[1]), int(coord[2]))
+        pit, fruit = int(pit), int(fruit)
+        if pit == fruit and pit not in changed:
+            unchanged.add(pit)
+        else:
+            unchanged.discard(pit)
+            unchanged.discard(fruit)
+            changed.add(pit)
+            changed.add(fruit)
+            binimg |= (cc_labels[slc] == fruit)
+        binimg = scipy.ndimage.binary_fill_holes(binimg)
+        sub = cc_labels[slc]
+        sub *= ~binimg
+        sub += np.asarray(fruit, dtype=cc_labels.dtype) * binimg
+    return cc_labels, unchanged, changed
+
+
+def get_mapping(orig_labels, cc_labels):
+    """kimimaro.skeletontricks.get_mapping (skeletontricks.pyx:490-525): the raster (x fastest) is walked once; at every voxel whose
+    component label differs from the PREVIOUS voxel's, remap[cc] = original label there -- the last such place wins."""
+    o = orig_labels.ravel(order="F")
+    c = cc_labels.ravel(order="F")
+    remap = {}
+    if o.size == 0:
+        return remap
+    starts = np.flatnonzero(np.concatenate([[True], c[1:] != c[:-1]]))
+    for i in starts:            # ascending: later run starts overwrite earlier ones
+        remap[int(c[i])] = o[i].item()
+    return remap
+
+
+def engage_avocado_protection(cc_labels, all_dbf, remapping, soma_detection_threshold, edtfn):
+    """kimimaro/intake.py:600-640.  The candidates of a pass are a Python set built from the sorted unique labels (fastremap.unique)
+    minus the labels that did not change in an earlier pass; the reference iterates that set, so does this."""
+    orig_cc_labels = np.copy(cc_labels, order="F")
+    unchanged = set()
+    for _ in range(20):
+        vals = np.unique(cc_labels * (all_dbf > soma_detection_threshold / 2.5))
+        candidates = set(int(v) for v in vals)
+        candidates -= unchanged
+        candidates.discard(0)
+        cc_labels, unchanged_this_cycle, changes = engage_avocado_protection_single_pass(cc_labels, all_dbf, candidates)
+        unchanged |= unchanged_this_cycle
+        if len(changes) == 0:
+            break
+        all_dbf = edtfn(cc_labels)
+    # fastremap.renumber: new ids 1..N in the order of first appearance in memory (0 stays 0)
+    flat = cc_labels.ravel(order="F")
+    uniq, first = np.unique(flat, return_index=True)
+    keep = uniq != 0
+    order = np.argsort(first[keep], kind="stable")
+    lut = np.zeros(int(uniq.max()) + 1 if uniq.size else 1, dtype=cc_labels.dtype)
+    lut[uniq[keep][order]] = np.arange(1, int(keep.sum()) + 1, dtype=cc_labels.dtype)
+    cc_labels = np.asfortranarray(lut[cc_labels])
+    cc_remapping = get_mapping(orig_cc_labels, cc_labels)
+    adjusted = {}
+    for new_cc, cc in cc_remapping.items():
+        if cc in remapping:
+            adjusted[new_cc] = remapping[cc]
+    return cc_labels, all_dbf, adjusted
+
+
 def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 1, 1),
                 object_ids=None, dust_threshold=1000, progress=False, fix_branching=True,
                 in_place=False, fix_borders=True, parallel=1, parallel_chunk_size=100,
                 extra_targets_before=[], extra_targets_after=[], fill_holes=False,
                 fix_avocados=False, voxel_graph=None, stats=None):
     """kimimaro/intake.py:58-221 + skeletonize_subset :434-517 (serial path)."""
-    if fix_avocados or voxel_graph is not None:
-        raise NotImplementedError("fix_avocados / voxel_graph are out of the restated scope")
+    if voxel_graph is not None:
+        raise NotImplementedError("skeletonize(voxel_graph=) is out of the restated scope (edt / cc3d walls: sources absent)")
     anisotropy = np.array(anisotropy, dtype=np.float32)
     all_labels = format_labels(all_labels)
     if object_ids is not None:
@@ -298,6 +412,10 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     after = _points_to_labels(extra_targets_after, cc_labels)
 
     all_dbf = K.edt(cc_labels, anisotropy, black_border=(minlabel == maxlabel))  # intake.py:174-185
+    if fix_avocados:                                                             # intake.py:187-193
+        cc_labels, all_dbf, remapping = engage_avocado_protection(
+            cc_labels, all_dbf, remapping, teasar_params.get("soma_detection_threshold", 0),
+            lambda lab: K.edt(lab, anisotropy, black_border=(minlabel == maxlabel)))
 
     counts = np.bincount(cc_labels.ravel(order="F"))
     cc_segids = [i for i in range(1, counts.size) if counts[i] > dust_threshold]

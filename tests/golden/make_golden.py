@@ -643,7 +643,48 @@ def gen_ball_graph(st):
     print("invalidation_ball_graph:", n)
 
 
-if __name__ == "__main__" and "ball_graph" in sys.argv[1:]:
+def gen_avocado(st):
+    """kimimaro.skeletontricks.find_avocado_fruit (skeletontricks.pyx:905-992) and get_mapping (:490-525) of the compiled reference on
+    seeded volumes: random label soups (every tie and every ray that runs into the background or the array's edge), nested shells
+    (a pit inside a fruit, inside another), coordinates on faces, edges and corners."""
+    rng = np.random.default_rng(0xA70CAD0)
+    cases, n = {}, 0
+    for t in range(120):
+        shp = tuple(int(v) for v in rng.integers(1, 9, 3))
+        if t % 3 == 0:
+            shp = tuple(max(v, 3) for v in shp)
+            lab = np.full(shp, 3, dtype=np.uint32, order="F")
+            lab[1:-1, 1:-1, 1:-1] = 2
+            if min(shp) >= 5:
+                lab[2:-2, 2:-2, 2:-2] = 1
+            if t % 6 == 0:
+                lab[tuple(int(rng.integers(0, v)) for v in shp)] = 0
+        else:
+            lab = np.asfortranarray(rng.integers(0, int(rng.integers(2, 6)), shp).astype(np.uint32))
+        pts = np.array([[int(rng.integers(0, v)) for v in shp] for _ in range(6)], dtype=np.int64)
+        out = np.array([[int(v) for v in st.find_avocado_fruit(lab, int(p[0]), int(p[1]), int(p[2]))] for p in pts], dtype=np.int64)
+        orig = np.asfortranarray(rng.integers(0, 6, shp).astype(np.uint32))
+        cc = np.asfortranarray(rng.integers(0, 5, shp).astype(np.uint32))
+        mp = st.get_mapping(orig, cc)
+        keys = np.array(sorted(int(k) for k in mp), dtype=np.int64)
+        cases["lab%d" % n] = lab
+        cases["pts%d" % n] = pts
+        cases["fruit%d" % n] = out
+        cases["orig%d" % n] = orig
+        cases["cc%d" % n] = cc
+        cases["mapk%d" % n] = keys
+        cases["mapv%d" % n] = np.array([int(mp[k]) for k in keys], dtype=np.int64)
+        n += 1
+    cases["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "avocado.npz"), **cases)
+    print("avocado:", n)
+
+
+if __name__ == "__main__" and "avocado" in sys.argv[1:]:
+    st = build_ref.load()
+    assert st is not None, "needs /root/reference"
+    gen_avocado(st)
+elif __name__ == "__main__" and "ball_graph" in sys.argv[1:]:
     st = build_ref.load()
     assert st is not None, "needs /root/reference"
     gen_ball_graph(st)
@@ -675,5 +716,6 @@ elif __name__ == "__main__":
     gen_pdrf(trace)
     gen_border(st)
     gen_edt()
+    gen_avocado(st)
 
 

@@ -75,3 +75,24 @@ def lollipop(length=1500, radius=14):
     m[length:][ball] = 1
     m[1:length + 3, n // 2, n // 2] = 1
     return m, tuple(int(v) for v in c)
+
+
+def avocado_volume(shape=(72, 64, 48), seed=3):
+    """cells whose nucleus carries a label of its own ("pit" inside "fruit", kimimaro/intake.py:600-704): a free-standing avocado,
+    one cut by a wall of the volume, a nested one (nucleolus in nucleus in cell), a plain blob and a thin process, on background."""
+    lab = np.zeros(shape, dtype=np.uint32, order="F")
+    gx, gy, gz = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+
+    def ball(c, r):
+        return ((gx - c[0]) / r[0]) ** 2 + ((gy - c[1]) / r[1]) ** 2 + ((gz - c[2]) / r[2]) ** 2 <= 1.0
+
+    lab[ball((20, 20, 22), (14, 13, 12))] = 11          # fruit
+    lab[ball((21, 20, 22), (7, 6, 6))] = 12             # its pit
+    lab[ball((4, 48, 24), (12, 11, 10))] = 21           # fruit cut by the x = 0 wall
+    lab[ball((3, 48, 24), (6, 6, 5))] = 22              # pit on the wall
+    lab[ball((52, 40, 24), (16, 15, 14))] = 31          # nested: cell
+    lab[ball((52, 40, 24), (10, 9, 9))] = 32            # nucleus
+    lab[ball((52, 40, 25), (4, 4, 4))] = 33             # nucleolus
+    lab[ball((50, 10, 12), (8, 7, 7))] = 41             # plain blob
+    lab[30:66, 58:61, 40:43] = 51                       # thin process
+    return lab

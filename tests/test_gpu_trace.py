@@ -797,3 +797,35 @@ def test_search_mirrors_with_voxel_graph_match_oracle(eng):
         np.testing.assert_array_equal(ops.railroad(field, src, voxel_graph=g), wpath)
     finally:
         ops._engine = None
+
+
+def test_fix_avocados_matches_oracle(eng):
+    """skeletonize(fix_avocados=True) (kimimaro/intake.py:187-193, 600-704) on the MI355X -- transforms, bounding boxes and the 2-D /
+    3-D fills are HIP kernels, the sets and their iteration order the reference's -- against the oracle restatement: pits merged
+    into their fruits (free-standing, cut by a wall, nested), everything else untouched, skeletons equal."""
+    import kimimaro_amd
+    from oracle import pipeline as P
+    from shapes import avocado_volume
+    lab = avocado_volume()
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    params.update(scale=1.5, const=20, soma_detection_threshold=10.0, soma_acceptance_threshold=1e9)
+    an = (4, 4, 4)
+    got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=50, fix_borders=False, fix_avocados=True,
+                                   progress=False, _engine=eng)
+    want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=50, fix_borders=False, fix_avocados=True)
+    assert sorted(got) == sorted(want) == [11, 21, 31, 41, 51]
+    for k in got:
+        np.testing.assert_array_equal(got[k].vertices, want[k].vertices)
+        np.testing.assert_array_equal(got[k].edges, want[k].edges)
+        np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
+    # the 2-D fill the six faces of a crop go through (kh_fill_voids_nd): the outline of the IMAGE is its border
+    import scipy.ndimage
+    rng = np.random.default_rng(5)
+    t = eng.torch
+    for _ in range(6):
+        img = np.asfortranarray(rng.random((int(rng.integers(1, 30)), int(rng.integers(1, 30)))) < 0.45)
+        d = t.from_numpy(np.ascontiguousarray(img.astype(np.uint8).reshape(-1, order="F"))).to(eng.device)
+        out, n = eng.fill_voids(d, (img.shape[0], img.shape[1], 1), ndim=2)
+        wantf = scipy.ndimage.binary_fill_holes(img)
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(img.shape, order="F").astype(bool), wantf)
+        assert n == int(wantf.sum()) - int(img.sum())

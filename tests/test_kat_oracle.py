@@ -154,3 +154,19 @@ def test_fill_all_holes_swallows_enclosed_components():
     assert (out[6:10, 6:10, 6:10] == 1).all() and (out[12:14, 12:14, 12:14] == 1).all()
     assert (out[8:10, 8:10, 0:2] == 0).all()
     assert (out[0:2, 0:2, 0:2] == 3).all()
+
+
+def test_fix_avocados_merges_pits_into_their_fruit():
+    """kimimaro/intake.py:187-193, 600-704 through the oracle restatement: a nucleus with a label of its own disappears into its
+    cell (also when the wall of the volume cuts both, and when a nucleolus sits inside the nucleus); nothing else changes."""
+    from shapes import avocado_volume
+    from oracle import pipeline as P
+    lab = avocado_volume()
+    params = dict(P.DEFAULT_TEASAR_PARAMS)
+    params.update(scale=1.5, const=20, soma_detection_threshold=10.0, soma_acceptance_threshold=1e9)
+    plain = P.skeletonize(lab, params, anisotropy=(4, 4, 4), dust_threshold=50, fix_borders=False)
+    fixed = P.skeletonize(lab, params, anisotropy=(4, 4, 4), dust_threshold=50, fix_borders=False, fix_avocados=True)
+    assert {12, 22, 32, 33} <= set(plain)                # the pits are objects of their own without the option ...
+    assert set(fixed) == {11, 21, 31, 41, 51}            # ... and gone with it
+    for k in (41, 51):
+        np.testing.assert_array_equal(fixed[k].vertices, plain[k].vertices)

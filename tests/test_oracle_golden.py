@@ -324,3 +324,24 @@ def test_legacy_find_target_golden():
         assert got == tuple(int(v) for v in z["target_%d" % i]), i
         fl = K.first_label(np.asfortranarray(mask.astype(np.uint8)))
         assert (tuple(int(v) for v in fl) if fl is not None else (-1, -1, -1)) == tuple(int(v) for v in z["first_%d" % i]), i
+
+
+def test_avocado_helpers_match_reference_vectors():
+    """find_avocado_fruit (skeletontricks.pyx:905-992) and get_mapping (:490-525): the oracle's restatements AND the product's own
+    ray scan (kimimaro_amd.intake._avocado_fruit_from_lines, pure host code) replay the compiled reference's outputs."""
+    from oracle import pipeline as P
+    from kimimaro_amd.intake import _avocado_fruit_from_lines
+    g = np.load(os.path.join(G, "avocado.npz"))
+    n = int(g["n"])
+    assert n >= 100
+    for i in range(n):
+        lab, pts, want = g["lab%d" % i], g["pts%d" % i], g["fruit%d" % i]
+        for p, w in zip(pts, want):
+            cx, cy, cz = (int(v) for v in p)
+            got = P.find_avocado_fruit(lab, cx, cy, cz)
+            assert (int(got[0]), int(got[1])) == (int(w[0]), int(w[1]))
+            got2 = _avocado_fruit_from_lines(lab[:, cy, cz], lab[cx, :, cz], lab[cx, cy, :], cx, cy, cz)
+            assert got2 == (int(w[0]), int(w[1]))
+        mp = P.get_mapping(g["orig%d" % i], g["cc%d" % i])
+        assert sorted(mp) == [int(k) for k in g["mapk%d" % i]]
+        assert [int(mp[int(k)]) for k in g["mapk%d" % i]] == [int(v) for v in g["mapv%d" % i]]
