@@ -1239,7 +1239,9 @@ __device__ __attribute__((noinline)) long long sweep_ball(SweepRef s, const uint
     for (uint32_t i = tid; i < s.spcap; i += nthr) { s.spk[i] = 0u; s.spc[i] = 0ull; }
   }
   if (bail) {
-    // undo: the killed voxels come back (ghosts as ghosts), every per-voxel word of the label is cleared
+    // undo: the voxels this call killed are alive again (a ghost whose kill had been committed comes back as a plain live voxel, not
+    // as a ghost: the caller never continues from that state -- with ghosts alive it answers a bail by rolling the whole journal back,
+    // trace.hip "heap_ok"), every per-voxel word of the label is cleared
     if (tid == 0) sh->bail = bail;
     for (uint32_t i = tid; i < nk; i += nthr) { const uint32_t v = s.killed[i]; s.alive[v] = (uint8_t)(s.alive[v] == 0 ? 1 : s.alive[v]); }
     for (uint32_t i = tid; i < nf; i += nthr) s.cstate[list[i]] = 0ull;

@@ -32,8 +32,8 @@ def _torch():
 # 8, ghost journal 8, path buffers and saved rail weights ~6 = 86 B, booked as 110; + the fixed parts of a small label (a 32 768-node
 # heap, the arena's level chunks, 64 Ki path slots).  Round 2 booked 300 B per voxel (28 GB of event arena per c3 volume then):
 # c5 ran as three launches one after the other, 12.4 s of paths; as one launch it is 91 -> ~200 GB of HBM and half the time.
-SCRATCH_BYTES_PER_VOXEL = 110
-SCRATCH_BYTES_PER_LABEL = 2 << 20
+SCRATCH_BYTES_PER_VOXEL = 60        # round 6: voxel list + DAF 8, work lists 16, the pool's share of heap and journal ~5, path buffers ~1,
+SCRATCH_BYTES_PER_LABEL = 3 << 19    # booked with slack; per label: the event arena (1.25 x the level window + 320 chunks: 0.6-1.4 MB)
 # Round 6: heap and ghost journal come out of one pool per launch, on demand (KH_TRACE_SCRATCH_POOL): this fraction of what all
 # labels together could ask for (c3: 141 of 3 402 labels ever run the heap emulation -- 6 % of the nodes --, 360 ever hold a ghost);
 # a label the pool cannot serve is traced again with scratch of its own, like every other overflow
@@ -296,6 +296,11 @@ class Engine:
             def make():
                 e = Engine(self.device)
                 e.soma_lanes = 1
+                # the lane engines trace with the parent's settings (a test that switches the sweep or the ghosts off means the somas too)
+                for knob in ("sweep", "ghosts", "ghost_paranoid", "int_keys", "scratch_divisor", "arena_divisor", "window_cap", "profile",
+                             "trace_threads", "edf_threads", "sweep_window", "sweep_lds_levels", "big_lds_heap", "scratch_pool",
+                             "scratch_pool_fraction", "heap_prio"):
+                    setattr(e, knob, getattr(self, knob))
                 return e
             self._soma_pool = Lanes(width, device=self.device, engine_factory=make,
                                     stream_factory=lambda e: _StreamScope(self.torch, e))

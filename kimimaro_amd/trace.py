@@ -41,12 +41,14 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
             vg = vg[..., np.newaxis]
         if tuple(vg.shape) != tuple(shape):
             raise ValueError("voxel_graph must have the shape of the labels")
-        if dmax > soma_detection_threshold:
-            raise NotImplementedError("voxel_graph together with the soma branch (its re-EDT would need edt(voxel_graph=))")
         d_graph = eng.to_device(np.asfortranarray(vg.astype(np.uint32)))
     if dmax > soma_detection_threshold:  # kimimaro/trace.py:108-119
         # fill_voids.fill (kh_fill_voids, row f3) + crop re-EDT, both on the GPU
         d_filled, nfilled = eng.fill_voids((d_cc != 0).to(eng.torch.uint8), shape)
+        if nfilled > 0 and voxel_graph is not None:
+            # only a soma whose voids were filled is transformed again (kimimaro/trace.py:109-117), and only that needs edt(voxel_graph=)
+            raise NotImplementedError("voxel_graph together with a soma whose internal voids get filled (the re-EDT would need "
+                                      "edt(voxel_graph=), whose wall semantics are not restated)")
         if nfilled > 0:
             d_cc = d_filled.to(eng.torch.int32)
             cc = eng.to_host_volume(d_cc, shape)
