@@ -1,5 +1,5 @@
 /* Developer experiment (round 5): the "decision-bit" form of the libstdc++ heap emulation, checked on the CPU before it was written
- * for the wave (tests/experiments/bitheap_r5.patch: built, bit exact on the GPU, measured, and taken out again -- DESIGN.md 3.4.7).
+ * for the wave (experiments/bitheap_r5.patch: built, bit exact on the GPU, measured, and taken out again -- DESIGN.md 3.4.7).
  *
  * libstdc++'s pop walks the hole from the root to a LEAF along the smaller child (ties: left) whatever the keys are, then pushes the
  * former last element up from there.  Which child is the smaller one is ONE BIT per internal node, and a pop or a push changes that
@@ -10,7 +10,7 @@
  * This file states the update rules the kernel uses and checks them against a literal transcription of
  * bits/stl_heap.h (__push_heap / __adjust_heap, comparator `a.dist >= b.dist` of dijkstra_invalidation.hpp:233-237) on random
  * streams with heavy ties: identical arrays after every operation, and every bit equal to its definition.
- * Build and run: gcc -O2 -o /tmp/bitheap_sim tests/experiments/bitheap_sim.c && /tmp/bitheap_sim */
+ * Build and run: gcc -O2 -o /tmp/bitheap_sim experiments/bitheap_sim.c && /tmp/bitheap_sim */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

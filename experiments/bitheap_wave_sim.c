@@ -1,7 +1,7 @@
-/* Developer experiment (round 5): lane-level CPU emulation of the wave code of the decision-bit heap (tests/experiments/bitheap_r5.patch:
+/* Developer experiment (round 5): lane-level CPU emulation of the wave code of the decision-bit heap (experiments/bitheap_r5.patch:
  * heap_push_wave, heap_pop_wave and the batched append of invalidate_ball), statement by statement over 64 lanes, against a
  * literal transcription of bits/stl_heap.h.  Memory is bounds-checked: an out-of-range access aborts with the statement.
- * gcc -O2 -o /tmp/bitheap_wave_sim tests/experiments/bitheap_wave_sim.c && /tmp/bitheap_wave_sim */
+ * gcc -O2 -o /tmp/bitheap_wave_sim experiments/bitheap_wave_sim.c && /tmp/bitheap_wave_sim */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

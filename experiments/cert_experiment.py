@@ -1,7 +1,7 @@
-"""Developer experiment: how often does the order-free certificate of tests/experiments/cert_ball.c hold on
+"""Developer experiment: how often does the order-free certificate of experiments/cert_ball.c hold on
 the invalidation calls of realistic labels, and is the certified result equal to the exact (libstdc++ order) one?
-Build: gcc -O2 -ffp-contract=off -shared -fPIC tests/experiments/cert_ball.c -o tests/experiments/cert_ball3.so -lm
-Usage: python tests/experiments/cert_experiment.py mini|c2 [max_labels]"""
+Build: gcc -O2 -ffp-contract=off -shared -fPIC experiments/cert_ball.c -o experiments/cert_ball3.so -lm
+Usage: python experiments/cert_experiment.py mini|c2 [max_labels]"""
 import os, sys, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,9 +1,9 @@
-"""Developer experiment: the order-free sweep with GHOSTS (tests/experiments/cert_ball4.c) over whole labels.
+"""Developer experiment: the order-free sweep with GHOSTS (experiments/cert_ball4.c) over whole labels.
 A voxel the sweep cannot decide stays a ghost for the following calls.  Counts, per label, the calls, the ghosts, and
 whether a ghost ever interferes with the control flow of compute_paths (target choice / termination): only then would
 the exact heap emulation be needed.  Also checks soundness against the exact result after every call.
-Build: gcc -O2 -ffp-contract=off -shared -fPIC tests/experiments/cert_ball4.c -o tests/experiments/cert_ball4.so -lm
-Usage: python tests/experiments/ghost_experiment.py mini|c2|c3 [max_labels] [first]"""
+Build: gcc -O2 -ffp-contract=off -shared -fPIC experiments/cert_ball4.c -o experiments/cert_ball4.so -lm
+Usage: python experiments/ghost_experiment.py mini|c2|c3 [max_labels] [first]"""
 import os, sys, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

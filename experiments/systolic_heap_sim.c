@@ -15,7 +15,7 @@
  *            chains) starts only when no in-flight hole is an ancestor-or-self of a slot of S;
  *        I3  the prefetched `last` element is dropped when a tick wrote its slot.
  *
- *   gcc -O2 -o /tmp/systolic_heap_sim tests/experiments/systolic_heap_sim.c -lm && /tmp/systolic_heap_sim 200
+ *   gcc -O2 -o /tmp/systolic_heap_sim experiments/systolic_heap_sim.c -lm && /tmp/systolic_heap_sim 200
  */
 #include <math.h>
 #include <stdint.h>

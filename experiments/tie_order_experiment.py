@@ -1,7 +1,7 @@
 """Developer experiment: does the tie order of the invalidation heap matter?
 Replays every roll_invalidation_ball_inside_component call of the oracle pipeline with three canonical total
-orders (tests/experiments/canon_heap.c) and counts the calls whose final mask differs from the libstdc++ order.
-Build first: gcc -O2 -ffp-contract=off -shared -fPIC tests/experiments/canon_heap.c -o tests/experiments/canon_heap.so -lm"""
+orders (experiments/canon_heap.c) and counts the calls whose final mask differs from the libstdc++ order.
+Build first: gcc -O2 -ffp-contract=off -shared -fPIC experiments/canon_heap.c -o experiments/canon_heap.so -lm"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
