@@ -433,6 +433,7 @@ def main():
                 torch.cuda.synchronize()
                 state["single_ms"] = (time.perf_counter() - t1) * 1e3
                 state["production_kernel_ms"] = list(getattr(eng, "last_path_kernel_ms", None) or [])
+                state["production_span_ms"] = float(getattr(eng, "last_path_span_ms", 0.0) or 0.0)
             eng.time_kernels = False
             torch.cuda.empty_cache()
         open_process_lanes(width)
@@ -579,7 +580,7 @@ def main():
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     # runs, gfx950 x2 FETCH correction calibrated on the x pass): the newest profiles/rNN_c3_edt_pmc.json.  Only valid for c3.
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_c3_edt_pmc.json", "r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_c3_edt_pmc.json", "r05_c3_edt_pmc.json", "r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
                 if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(pmc):
         kern = json.load(open(pmc))["kernels"]
@@ -591,7 +592,7 @@ def main():
     roofline_edt = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": "profiles/%s (rocprofv3 --pmc passes of tools/edt_only.py on the same volume%s; not live)"
-                                  % (os.path.basename(pmc), "" if "r05_" in pmc else "; STALE: measured before round 5's x pass") if traffic else None,
+                                  % (os.path.basename(pmc), "" if ("r05_" in pmc or "r06_" in pmc) else "; STALE: measured before round 5's x pass") if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
@@ -623,14 +624,14 @@ def main():
     # HBM traffic of that kernel from the committed counter passes (tools/pmc_trace_r3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs over one c3 volume, FETCH x 2 on gfx950): only valid for c3
     tr_traffic, tr_src = None, None
-    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_c3_trace_pmc.json", "r04_c3_trace_pmc.json",
-                                                                         "r03_c3_trace_pmc.json")) if os.path.exists(q)), "")
+    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_c3_trace_pmc.json", "r05_c3_trace_pmc.json",
+                                                                         "r04_c3_trace_pmc.json")) if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(tpmc):
         for name, v in json.load(open(tpmc))["kernels"].items():
             if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected_per_volume"):
                 # (the volume's launches -- the largest labels as a kernel variant of their own -- added up)
                 tr_traffic = (tr_traffic or 0.0) + v["hbm_bytes_corrected_per_volume"]
-                stale = "" if "r05_" in os.path.basename(tpmc) else "; STALE: measured on the round-4 kernels"
+                stale = "" if "r06_" in os.path.basename(tpmc) else "; STALE: measured on an earlier round's kernels"
                 tr_src = ("profiles/%s (rocprofv3 --pmc passes over one volume, all path-kernel launches of the volume; not live%s)"
                           % (os.path.basename(tpmc), stale))
     # the dominant kernel (97 % of the GPU time): its launches of ONE volume overlap on two streams (the largest labels on the
@@ -639,12 +640,14 @@ def main():
     # the instrumented pass below, the profile build, which is where the cycle counters of `chains` come from)
     kms = state.get("production_kernel_ms") or state.get("path_kernel_ms") or []
     span_s = max([m for _, m in kms], default=float("nan")) / 1e3 if kms else tr_s
+    if state.get("production_kernel_ms") and state.get("production_span_ms", 0.0) > 0.0:
+        span_s = state["production_span_ms"] / 1e3          # first start to last end of the volume's (overlapped) launches
     roofline = {"bound": "hbm", "kernel": "trace_paths_kernel", "achieved": round(trace_bytes / span_s / 1e9, 3),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trace_bytes / span_s / 1e9 / HBM_PEAK_GBS, 6),
                 "traffic": tr_traffic, "traffic_source": tr_src, "bytes_per_launch": int(trace_bytes),
                 "ms_per_launch": round(span_s * 1e3, 3),
                 "launches": [{"labels": int(c), "ms": round(float(m), 3)} for c, m in kms],
-                "launch_note": "algorithmic bytes of ONE volume (SURVEY 8d, all its labels) / the longest of the volume's overlapped "
+                "launch_note": "algorithmic bytes of ONE volume (SURVEY 8d, all its labels) / the span (first start to last end) of the volume's overlapped "
                                "path-loop launches (the 256 largest labels run as trace_paths_kernel<false, 2> on a second stream, the "
                                "rest as <false, 1>), HIP events on each launch's own stream, taken during the single_volume_ms call "
                                "(one volume alone on the GPU, production kernels)",

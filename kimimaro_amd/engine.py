@@ -169,6 +169,7 @@ class Engine:
         self.torch.cuda.set_device(self.device)
         self.last_tasks = None   # task records (statistics, status) of this engine's most recent run_labels call
         self.last_path_kernel_ms = []   # (labels, milliseconds) of its path-loop launches when `timings` was asked for (HIP events)
+        self.last_path_span_ms = 0.0    # first start to last end of those launches (they overlap on two streams)
         self.profile = False  # True: kh_trace_paths also fills the pop / push / fire cycle split (slower)
         self._side = None     # second stream: the biggest labels run there while the others are collected
         self.split_slots = int(os.environ.get("KH_SPLIT_SLOTS", "256"))   # labels that go to the second stream (one big-LDS workgroup per CU) when results are consumed incrementally
@@ -813,6 +814,9 @@ class Engine:
         def kernel_times():
             """milliseconds of each path-loop launch of this call, from HIP events on the launch's own stream"""
             self.last_path_kernel_ms = [(c, e0.elapsed_time(e1)) for _, c, e0, e1, _ in kernel_events]
+            # the span of the path phase: first start to last end over the (overlapped) launches of this call
+            first = min(kernel_events, key=lambda k: -min(k[2].elapsed_time(o[2]) for o in kernel_events))[2] if kernel_events else None
+            self.last_path_span_ms = max((first.elapsed_time(e1) for _, _, _, e1, _ in kernel_events), default=0.0) if first else 0.0
 
         def collect(lo, hi):
             """results of task slots [lo, hi) (device -> host on the current stream)."""
