@@ -151,6 +151,9 @@ typedef struct kh_label_t {
                             each, rounded up to 256 bytes): the fifth to eighth possible owner of a voxel (csrc/sweep.h) */
   uint32_t stat_ghost_calls;  /* out: calls of the sweep that left voxels undecided and went on with them as ghosts */
   uint32_t stat_rollbacks;    /* out: times the label rolled back to such a call and redid it by the heap emulation */
+  /* KH_TRACE_FUSED_EDF: compute_pdrf's parameters (kimimaro/trace.py:315-356, the repeated-squaring branch) */
+  uint32_t pdrf_log2e;   /* in: log2 of pdrf_exponent */
+  float pdrf_scale;      /* in: pdrf_scale */
 } kh_label_t;
 
 /* ---- a4: dijkstra3d.euclidean_distance_field for a batch of labels ------------------
@@ -190,6 +193,8 @@ int kh_apply_voxel_graph(uint32_t* nbrmask, const uint32_t* graph, int64_t nvox,
  *   log2_exponent = KH_PDRF_FINISH  pdrf = pdrf*scale + daf/max_daf, daf normalised in place -- the tail of the normal call. */
 #define KH_PDRF_BASE (-1)
 #define KH_PDRF_FINISH (-2)
+#define KH_PDRF_KEEP_OTHERS 0x100   /* ORed into a log2_exponent >= 0: the voxels of unselected labels are left as they are (instead of
+                                       +inf) -- the selected labels are only a part of what another launch computes into the same volume */
 int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* slot_of_label,
             const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale,
             float* pdrf, void* stream);
@@ -248,8 +253,13 @@ int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const int32_t* sl
                                        it first runs the heap emulation and its ghost journal ((2 * q_capacity + 3) / 4 nodes) when it first
                                        makes a ghost; `journal` is ignored, heap_offset too.  A label the pool cannot serve ends with
                                        KH_ST_HEAP_OVERFLOW (trace it again with a slice of its own) or goes on without ghosts. */
+#define KH_TRACE_FUSED_EDF 512      /* the label's workgroup runs find_root, the DAF search and compute_pdrf itself before its path loop
+                                       (what kh_edf_batch modes 1 and 2, kh_gather_f32 and kh_pdrf do for all labels at once): a task with
+                                       root == 0xFFFFFFFF gets its root from the search from task.source; list_daf and pdrf are OUTPUTS for
+                                       the tasks' voxels (pdrf elsewhere is not read), dist serves as the searches' field; task.M,
+                                       pdrf_log2e, pdrf_scale, fsr as for kh_pdrf / kh_edf_batch.  Only the power-of-two exponents. */
 #define KH_SWEEP_LDS_LEVELS 16384   /* level words kept in LDS up to this many levels per label */
-int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
+int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, float* list_daf,
                    const uint32_t* nbrmask,
                    int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                    const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,

@@ -30,7 +30,7 @@ class KimiHipError(RuntimeError):
     pass
 
 
-# kh_label_t  (include/kimi_hip.h) -- 50 x 4 bytes
+# kh_label_t  (include/kimi_hip.h) -- 52 x 4 bytes
 LABEL_T = np.dtype([
     ("segid", "<u4"), ("list_offset", "<u4"), ("count", "<u4"), ("xmin", "<u4"), ("xmax", "<u4"),
     ("source", "<u4"), ("max_loc", "<u4"), ("max_val", "<f4"), ("M", "<f4"), ("root", "<u4"),
@@ -44,11 +44,13 @@ LABEL_T = np.dtype([
     ("nlev", "<u4"), ("sweep_rmax", "<f4"), ("ev_offset", "<u4"), ("ev_chunks", "<u4"), ("ev_shift", "<u4"),
     ("stat_sweep_calls", "<u4"), ("stat_sweep_bails", "<u4"), ("stat_sweep_levels", "<u4"), ("stat_sweep_events", "<u4"),
     ("stat_sweep_why", "<u4"), ("lev_window", "<u4"), ("ev_spill", "<u4"), ("stat_ghost_calls", "<u4"), ("stat_rollbacks", "<u4"),
+    ("pdrf_log2e", "<u4"), ("pdrf_scale", "<f4"),
 ])
-assert LABEL_T.itemsize == 200
+assert LABEL_T.itemsize == 208
 SWEEP_LDS_LEVELS = 16384  # KH_SWEEP_LDS_LEVELS
 SWEEP_MAX_LEVELS = 1 << 22  # labels with more levels than this use the heap emulation only
 PDRF_BASE, PDRF_FINISH = -1, -2  # KH_PDRF_BASE / KH_PDRF_FINISH
+PDRF_KEEP_OTHERS = 0x100         # KH_PDRF_KEEP_OTHERS
 
 
 def is_pow2_exponent(e):

@@ -131,11 +131,12 @@ template <typename LT>
 __global__ __launch_bounds__(256) void pdrf_kernel(const LT* __restrict__ lab, int64_t nvox,
                                                    const int32_t* __restrict__ slot_of_label,
                                                    const kh_label_t* __restrict__ tasks, const float* __restrict__ dbf,
-                                                   float* __restrict__ daf, int nsq, float scale, float* __restrict__ pdrf) {
+                                                   float* __restrict__ daf, int nsq, float scale, float* __restrict__ pdrf, int keep) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * 256) {
     const uint32_t L = ld_label(lab, i);
     const int slot = L ? slot_of_label[L] : -1;
     float p = KH_INF;
+    if (slot < 0 && keep) continue;        // KH_PDRF_KEEP_OTHERS: not this call's voxel
     if (slot >= 0) {
       const float M = tasks[slot].M;
       const float max_daf = tasks[slot].max_val;
@@ -384,14 +385,16 @@ extern "C" int kh_pdrf(const void* labels, int label_bytes, int64_t nvox, const 
                        const kh_label_t* tasks, const float* dbf, float* daf, int log2_exponent, float scale, float* pdrf,
                        void* stream) {
   if (int rc = require_device()) return rc;
+  int keep = 0;
+  if (log2_exponent >= 0 && (log2_exponent & KH_PDRF_KEEP_OTHERS)) { keep = 1; log2_exponent &= ~KH_PDRF_KEEP_OTHERS; }
   if ((log2_exponent < 0 && log2_exponent != KH_PDRF_BASE && log2_exponent != KH_PDRF_FINISH) || log2_exponent > 15) {
-    set_error("kh_pdrf: log2_exponent must be 0..15, KH_PDRF_BASE or KH_PDRF_FINISH");
+    set_error("kh_pdrf: log2_exponent must be 0..15 (| KH_PDRF_KEEP_OTHERS), KH_PDRF_BASE or KH_PDRF_FINISH");
     return KH_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
   KH_DISPATCH_LT(label_bytes, hipLaunchKernelGGL((pdrf_kernel<LT>), dim3(grid_for(nvox, 256)), dim3(256), 0, st,
                                                  (const LT*)labels, nvox, slot_of_label, tasks, dbf, daf, log2_exponent, scale,
-                                                 pdrf));
+                                                 pdrf, keep));
   KH_LAUNCH_CHECK();
   return KH_OK;
 }

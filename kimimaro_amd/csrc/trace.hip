@@ -286,27 +286,19 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g_, const uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int mode, const uint32_t* __restrict__ lists,
-                                                        const uint32_t* __restrict__ nbrmask, Geometry g, float* field,
-                                                        uint8_t* qstate, uint32_t* queues, float delta_floor) {
-  __shared__ Ctl ctl;
-  kh_label_t* task = &tasks[blockIdx.x];
+// One distance-field search of ONE label by its workgroup (dijkstra3d.euclidean_distance_field, kimimaro/trace.py:139-145, 302-307):
+// the field over the label's voxels from `source`, +inf before; task.max_loc / max_val = the farthest voxel (ties -> smallest
+// linear index); mode 1 (find_root): task.root = that voxel.  Out of line: the batch kernel and the path kernel share it.
+__device__ __attribute__((noinline)) void edf_label(Ctl* ctl_, kh_label_t* task, int mode, const uint32_t* __restrict__ list, uint32_t nf,
+                                                    const uint32_t* __restrict__ nbrmask, float* field, uint8_t* qstate, Queues q,
+                                                    float delta_floor, uint32_t source) {
+  Ctl& ctl = *ctl_;
+  const Geometry& g = ctl.g;
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
-  if (mode == 1 && task->root != 0xFFFFFFFFu) return;
-  const uint32_t source = (mode == 2) ? task->root : task->source;
-  const uint32_t* list = lists + task->list_offset;
-  const uint32_t nf = task->count;
-  if (tid == 0) { ctl.status = 0; ctl.g = g; }
   for (uint32_t i = tid; i < nf; i += nthr) st_f32_l2(&field[list[i]], KH_INF);
   __syncthreads();
-  Queues q;
-  q.cap = task->q_capacity;
-  q.a = queues + (uint64_t)task->q_offset * 4;
-  q.b = q.a + q.cap;
-  q.c = q.b + q.cap;
-  q.touched = q.c + q.cap;
   uint32_t seeded = 0;
   if (mode == 2 && task->fsr > 0.0f) {
     // free_space_radius (trace.py:134,142; dijkstra3d source absent, restated in oracle ko_edf): label
@@ -359,8 +351,29 @@ __global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int 
     task->max_loc = loc;
     task->max_val = __uint_as_float((uint32_t)(best >> 32));
     if (mode == 1) task->root = loc;
-    task->status |= ctl.status;
+    ctl.red64[0] = best;          // (for the callers' other threads: the record itself was written by this thread only)
   }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int mode, const uint32_t* __restrict__ lists,
+                                                        const uint32_t* __restrict__ nbrmask, Geometry g, float* field,
+                                                        uint8_t* qstate, uint32_t* queues, float delta_floor) {
+  __shared__ Ctl ctl;
+  kh_label_t* task = &tasks[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (mode == 1 && task->root != 0xFFFFFFFFu) return;
+  const uint32_t source = (mode == 2) ? task->root : task->source;
+  if (tid == 0) { ctl.status = 0; ctl.g = g; }
+  __syncthreads();
+  Queues q;
+  q.cap = task->q_capacity;
+  q.a = queues + (uint64_t)task->q_offset * 4;
+  q.b = q.a + q.cap;
+  q.c = q.b + q.cap;
+  q.touched = q.c + q.cap;
+  edf_label(&ctl, task, mode, lists + task->list_offset, task->count, nbrmask, field, qstate, q, delta_floor, source);
+  if (tid == 0) task->status |= ctl.status;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -985,7 +998,7 @@ template <bool PROF, int TOPL>
 #define KH_TRACE_WAVES_PER_EU 3   /* 168 VGPRs; 4 -> 128 VGPRs with 66 of them spilled */
 #endif
 __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel(kh_label_t* tasks, const uint32_t* __restrict__ lists,
-                                                          const float* __restrict__ list_daf,
+                                                          float* list_daf,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g,
                                                           const float* __restrict__ dbf, float* pdrf, float* dist,
                                                           uint8_t* alive, uint8_t* qstate,
@@ -1006,7 +1019,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t* list = lists + task->list_offset;
-  const float* ldaf = list_daf + task->list_offset;
+  float* ldaf = list_daf + task->list_offset;
   const uint32_t nf = task->count;
   Queues q;
   q.cap = task->q_capacity;
@@ -1027,7 +1040,8 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   uint32_t* journal = (journal_buf && !pool) ? journal_buf + (uint64_t)task->q_offset * 2 : nullptr;   // 2 * q_capacity entries; pool: on demand
   bool journal_off = false;            // the pool could not serve this label's journal: its ghost calls are rolled back at once
   const uint32_t pcap = task->path_capacity;
-  const uint32_t root = task->root;
+  uint32_t root = task->root;          // (0xFFFFFFFF with KH_TRACE_FUSED_EDF: found below, trace.py:291-308)
+  uint32_t daf_loc = 0xFFFFFFFFu;      // KH_TRACE_FUSED_EDF: the voxel farthest from the root (the implicit first target, trace.py:160-172)
   const uint32_t* before = manual_targets + task->tgt_offset;
   const uint32_t* after = before + task->n_before;
   const bool soma = task->soma_mode != 0;
@@ -1053,6 +1067,45 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
   // the spill table of the sweep starts all-free (the arena is uninitialised memory)
   for (uint32_t i = tid; i < sw.spcap; i += nthr) { sw.spk[i] = 0u; sw.spc[i] = 0ull; }
   __syncthreads();
+  if (ghost_mode & 16u) {
+    // KH_TRACE_FUSED_EDF (round 6): the label's two distance-field searches and its PDRF run HERE, by the label's own workgroup,
+    // instead of as three launches over all labels in front of this kernel -- with volumes in flight every launch waits for the
+    // slots the others' path workgroups hold, and the chain of a volume (its largest label that needs the heap emulation) could
+    // only start once the searches of ALL its labels were through: 2.3 s into a 8.6 s round of twenty volumes.
+    // find_root (trace.py:291-308), DAF from the root (:139-145) into `dist` (+inf again afterwards), then per voxel of the list:
+    // the DAF for the target finder and compute_pdrf (:315-356, the repeated-squaring branch), every operation rounded to f32.
+    const float delta_floor = 2.0f * fminf(g.wx, fminf(g.wy, g.wz));
+    if (root == 0xFFFFFFFFu) {
+      edf_label(&ctl, task, 1, list, nf, nbrmask, dist, qstate, q, delta_floor, task->source);
+      root = 0xFFFFFFFFu - (uint32_t)ctl.red64[0];         // (every thread: the record was written by thread 0 only)
+      __syncthreads();
+    }
+    edf_label(&ctl, task, 2, list, nf, nbrmask, dist, qstate, q, delta_floor, root);
+    const float max_daf = __uint_as_float((uint32_t)(ctl.red64[0] >> 32));
+    daf_loc = 0xFFFFFFFFu - (uint32_t)ctl.red64[0];
+    const float M = task->M, pscale = task->pdrf_scale;
+    const int nsq = (int)task->pdrf_log2e;
+    __syncthreads();
+    for (uint32_t i = tid; i < nf; i += nthr) {
+      const uint32_t v = list[i];
+      float d = ld_f32_l2(&dist[v]);
+      ldaf[i] = d;
+      float p = dbf[v] * M;        // np.multiply(DBF, M)            trace.py:341
+      p = 1.0f - p;                // np.subtract(f(1), PDRF)        trace.py:342
+      for (int sq = 0; sq < nsq; sq++) p = p * p;   //              trace.py:343-345
+      p = p * pscale;              // PDRF *= f(pdrf_scale)          trace.py:349
+      if (d == KH_INF) d = 0.0f;   // inf2zero                       trace.py:146
+      if (max_daf != 0.0f) {
+        const float inv = 1.0f / max_daf;   // (1 / max_daf) in float32 (numpy 2 scalar)  trace.py:353
+        d = d * inv;
+        p = p + d;                 //                                trace.py:354
+      }
+      pdrf[v] = p;
+      st_f32_l2(&dist[v], KH_INF);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+  }
   if (soma) {
     // trace.py:160-168: one-off invalidation around the soma centre, before valid_labels is counted (:211)
     if (tid == 0) pverts[0] = root;
@@ -1085,7 +1138,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
       // ---- target selection, trace.py:225-230
       t0 = clock64();
       uint32_t target;
-      if (nb > 0) { nb--; target = implicit ? task->max_loc : before[nb]; }
+      if (nb > 0) { nb--; target = implicit ? (daf_loc != 0xFFFFFFFFu ? daf_loc : task->max_loc) : before[nb]; }
       else if (valid == 0) { na--; target = after[na]; }
       else {
         // CachedTargetFinder.find_target: the valid voxel with the largest DAF (ties: largest index)
@@ -1591,7 +1644,7 @@ static bool sweep_global(SweepGlobal& sg, const uint32_t* level_rank, int64_t ra
   return true;
 }
 template <bool PROF, int TOPL = 1>
-static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, const float* list_daf,
+static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint32_t* lists, float* list_daf,
                         const uint32_t* nbrmask, const Geometry& g, const float* dbf, float* pdrf, float* dist,
                         uint8_t* alive, uint8_t* qstate, const uint32_t* manual_targets, float scale, float constant,
                         uint32_t* queues, hnode_t* heap_nodes, uint32_t* path_vertices, uint32_t* path_lengths,
@@ -1642,7 +1695,7 @@ extern "C" int kh_level_keys(int64_t ra, int64_t rb, int64_t rc, float wx, float
   return KH_OK;
 }
 
-extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, const float* list_daf,
+extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lists, float* list_daf,
                               const uint32_t* nbrmask, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
                               const float* dbf, float* pdrf, float* dist, uint8_t* alive, uint8_t* qstate,
                               const uint32_t* manual_targets, float scale, float constant, uint32_t* queues,
@@ -1656,7 +1709,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   if (((uintptr_t)qstate & 3) != 0) { set_error("kh_trace_paths: qstate must be 4-byte aligned"); return KH_EINVAL; }
   if (((uintptr_t)heap_nodes & 15) != 0) { set_error("kh_trace_paths: heap_nodes must be 16-byte aligned"); return KH_EINVAL; }
   if ((flags & ~(KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 | KH_TRACE_THREADS_128 | KH_TRACE_NO_GHOSTS |
-                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP | KH_TRACE_VOXEL_GRAPH | KH_TRACE_SCRATCH_POOL)) ||
+                 KH_TRACE_GHOST_PARANOID | KH_TRACE_BIG_LDS_HEAP | KH_TRACE_VOXEL_GRAPH | KH_TRACE_SCRATCH_POOL | KH_TRACE_FUSED_EDF)) ||
       ((flags & KH_TRACE_THREADS_64) && (flags & KH_TRACE_THREADS_128))) {
     set_error("kh_trace_paths: unknown flags");
     return KH_EINVAL;
@@ -1675,7 +1728,7 @@ extern "C" int kh_trace_paths(kh_label_t* tasks, int ntasks, const uint32_t* lis
   // ghosts need the journal (and, with rails, the saved weights); bit 1: roll every ghost call back at once
   const bool use_pool = (flags & KH_TRACE_SCRATCH_POOL) != 0;
   const uint32_t ghost_mode = ((journal || use_pool) && !(flags & KH_TRACE_NO_GHOSTS) ? 1u : 0u) | ((flags & KH_TRACE_GHOST_PARANOID) ? 2u : 0u) |
-                              ((flags & KH_TRACE_VOXEL_GRAPH) ? 4u : 0u) | (use_pool ? 8u : 0u);
+                              ((flags & KH_TRACE_VOXEL_GRAPH) ? 4u : 0u) | (use_pool ? 8u : 0u) | ((flags & KH_TRACE_FUSED_EDF) ? 16u : 0u);
   if (flags & KH_TRACE_BIG_LDS_HEAP)
     return launch_trace<false, 2>(ntasks, st, tasks, lists, list_daf, nbrmask, g, dbf, pdrf, dist, alive, qstate, manual_targets,
                                   scale, constant, queues, (hnode_t*)heap_nodes, path_vertices, path_lengths, fix_branching, sg,

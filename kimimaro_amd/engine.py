@@ -181,6 +181,11 @@ class Engine:
         # heap and ghost journal of a launch's labels from one pool, on demand (False: a slice per label, rounds 1-5)
         self.scratch_pool = os.environ.get("KH_SCRATCH_POOL", "1") != "0"
         self.scratch_pool_fraction = SCRATCH_POOL_FRACTION      # tests: a pool too small for the labels that ask (they are traced again)
+        # find_root, the DAF search and compute_pdrf inside the path kernel, by each label's own workgroup (KH_TRACE_FUSED_EDF);
+        # False: as launches of their own over all labels in front of it (rounds 1-5; kept for return_fields and other exponents)
+        self.fuse_edf = os.environ.get("KH_FUSE_EDF", "1") != "0"
+        # volumes in flight: this many of the largest labels of a call are fused and launched FIRST, on a second stream (0: off)
+        self.early_labels = int(os.environ.get("KH_EARLY_LABELS", "0"))
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
         # ghosts: a call of the sweep that leaves voxels undecided goes on with them as ghosts instead of running
@@ -631,6 +636,9 @@ class Engine:
         tasks["path_offset"] = p_off
         tasks["path_capacity"] = pcap
         tasks["max_paths"] = 0 if max_paths is None else int(max_paths)
+        if _abi.is_pow2_exponent(params["pdrf_exponent"]):     # KH_TRACE_FUSED_EDF: compute_pdrf's parameters travel with the task
+            tasks["pdrf_log2e"] = int(params["pdrf_exponent"]).bit_length() - 1
+            tasks["pdrf_scale"] = np.float32(params["pdrf_scale"])
         if soma is not None:  # per label (caller order): soma_mode, fsr, soma_radius, soma_scale, soma_const
             for key in ("soma_mode", "fsr", "soma_radius", "soma_scale", "soma_const"):
                 tasks[key] = np.asarray(soma[key])[order]
@@ -688,7 +696,6 @@ class Engine:
         d_lists = self.empty(max(total, 1), t.int32)
         d_tgt = t.from_numpy(tgt_arr.view(np.int32)).to(self.device)
         d_nbr = self.empty(nvox, t.int32)
-        d_field = self.empty(nvox, t.float32)
         d_queues = self.empty(4 * int(qcap.sum()), t.int32)
         d_qstate = self.torch.zeros(nvox + 4, dtype=t.uint8, device=self.device)
         P = self.ptr
@@ -710,37 +717,72 @@ class Engine:
             d_gate = t.zeros(nvox + 4, dtype=t.uint8, device=self.device)
             _abi.check(lib.kh_apply_voxel_graph(P(d_nbr), P(voxel_graph), nvox, P(d_gate), st))
         mark("lists+nbrmask")
-        # find_root (trace.py:291-308) then DAF (trace.py:139-145)
-        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 1 | (self.edf_threads << 8), P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
-        mark("edf_root")
-        _abi.check(lib.kh_edf_batch(P(d_tasks), nl, 2 | (self.edf_threads << 8), P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
-        mark("edf_daf")
-        d_ldaf = self.empty(max(total, 1), t.float32)
-        _abi.check(lib.kh_gather_f32(P(d_field), P(d_lists), total, P(d_ldaf), st))
-        # PDRF (trace.py:148)
         expo = params["pdrf_exponent"]
+        # The searches (find_root, DAF) and the PDRF either run inside the path kernel, by each label's own workgroup
+        # (KH_TRACE_FUSED_EDF), or as launches over the labels in front of it (`searches` below).  With volumes in flight
+        # (`early_labels`, set by kimimaro_amd.lanes) the LARGEST labels are fused and go first, on a second stream: their chains --
+        # the heap emulation of a volume's large labels, seconds long -- then start at once instead of behind the searches of all
+        # labels; the rest keeps the batch kernels (70 VGPRs: twice the waves per CU of the path kernel) on the lane's own stream.
+        can_fuse = _abi.is_pow2_exponent(expo) and not return_fields
+        early = int(min(self.early_labels, nl - 1)) if (can_fuse and consume is not None and self.early_labels > 0 and nl > 1) else 0
+        fuse_rest = can_fuse and self.fuse_edf and early == 0
+        d_ldaf = self.empty(max(total, 1), t.float32)
         d_pdrf = self.empty(nvox, t.float32)
-        pdrf_call = lambda stage: _abi.check(lib.kh_pdrf(P(d_cc), label_bytes, nvox, P(d_slot), P(d_tasks), P(d_dbf), P(d_field),
-                                                         stage, np.float32(params["pdrf_scale"]), P(d_pdrf), st))
-        if _abi.is_pow2_exponent(expo):
-            pdrf_call(int(expo).bit_length() - 1)          # repeated squaring, trace.py:343-345
-        else:
-            # trace.py:346-347: np.power.  Its rounding is the host numpy's (libm / SVML powf), which no device powf can
-            # promise, so exactly that function is applied -- by numpy itself -- between the two device halves.
-            # Only the selected labels' voxels make the trip (their list is on the device already): gathered into a compact
-            # array, raised on the host, scattered back -- 8 B per foreground voxel instead of 8 B per voxel of the volume.
-            pdrf_call(_abi.PDRF_BASE)
-            d_base = self.empty(max(total, 1), t.float32)
-            _abi.check(lib.kh_gather_f32(P(d_pdrf), P(d_lists), total, P(d_base), st))
-            base = d_base[:total].cpu().numpy()
-            with np.errstate(all="ignore"):
-                np.power(base, expo, out=base)
-            idx = d_lists[:total].to(t.int64) & 0xFFFFFFFF       # u32 linear indices kept in an int32 tensor
-            d_pdrf.index_copy_(0, idx, t.from_numpy(base).to(self.device))
-            pdrf_call(_abi.PDRF_FINISH)
-        mark("pdrf")
-        if not return_fields:
-            del d_field          # the DAF lives on in list order (d_ldaf); its volume goes back to the pool
+        fields = {"d_field": None}
+
+        def searches(first, count):
+            """find_root + DAF + PDRF of the task slots [first, first + count) as batch launches on the current stream"""
+            if count <= 0:
+                return
+            if fields["d_field"] is None:
+                fields["d_field"] = self.empty(nvox, t.float32)
+            d_field = fields["d_field"]
+            tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
+            lo = int(list_off[first])
+            n_list = int(cnt[first:first + count].sum())
+            lists_ptr = C.c_void_p(d_lists.data_ptr() + 4 * lo)
+            ldaf_ptr = C.c_void_p(d_ldaf.data_ptr() + 4 * lo)
+            d_slot_use, keep = d_slot, 0
+            if first > 0 or first + count < nl:
+                # only these labels: the others' voxels are left alone (they are another launch's business)
+                sl = slot_of_label.copy()
+                sl[segids[order][:first]] = -1
+                sl[segids[order][first + count:]] = -1
+                d_slot_use, keep = t.from_numpy(sl).to(self.device), _abi.PDRF_KEEP_OTHERS
+            # find_root (trace.py:291-308) then DAF (trace.py:139-145)
+            _abi.check(lib.kh_edf_batch(tasks_ptr, count, 1 | (self.edf_threads << 8), P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
+            mark("edf_root")
+            _abi.check(lib.kh_edf_batch(tasks_ptr, count, 2 | (self.edf_threads << 8), P(d_lists), P(d_nbr), sx, sy, sz, wx, wy, wz, P(d_field), P(d_qstate), P(d_queues), st))
+            mark("edf_daf")
+            _abi.check(lib.kh_gather_f32(P(d_field), lists_ptr, n_list, ldaf_ptr, st))
+            # PDRF (trace.py:148)
+            pdrf_call = lambda stage: _abi.check(lib.kh_pdrf(P(d_cc), label_bytes, nvox, P(d_slot_use), P(d_tasks), P(d_dbf), P(d_field),
+                                                             stage | keep if stage >= 0 else stage, np.float32(params["pdrf_scale"]),
+                                                             P(d_pdrf), st))
+            if _abi.is_pow2_exponent(expo):
+                pdrf_call(int(expo).bit_length() - 1)          # repeated squaring, trace.py:343-345
+            else:
+                # trace.py:346-347: np.power.  Its rounding is the host numpy's (libm / SVML powf), which no device powf can
+                # promise, so exactly that function is applied -- by numpy itself -- between the two device halves.
+                # Only the selected labels' voxels make the trip (their list is on the device already): gathered into a compact
+                # array, raised on the host, scattered back -- 8 B per foreground voxel instead of 8 B per voxel of the volume.
+                pdrf_call(_abi.PDRF_BASE)
+                d_base = self.empty(max(total, 1), t.float32)
+                _abi.check(lib.kh_gather_f32(P(d_pdrf), P(d_lists), total, P(d_base), st))
+                base = d_base[:total].cpu().numpy()
+                with np.errstate(all="ignore"):
+                    np.power(base, expo, out=base)
+                idx = d_lists[:total].to(t.int64) & 0xFFFFFFFF       # u32 linear indices kept in an int32 tensor
+                d_pdrf.index_copy_(0, idx, t.from_numpy(base).to(self.device))
+                pdrf_call(_abi.PDRF_FINISH)
+            mark("pdrf")
+            if not return_fields:
+                fields["d_field"] = None     # the DAF lives on in list order (d_ldaf); its volume goes back to the pool
+
+        searched = False
+        if early == 0 and not fuse_rest:
+            searches(0, nl)          # (before the path loop's own volumes are allocated: the DAF volume's block serves them afterwards)
+            searched = True
         d_dist = self.empty(nvox, t.float32)
         _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
@@ -772,6 +814,8 @@ class Engine:
         n_large = int(min(self.split_slots, np.count_nonzero(cnt >= self.split_min_voxels)))
         if self.big_lds_labels is not None:     # (also in a lane, whose split_slots is 0: the lane then uses a second stream)
             n_large = int(min(self.big_lds_labels, np.count_nonzero(cnt >= self.split_min_voxels)))
+        if early > 0:
+            n_large = early
         # KH_TRACE_PROFILE | KH_TRACE_HEAP_PRIO | KH_TRACE_THREADS_64 / _128
         # ... | KH_TRACE_NO_GHOSTS | KH_TRACE_GHOST_PARANOID
         prof = (1 if self.profile else 0) | (2 if self.heap_prio else 0) | {64: 4, 128: 8}.get(self.trace_threads, 0) | \
@@ -791,10 +835,11 @@ class Engine:
 
         kernel_events = []     # (first, count, start, end): HIP events on the stream each path-loop launch went to (timings only)
 
-        def launch(first, count, stream, tstream=None, big=False):
+        def launch(first, count, stream, tstream=None, big=False, fused=False):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
             big_ok = self.trace_threads == 256 if self.big_lds_labels is None else True
-            flags = prof | (64 if big and self.big_lds_heap and big_ok else 0) | (256 if use_pool else 0)   # KH_TRACE_BIG_LDS_HEAP, _SCRATCH_POOL
+            flags = prof | (64 if big and self.big_lds_heap and big_ok else 0) | (256 if use_pool else 0) | (512 if fused else 0)
+            # (KH_TRACE_BIG_LDS_HEAP, KH_TRACE_SCRATCH_POOL, KH_TRACE_FUSED_EDF)
             if big and self.big_threads:          # the second-stream launch with a thread count of its own
                 flags = (flags & ~12) | {64: 4, 128: 8}.get(self.big_threads, 0)
             if timings is not None or self.time_kernels:
@@ -892,10 +937,14 @@ class Engine:
             cur = t.cuda.current_stream(self.device)
             if self._side is None:
                 self._side = t.cuda.Stream(device=self.device)
+            if not (fuse_rest or early > 0 or searched):
+                searches(0, nl)                 # (no fusion at all: every label's searches before either launch)
             self._side.wait_stream(cur)
-            launch(0, n_large, C.c_void_p(self._side.cuda_stream), self._side, big=True)
+            launch(0, n_large, C.c_void_p(self._side.cuda_stream), self._side, big=(early == 0), fused=(fuse_rest or early > 0))
             try:
-                launch(n_large, nl - n_large, st)
+                if early > 0:
+                    searches(n_large, nl - n_large)
+                launch(n_large, nl - n_large, st, fused=fuse_rest)
                 small = collect(n_large, nl)
                 consume(small)                  # overlaps the big labels' kernel: no device-wide sync in here
             finally:
@@ -910,7 +959,9 @@ class Engine:
             mark("d2h")
             self.last_tasks = splice_retried(np.concatenate([big["tasks"], small["tasks"]]))
             return None
-        launch(0, nl, st)
+        if not fuse_rest and not searched:
+            searches(0, nl)
+        launch(0, nl, st, fused=fuse_rest)
         mark("paths")
         res = collect(0, nl)                  # (its device -> host copies wait for the launch)
         if timings is not None or self.time_kernels:
@@ -943,7 +994,7 @@ class Engine:
             res["loff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_l])])
         self.last_tasks = res["tasks"]
         if return_fields:
-            res["daf"] = d_field.cpu().numpy()
+            res["daf"] = fields["d_field"].cpu().numpy()
             res["pdrf"] = d_pdrf.cpu().numpy()
             res["alive"] = d_alive.cpu().numpy()
         return res

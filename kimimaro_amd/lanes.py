@@ -71,6 +71,10 @@ class Lanes:
                 e = Engine(device)
                 if "KH_TRACE_THREADS" not in os.environ:
                     e.trace_threads = LANE_THREADS
+                if "KH_FUSE_EDF" not in os.environ:
+                    # the searches stay batch launches of their own in a lane (70 VGPRs: twice the waves per CU of the path kernel);
+                    # fused into the path kernel (the single-volume default) twenty volumes took 523 ms per step against 428
+                    e.fuse_edf = False
                 e.soma_lanes = 1        # (no lanes inside a lane: the other volumes are what fills the GPU)
                 return e
 
@@ -257,6 +261,8 @@ def _lane_main(conn, device, setup, setup_args, index, engine_factory):
             eng = Engine(device)
             if "KH_TRACE_THREADS" not in os.environ:
                 eng.trace_threads = LANE_THREADS
+            if "KH_FUSE_EDF" not in os.environ:
+                eng.fuse_edf = False
             eng.split_slots = 0       # the other lanes are what overlaps the tail of this lane's largest components
         else:
             eng = engine_factory()

@@ -319,7 +319,7 @@ def test_skeletonize_sweep_and_heap_paths(sweep, slots):
         np.testing.assert_allclose(got[k].radii, want[k].radii, rtol=1e-4)
 
 
-@pytest.mark.parametrize("variant", ["threads64", "threads128", "table_keys", "no_window", "tiny_arena", "narrow_window", "tiny_pool", "no_pool"])
+@pytest.mark.parametrize("variant", ["threads64", "threads128", "table_keys", "no_window", "tiny_arena", "narrow_window", "tiny_pool", "no_pool", "unfused", "early_labels"])
 def test_sweep_storage_variants_and_their_bails(variant):
     """Round-4 storage of the sweep (pending-deadline filter, level window, recycled chunks) and its knobs: one wave / two
     waves per label, levels from the table of ranks (the fallback of round 6's integer levels), the window off, an arena a 64th of its size (calls run out of chunks: SW_BAIL_ARENA) and a
@@ -344,6 +344,10 @@ def test_sweep_storage_variants_and_their_bails(variant):
         eng2.scratch_pool_fraction = 0.001   # heap and journal on demand from a pool that serves nobody: ghost calls are rolled back at
     elif variant == "no_pool":               # once, labels that need the heap emulation are traced again with scratch of their own
         eng2.scratch_pool = False
+    elif variant == "unfused":
+        eng2.fuse_edf = False                # find_root / DAF / PDRF as batch launches in front of the path kernel (what the lanes run)
+    elif variant == "early_labels":
+        eng2.early_labels = 3                # the three largest labels fused and first on a second stream, the rest behind batch searches
     an = (16, 16, 40)
     lab = voronoi_labels((96, 96, 40), 7, seed=5, pts_per_label=3, step=12.0, anisotropy=an)
     params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
