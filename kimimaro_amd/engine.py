@@ -737,6 +737,11 @@ class Engine:
             if fields["d_field"] is None:
                 fields["d_field"] = self.empty(nvox, t.float32)
             d_field = fields["d_field"]
+            _searches_launch(first, count, d_field)
+            if not return_fields:
+                fields["d_field"] = None     # the DAF lives on in list order (d_ldaf); its volume goes back to the pool
+
+        def _searches_launch(first, count, d_field):
             tasks_ptr = C.c_void_p(d_tasks.data_ptr() + first * _abi.LABEL_T.itemsize)
             lo = int(list_off[first])
             n_list = int(cnt[first:first + count].sum())
@@ -776,8 +781,6 @@ class Engine:
                 d_pdrf.index_copy_(0, idx, t.from_numpy(base).to(self.device))
                 pdrf_call(_abi.PDRF_FINISH)
             mark("pdrf")
-            if not return_fields:
-                fields["d_field"] = None     # the DAF lives on in list order (d_ldaf); its volume goes back to the pool
 
         searched = False
         if early == 0 and not fuse_rest:

@@ -11,6 +11,7 @@
 #   bench:<name>:<args with , for spaces>[:ENV=V,...]   any other bench.py call
 #   pmc:<name>[:ENV=V,...]       counter passes of the path kernel on one c3 volume (FETCH_SIZE / WRITE_SIZE / SQ / TCC, one set per run)
 #   kstats:<name>[:ENV=V,...]    rocprofv3 --kernel-trace --stats of one bench step
+#   ktrace:<name>:<bench args>[:ENV]   rocprofv3 --kernel-trace of a bench call, summarised as a timeline (tools/summarize_timeline.py)
 #   probe:<name>:<threads>:LIB=<probe build>   per-phase cycles of the sweep's level loop (-DKH_SWEEP_PROBE build)
 #   smoke                        __graft_entry__.smoke()
 # ENV: e.g. LIB=build_variants/libkimi_base.so (another build of the library, loaded through KIMI_HIP_LIB), KH_TRACE_THREADS=64
@@ -92,6 +93,11 @@ for STEP in "$@"; do
         rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_$A1 -o kt -- \
           python $REPO/bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline > $OUT/kstats_$A1.json 2> $OUT/kstats_$A1.err )
       find $OUT/kstats_$A1 -name "*kernel_stats.csv" | head -1 | xargs -r head -8 ;;
+    ktrace)  # ktrace:<name>:<bench args with , for spaces>[:ENV]   kernel timeline of a bench call (rocprofv3 --kernel-trace)
+      ( envs "${A3:-}"; cd /tmp && export TMPDIR=/tmp
+        rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace_$A1 -o kt -- \
+          python $REPO/bench.py $(echo $A2 | tr ',' ' ') --no-cpu-baseline > $OUT/ktrace_$A1.json 2> $OUT/ktrace_$A1.err )
+      python tools/summarize_timeline.py $(find $OUT/ktrace_$A1 -name "*kernel_trace.csv" | head -1) ;;
     probe)   # probe:<name>:<threads>[:ENV]  cycles per phase of the sweep's level loop (a -DKH_SWEEP_PROBE build given by LIB=)
       ( envs "${A3:-}"; KH_TRACE_THREADS=${A2:-64} timeout 600 python tools/trace_only.py c3 > $OUT/probe_$A1.txt 2>&1 )
       grep TRACEONLY $OUT/probe_$A1.txt
