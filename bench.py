@@ -187,6 +187,19 @@ def cpu_baseline_all_cores(cc_labels, an, params, dust_threshold, one_core_rate,
             os.remove(path)
 
 
+def _daf_tie_note(workload):
+    """the one tie the reference leaves to numpy's unstable argsort (CachedTargetFinder, skeletontricks.pyx:1004): how many skeletons
+    of this workload depend on it (tools/daf_tie_exposure.py --flip, committed under profiles/)"""
+    path = os.path.join(ROOT, "profiles", "r06_%s_daf_tie_flip.json" % workload)
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    o = d.get("opposite_tie_rule", {})
+    return ("%d of %d target selections had an equal-DAF rival; with the opposite tie rule %d of %d skeletons differ (oracle, %s)"
+            % (d["selections_with_an_equal_daf_rival"], d["target_selections"], o.get("skeletons_that_differ", -1),
+               o.get("skeletons", -1), os.path.basename(path)))
+
+
 def volume_step(e, st):
     """the whole step of one rank's share of the volume in `st` on engine e (current stream of the calling thread):
     connected components -> EDT -> statistics -> border targets -> searches -> path loop -> host skeletons."""
@@ -708,6 +721,7 @@ def main():
         "value_single_volume": round(ncomp / (single_ms / 1e3), 3) if single_ms == single_ms else None,
         "hbm_reserved_peak_gb": round((torch.cuda.max_memory_reserved() + plane["peak"]) / 1e9, 1),
         "hbm_free_when_lanes_were_chosen_gb": state.get("hbm_free_gb"),
+        "daf_tie_note": _daf_tie_note(args.workload),
         "lanes": args.lanes if inflight > 1 else "none",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint32, %d chains -> %d components > dust, anisotropy=%s, "
