@@ -106,6 +106,73 @@ __device__ __forceinline__ void gflag_clear(gu32_t* qs, uint32_t v, uint32_t bit
   __hip_atomic_fetch_and(qs + (v >> 2), ~(bit << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The 27 words around voxel u of a whole-volume u32 / f32 array as nine rows of three consecutive words:
+// w[(dx + 1) + 3 * ((dy + 1) + 3 * (dz + 1))] = a[u + dx + sx * dy + sxy * dz].  A row outside the volume reads u's own row (its
+// neighbours are in nobody's mask); a row that starts one word before the array or ends one behind it is read one word further in
+// and shifted (the missing word belongs to a neighbour outside the volume).  nvox >= 3.
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef u32x3_t u32x3_a4_t __attribute__((aligned(4)));
+__device__ __forceinline__ void rows27_base(uint32_t nvox, int sx, int sxy, int sy, int sz, uint32_t u, int y, int z, uint32_t (&bc)[9],
+                                            int (&sh)[9]) {
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int dy = r % 3 - 1, dz = r / 3 - 1;
+    const bool in = (unsigned)(y + dy) < (unsigned)sy && (unsigned)(z + dz) < (unsigned)sz;
+    const long long base = (long long)u + (in ? dy * sx + dz * sxy : 0) - 1;
+    const long long hi = nvox >= 3u ? (long long)nvox - 3 : 0;       // (arrays of fewer than three words carry padding: include/kimi_hip.h)
+    const long long c = base < 0 ? 0 : (base > hi ? hi : base);
+    bc[r] = (uint32_t)c;
+    sh[r] = (int)(base - c);
+  }
+}
+__device__ __forceinline__ void rows27_shift(const u32x3_t (&t)[9], const int (&sh)[9], uint32_t (&w)[27]) {
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    w[3 * r + 0] = sh[r] > 0 ? t[r].y : t[r].x;                       // (sh < 0: the word in front of the array -- never used)
+    w[3 * r + 1] = sh[r] > 0 ? t[r].z : (sh[r] < 0 ? t[r].x : t[r].y);
+    w[3 * r + 2] = sh[r] < 0 ? t[r].y : t[r].z;                       // (sh > 0: the word behind the array -- never used)
+  }
+}
+// words that memory-side atomics change: past the vector cache (sc1).  The nine loads and their wait are ONE asm statement, so the
+// compiler never sees a register that is still in flight; the wait also covers the loads it has issued itself just before.
+__device__ __forceinline__ void rows27_sc1(const KH_AS_GLOBAL uint32_t* a, uint32_t nvox, int sx, int sxy, int sy, int sz, uint32_t u,
+                                           int y, int z, uint32_t (&w)[27]) {
+  uint32_t bc[9];
+  int sh[9];
+  rows27_base(nvox, sx, sxy, sy, sz, u, y, z, bc, sh);
+  u32x3_t t[9];
+  asm volatile(
+      "global_load_dwordx3 %0, %9, off sc1\n\t"
+      "global_load_dwordx3 %1, %10, off sc1\n\t"
+      "global_load_dwordx3 %2, %11, off sc1\n\t"
+      "global_load_dwordx3 %3, %12, off sc1\n\t"
+      "global_load_dwordx3 %4, %13, off sc1\n\t"
+      "global_load_dwordx3 %5, %14, off sc1\n\t"
+      "global_load_dwordx3 %6, %15, off sc1\n\t"
+      "global_load_dwordx3 %7, %16, off sc1\n\t"
+      "global_load_dwordx3 %8, %17, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8])
+      : "v"(a + bc[0]), "v"(a + bc[1]), "v"(a + bc[2]), "v"(a + bc[3]), "v"(a + bc[4]), "v"(a + bc[5]), "v"(a + bc[6]), "v"(a + bc[7]),
+        "v"(a + bc[8])
+      : "memory");
+  rows27_shift(t, sh, w);
+}
+// words only plain stores of this workgroup change (the weight field: rails are zeroed between the searches)
+__device__ __forceinline__ void rows27_plain(const KH_AS_GLOBAL float* a, uint32_t nvox, int sx, int sxy, int sy, int sz, uint32_t u, int y,
+                                             int z, float (&w)[27]) {
+  uint32_t bc[9];
+  int sh[9];
+  rows27_base(nvox, sx, sxy, sy, sz, u, y, z, bc, sh);
+  u32x3_t t[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) t[r] = *(const KH_AS_GLOBAL u32x3_a4_t*)((const KH_AS_GLOBAL uint32_t*)a + bc[r]);
+  uint32_t wu[27];
+  rows27_shift(t, sh, wu);
+#pragma unroll
+  for (int i = 0; i < 27; i++) w[i] = __uint_as_float(wu[i]);
+}
+
 // MODE 0: EDF (edge length by direction).  MODE 1: railroad (cost = pdrf of the entered voxel, rails
 // absorb, stops once everything at or below the nearest rail is final).  MODE 2: parental field
 // (trace.py:155, fix_branching=False): field costs, no rails, runs to completion.
@@ -146,70 +213,71 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g_, const uint32_
       if (n == 0) break;
       for (uint32_t i = tid; i < n; i += nthr) gflag_clear(qstate, cur[i], 1u);
       __syncthreads();
-      const uint64_t items = (uint64_t)n << 5;
-      // A relaxation is a chain of dependent round trips (work list -> neighbour mask and distance of u -> weight and
-      // distance of v -> atomic), and a thread has many of them per pass when the label runs on one wave: SB of them
-      // travel together, stage by stage, so that the loads of a stage are all in flight before the first is needed.
-      constexpr int SB = 4;
-      for (uint64_t w0 = tid; w0 < items; w0 += (uint64_t)nthr * SB) {
-        uint32_t uu[SB], vv[SB], nbv[SB], oldv[SB], nmv[SB], duv[SB];
-        float wnv[SB];
-        int kk[SB];
-        bool act[SB];
+      // Round 6: ONE THREAD PER FRONTIER VOXEL.  Rounds 4-5 spread (voxel, direction) pairs over the lanes: 32 work items per voxel,
+      // each with its own loads of the voxel's mask and distance and a gather of the neighbour's -- a gather is paid per lane
+      // (csrc/sweep.h, round 6), and the pairs of one voxel sat in 32 lanes.  Now a thread reads its voxel's mask and distance and
+      // the 27 distances around it as nine rows of three consecutive words (global_load_dwordx3 sc1: past the vector cache,
+      // the words are changed by memory-side atomics) -- and with a weight field its 27 weights the same way -- in ONE round trip
+      // whose addresses depend on nothing but the voxel; the look-before-the-atomic is then arithmetic, and only the relaxations
+      // that lower a distance go out as atomics, thirteen at a time.  The wavefront of a label is a few hundred voxels: one pass.
+      const int gsx = g->sx, gsxy = g->sxy, gsy = g->sy, gsz = g->sz;
+      const uint32_t nvox = (uint32_t)gsxy * (uint32_t)gsz;
+      for (uint32_t i = tid; i < n; i += nthr) {
+        const uint32_t u = cur[i];
+        const uint32_t zz = u / (uint32_t)gsxy, rr = u - zz * (uint32_t)gsxy, yy = rr / (uint32_t)gsx;
+        const uint32_t nm = nbrmask[u];
+        const uint32_t dub = gld_l2(dist + u);
+        float wr[27];
+        if (FIELD) rows27_plain(wfield, nvox, gsx, gsxy, gsy, gsz, u, (int)yy, (int)zz, wr);
+        uint32_t dr[27];
+        rows27_sc1(dist, nvox, gsx, gsxy, gsy, gsz, u, (int)yy, (int)zz, dr);
+        const float du = __uint_as_float(dub);
 #pragma unroll
-        for (int j = 0; j < SB; j++) {
-          const uint64_t w = w0 + (uint64_t)j * nthr;
-          kk[j] = (int)(w & 31);
-          act[j] = w < items && kk[j] < 26;
-          if (!act[j]) kk[j] = 0;
-          uu[j] = act[j] ? cur[w >> 5] : source;
-        }
+        for (int h = 0; h < 2; h++) {
+          uint32_t oldv[13], nbv[13];
+          uint32_t act = 0;
 #pragma unroll
-        for (int j = 0; j < SB; j++) {
-          nmv[j] = nbrmask[uu[j]];
-          duv[j] = gld_l2(dist + uu[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < SB; j++) {
-          act[j] = act[j] && ((nmv[j] >> kk[j]) & 1u);
-          vv[j] = act[j] ? uu[j] + (uint32_t)g->off[kk[j]] : source;
-        }
-        // a look before the atomic: distances only go down, so an edge that cannot lower dist[v] now never will.  Nine
-        // out of ten relaxations end here -- as a read; the atomic they replace is a read-modify-write that leaves its
-        // line dirty even when the minimum does not change (edf_batch_kernel wrote twice as many bytes as it read)
-#pragma unroll
-        for (int j = 0; j < SB; j++) {
-          wnv[j] = FIELD ? wfield[vv[j]] : g->w[kk[j]];
-          oldv[j] = gld_l2(dist + vv[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < SB; j++) {
-          nbv[j] = __float_as_uint(__uint_as_float(duv[j]) + wnv[j]);
-          act[j] = act[j] && nbv[j] < oldv[j];
-          if (act[j]) oldv[j] = __hip_atomic_fetch_min(dist + vv[j], nbv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int j = 0; j < SB; j++) {
-          if (!act[j] || !(nbv[j] < oldv[j])) continue;
-          const uint32_t v = vv[j], nb = nbv[j], old = oldv[j];
-          const float nd = __uint_as_float(nb), wn = wnv[j];
-          if (RAIL && old == INF_BITS) {
-            const uint32_t t = __hip_atomic_fetch_add(&ctl->n_touched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (t < q.cap) touched[t] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          if (RAIL && wn == 0.0f) {  // a rail: absorbing
-            __hip_atomic_fetch_min(&ctl->best_rail, pack(nd, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            continue;
-          }
-          if (nd < T) {
-            if (!(gflag_or(qstate, v, 1u) & 1u)) {
-              const uint32_t p = __hip_atomic_fetch_add(&ctl->n_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (p < q.cap) next[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int j = 0; j < 13; j++) {
+            const int k = 13 * h + j;
+            int dx, dy, dz;
+            dir_delta(k, dx, dy, dz);
+            const int idx = (dx + 1) + 3 * ((dy + 1) + 3 * (dz + 1));
+            const float wn = FIELD ? wr[idx] : g->w[k];
+            nbv[j] = __float_as_uint(du + wn);
+            oldv[j] = dr[idx];
+            // a look before the atomic: distances only go down, so an edge that cannot lower dist[v] now never will
+            if (((nm >> k) & 1u) && nbv[j] < oldv[j]) {
+              act |= 1u << j;
+              oldv[j] = __hip_atomic_fetch_min(dist + (u + (uint32_t)(dx + gsx * dy + gsxy * dz)), nbv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-          } else {
-            if (!(gflag_or(qstate, v, 2u) & 2u)) {
-              const uint32_t p = __hip_atomic_fetch_add(&ctl->n_far, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (p < q.cap) far[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+#pragma unroll
+          for (int j = 0; j < 13; j++) {
+            if (!((act >> j) & 1u) || !(nbv[j] < oldv[j])) continue;
+            const int k = 13 * h + j;
+            int dx, dy, dz;
+            dir_delta(k, dx, dy, dz);
+            const int idx = (dx + 1) + 3 * ((dy + 1) + 3 * (dz + 1));
+            const uint32_t v = u + (uint32_t)(dx + gsx * dy + gsxy * dz), old = oldv[j];
+            const float nd = __uint_as_float(nbv[j]), wn = FIELD ? wr[idx] : 1.0f;
+            if (RAIL && old == INF_BITS) {
+              const uint32_t t = __hip_atomic_fetch_add(&ctl->n_touched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (t < q.cap) touched[t] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (RAIL && wn == 0.0f) {  // a rail: absorbing
+              __hip_atomic_fetch_min(&ctl->best_rail, pack(nd, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              continue;
+            }
+            if (nd < T) {
+              if (!(gflag_or(qstate, v, 1u) & 1u)) {
+                const uint32_t p = __hip_atomic_fetch_add(&ctl->n_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (p < q.cap) next[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            } else {
+              if (!(gflag_or(qstate, v, 2u) & 2u)) {
+                const uint32_t p = __hip_atomic_fetch_add(&ctl->n_far, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (p < q.cap) far[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
             }
           }
         }

@@ -727,7 +727,7 @@ class Engine:
         early = int(min(self.early_labels, nl - 1)) if (can_fuse and consume is not None and self.early_labels > 0 and nl > 1) else 0
         fuse_rest = can_fuse and self.fuse_edf and early == 0
         d_ldaf = self.empty(max(total, 1), t.float32)
-        d_pdrf = self.empty(nvox, t.float32)
+        d_pdrf = self.empty(nvox + 4, t.float32)
         fields = {"d_field": None}
 
         def searches(first, count):
@@ -735,7 +735,7 @@ class Engine:
             if count <= 0:
                 return
             if fields["d_field"] is None:
-                fields["d_field"] = self.empty(nvox, t.float32)
+                fields["d_field"] = self.empty(nvox + 4, t.float32)
             d_field = fields["d_field"]
             _searches_launch(first, count, d_field)
             if not return_fields:
@@ -786,8 +786,8 @@ class Engine:
         if early == 0 and not fuse_rest:
             searches(0, nl)          # (before the path loop's own volumes are allocated: the DAF volume's block serves them afterwards)
             searched = True
-        d_dist = self.empty(nvox, t.float32)
-        _abi.check(lib.kh_fill_f32(P(d_dist), nvox, float("inf"), st))
+        d_dist = self.empty(nvox + 4, t.float32)     # (+ padding: the searches read rows of three words)
+        _abi.check(lib.kh_fill_f32(P(d_dist), nvox + 4, float("inf"), st))
         d_alive = self.empty(nvox, t.uint8)
         _abi.check(lib.kh_init_alive(P(d_cc), label_bytes, nvox, P(d_slot), P(d_alive), st))
         jnodes = (2 * qcap + 3) // 4                        # a label's ghost journal in 16-byte nodes
@@ -997,7 +997,7 @@ class Engine:
             res["loff"] = np.concatenate([[0], np.cumsum([len(v) for v in per_l])])
         self.last_tasks = res["tasks"]
         if return_fields:
-            res["daf"] = fields["d_field"].cpu().numpy()
-            res["pdrf"] = d_pdrf.cpu().numpy()
+            res["daf"] = fields["d_field"][:nvox].cpu().numpy()
+            res["pdrf"] = d_pdrf[:nvox].cpu().numpy()
             res["alive"] = d_alive.cpu().numpy()
         return res

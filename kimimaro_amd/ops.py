@@ -202,12 +202,12 @@ def euclidean_distance_field(labels, source, anisotropy=(1, 1, 1), free_space_ra
     task["root"] = _loc(source, shape)
     task["fsr"] = np.float32(free_space_radius)
     d_task = t.from_numpy(task.view(np.uint8).reshape(-1).copy()).to(eng.device)
-    d_field = t.full((ctx["nvox"],), float("inf"), dtype=t.float32, device=eng.device)
+    d_field = t.full((ctx["nvox"] + 4,), float("inf"), dtype=t.float32, device=eng.device)   # (+ padding: the searches read rows of three words)
     P = eng.ptr
     _abi.check(eng.lib.kh_edf_batch(P(d_task), 1, 2, P(ctx["d_lists"]), P(ctx["d_nbr"]), shape[0], shape[1], shape[2],
                                     float(anisotropy[0]), float(anisotropy[1]), float(anisotropy[2]), P(d_field),
                                     P(ctx["d_qstate"]), P(ctx["d_queues"]), eng.stream()))
-    out = d_field.cpu().numpy().reshape(shape, order="F").reshape(np.asarray(labels).shape, order="F")
+    out = d_field[:ctx["nvox"]].cpu().numpy().reshape(shape, order="F").reshape(np.asarray(labels).shape, order="F")
     if not return_max_location:
         return out
     done = d_task.cpu().numpy().view(_abi.LABEL_T)
@@ -226,8 +226,9 @@ class _Search:
         self.graph = voxel_graph is not None
         self.ctx = eng.single_object(np.isfinite(f), (1, 1, 1), voxel_graph=voxel_graph)
         t = eng.torch
-        self.d_field = t.from_numpy(np.ascontiguousarray(f.reshape(-1, order="F"))).to(eng.device)
-        self.d_dist = t.full((f.size,), float("inf"), dtype=t.float32, device=eng.device)
+        flat = np.concatenate([f.reshape(-1, order="F"), np.full(4, np.inf, dtype=np.float32)])     # (+ padding: rows of three words)
+        self.d_field = t.from_numpy(np.ascontiguousarray(flat)).to(eng.device)
+        self.d_dist = t.full((f.size + 4,), float("inf"), dtype=t.float32, device=eng.device)
 
     def run(self, mode, source, target=0):
         eng, ctx, t, P = self.eng, self.ctx, self.eng.torch, self.eng.ptr
