@@ -59,6 +59,7 @@ struct Ctl {
   uint32_t red_cnt[16];
   float T;
   uint32_t u0, u1, u2, u3;
+  uint32_t retry[2];     // sssp: a frontier voxel of this batch could not place an offer (parity of the batch)
   uint32_t pool_base;
   unsigned long long cyc3[3];
   Geometry g;  // the 26 offsets / edge lengths are indexed per lane: keep them in LDS, not in SGPRs
@@ -173,122 +174,202 @@ __device__ __forceinline__ void rows27_plain(const KH_AS_GLOBAL float* a, uint32
   for (int i = 0; i < 27; i++) w[i] = __uint_as_float(wu[i]);
 }
 
+// LDS scratch of a search (north_star: "frontier relaxation with LDS bucket queues and wave-ballot compaction"): KH_SSSP_LDS_BYTES
+// per thread of the workgroup, laid out as
+//   key[H], val[H]   the COMBINE TABLE of a batch of frontier voxels: open addressing on the voxel index, val = the smallest
+//                    fl(d[u] + w) any frontier voxel of the batch offers the voxel (LDS atomic min).  A batch relaxes into the
+//                    table, a barrier, then every occupied slot is flushed by ONE thread: it is the only writer of dist[v], of
+//                    v's membership byte and of v's list entries, so the searches issue NO global atomic (every global atomic
+//                    on gfx950 is a fabric round trip that drops its line from the L2: DESIGN.md r6-1).
+//   qa[NQ], qb[NQ]   the heads of the two near work lists (bucket "below T" being processed / being built); entries from NQ on
+//                    overflow to the label's lists in HBM at the same index.  The far bucket stays in HBM (it is split by a
+//                    streaming pass).
+// List slots are handed out per wave: a ballot of the lanes that append, ONE LDS atomic add by the first of them, a prefix
+// population count for the others.
+#define KH_SSSP_LDS_BYTES 48u   /* per thread: H = 4 slots of 8 bytes, NQ = 2 + 2 entries of 4 bytes */
+static constexpr uint32_t SSSP_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uintptr_t uni64(uintptr_t v) { return ((uintptr_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+typedef KH_AS_GLOBAL uint8_t gu8_t;
+__device__ __forceinline__ uint32_t gld8_l2(const gu8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gst8_l2(gu8_t* p, uint32_t v) { __hip_atomic_store(p, (uint8_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// slot of this lane among the lanes of its wave with p set (all lanes of the wave call this): base from one LDS atomic
+__device__ __forceinline__ uint32_t wave_slot(bool p, KH_AS_LDS uint32_t* counter, int lane) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+  if (m == 0ull) return 0u;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0u;
+  if (lane == leader) base = __hip_atomic_fetch_add(counter, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ bool sssp_offer(KH_AS_LDS uint32_t* key, KH_AS_LDS uint32_t* val, uint32_t hmask, int hshift, uint32_t v,
+                                           uint32_t nb) {
+  uint32_t s = (v * 0x9E3779B1u) >> hshift;
+#pragma unroll 1
+  for (int t = 0; t < 12; t++) {
+    uint32_t seen = SSSP_EMPTY;
+    __hip_atomic_compare_exchange_strong(key + s, &seen, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (seen == SSSP_EMPTY || seen == v) {
+      __hip_atomic_fetch_min(val + s, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return true;
+    }
+    s = (s + 1u) & hmask;
+  }
+  return false;       // the neighbourhood of the slot is full: the frontier voxel is relaxed again after the flush
+}
+
 // MODE 0: EDF (edge length by direction).  MODE 1: railroad (cost = pdrf of the entered voxel, rails
 // absorb, stops once everything at or below the nearest rail is final).  MODE 2: parental field
 // (trace.py:155, fix_branching=False): field costs, no rails, runs to completion.
 // On return distances below the final threshold are exact (ctl->best_rail set for MODE 1).
+// lds / lds_bytes: the workgroup's search scratch, >= KH_SSSP_LDS_BYTES * blockDim.x bytes, 4-byte aligned.
 template <int MODE>
 __device__ __attribute__((noinline)) void sssp(const Geometry& g_, const uint32_t* __restrict__ nbrmask_, const float* __restrict__ wfield_,
                      float* dist_, uint8_t* qstate_, uint32_t source, Queues q, Ctl* ctl_, float delta_floor,
-                     uint32_t preseeded_far = 0) {
+                     unsigned char* lds_, uint32_t lds_bytes, uint32_t preseeded_far = 0) {
   constexpr bool RAIL = MODE == 1;
   constexpr bool FIELD = MODE != 0;  // MODE 2: dijkstra3d.parental_field -- field weights, no rails, runs to completion
   const int tid = threadIdx.x;
   const int nthr = blockDim.x, nwav = nthr >> 6;
   const int lane = tid & 63, wave = tid >> 6;
-  const KH_AS_LDS Geometry* g = (const KH_AS_LDS Geometry*)&g_;      // the kernels keep their Geometry in LDS (Ctl::g)
-  KH_AS_LDS Ctl* ctl = (KH_AS_LDS Ctl*)ctl_;
-  const gu32_t* nbrmask = (const gu32_t*)nbrmask_;
-  const gf32_t* wfield = (const gf32_t*)wfield_;
-  gu32_t* dist = (gu32_t*)dist_;                                     // float bit patterns (non-negative: ordered like unsigned)
-  gu32_t* qstate = (gu32_t*)qstate_;                                 // 4-byte aligned (checked by the entry points)
-  gu32_t* cur = (gu32_t*)q.a;
-  gu32_t* next = (gu32_t*)q.b;
-  gu32_t* far = (gu32_t*)q.c;
-  gu32_t* touched = (gu32_t*)q.touched;
+  // The arguments of a function that is not a kernel arrive in VECTOR registers, uniform or not: eight 64-bit pointers and every
+  // address derived from them would live in VGPR pairs.  Read back through lane 0 they are scalars again.
+  const KH_AS_LDS Geometry* g = (const KH_AS_LDS Geometry*)(uintptr_t)uni32((uint32_t)(uintptr_t)(const KH_AS_LDS Geometry*)&g_);
+  KH_AS_LDS Ctl* ctl = (KH_AS_LDS Ctl*)(uintptr_t)uni32((uint32_t)(uintptr_t)(KH_AS_LDS Ctl*)ctl_);
+  const gu32_t* nbrmask = (const gu32_t*)uni64((uintptr_t)nbrmask_);
+  const gf32_t* wfield = (const gf32_t*)uni64((uintptr_t)wfield_);
+  gu32_t* dist = (gu32_t*)uni64((uintptr_t)dist_);                   // float bit patterns (non-negative: ordered like unsigned)
+  gu8_t* qs8 = (gu8_t*)uni64((uintptr_t)qstate_);                    // membership bytes: bit 0 near list being built, bit 1 far list
+  q.cap = uni32(q.cap);
+  gu32_t* cur = (gu32_t*)uni64((uintptr_t)q.a);
+  gu32_t* next = (gu32_t*)uni64((uintptr_t)q.b);
+  gu32_t* far = (gu32_t*)uni64((uintptr_t)q.c);
+  gu32_t* touched = (gu32_t*)uni64((uintptr_t)q.touched);
+  source = uni32(source);
+  lds_bytes = uni32(lds_bytes);
+  delta_floor = __uint_as_float(uni32(__float_as_uint(delta_floor)));
+  lds_ = (unsigned char*)(uintptr_t)uni32((uint32_t)(uintptr_t)(KH_AS_LDS unsigned char*)lds_);
+  uint32_t H = 1u;
+  while (H * 24u <= lds_bytes) H <<= 1;                              // the largest power of two with 12 H <= lds_bytes
+  const uint32_t NQ = H >> 1, hmask = H - 1u;
+  const int hshift = __clz((int)H) + 1;
+  KH_AS_LDS uint32_t* key = (KH_AS_LDS uint32_t*)(uintptr_t)lds_;
+  KH_AS_LDS uint32_t* val = key + H;
+  KH_AS_LDS uint32_t* curL = val + H;
+  KH_AS_LDS uint32_t* nextL = curL + NQ;
   float T = RAIL ? 1e-45f : delta_floor;
+  for (uint32_t s = tid; s < H; s += nthr) { key[s] = SSSP_EMPTY; val[s] = 0xFFFFFFFFu; }
   if (tid == 0) {
     ctl->n_cur = 1; ctl->n_next = 0; ctl->n_far = preseeded_far; ctl->n_far2 = 0;  // far list q.c may hold seeds
     ctl->n_touched = 0;
     ctl->best_rail = NONE64;
-    cur[0] = source;
+    ctl->retry[0] = ctl->retry[1] = 0u;
+    curL[0] = source;
     __hip_atomic_store(dist + source, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (RAIL) { touched[0] = source; ctl->n_touched = 1; }
   }
   __syncthreads();
+  const int gsx = g->sx, gsxy = g->sxy, gsy = g->sy, gsz = g->sz;
+  const uint32_t nvox = (uint32_t)gsxy * (uint32_t)gsz;
+  uint32_t par = 0u;
   for (;;) {
     // ---- near phase: label-correct everything below T
     for (;;) {
       const uint32_t n = ctl->n_cur;
       if (n == 0) break;
-      for (uint32_t i = tid; i < n; i += nthr) gflag_clear(qstate, cur[i], 1u);
-      __syncthreads();
-      // Round 6: ONE THREAD PER FRONTIER VOXEL.  Rounds 4-5 spread (voxel, direction) pairs over the lanes: 32 work items per voxel,
-      // each with its own loads of the voxel's mask and distance and a gather of the neighbour's -- a gather is paid per lane
-      // (csrc/sweep.h, round 6), and the pairs of one voxel sat in 32 lanes.  Now a thread reads its voxel's mask and distance and
-      // the 27 distances around it as nine rows of three consecutive words (global_load_dwordx3 sc1: past the vector cache,
-      // the words are changed by memory-side atomics) -- and with a weight field its 27 weights the same way -- in ONE round trip
-      // whose addresses depend on nothing but the voxel; the look-before-the-atomic is then arithmetic, and only the relaxations
-      // that lower a distance go out as atomics, thirteen at a time.  The wavefront of a label is a few hundred voxels: one pass.
-      const int gsx = g->sx, gsxy = g->sxy, gsy = g->sy, gsz = g->sz;
-      const uint32_t nvox = (uint32_t)gsxy * (uint32_t)gsz;
-      for (uint32_t i = tid; i < n; i += nthr) {
-        const uint32_t u = cur[i];
+      // ONE THREAD PER FRONTIER VOXEL, a batch of blockDim.x voxels at a time.  A thread reads its voxel's mask and the 27 distances
+      // around it as nine rows of three consecutive words (past the vector cache) -- with a weight field its 27 weights the same
+      // way -- in ONE round trip whose addresses depend on nothing but the voxel; every edge that lowers a distance is offered to
+      // the combine table; after the barrier the table is flushed (see above).
+      for (uint32_t base = 0; base < n; base += (uint32_t)nthr) {
+        const uint32_t i = base + (uint32_t)tid;
+        bool pending = i < n;
+        const uint32_t u = pending ? (i < NQ ? curL[i] : cur[i]) : source;
         const uint32_t zz = u / (uint32_t)gsxy, rr = u - zz * (uint32_t)gsxy, yy = rr / (uint32_t)gsx;
-        const uint32_t nm = nbrmask[u];
-        const uint32_t dub = gld_l2(dist + u);
-        float wr[27];
-        if (FIELD) rows27_plain(wfield, nvox, gsx, gsxy, gsy, gsz, u, (int)yy, (int)zz, wr);
-        uint32_t dr[27];
-        rows27_sc1(dist, nvox, gsx, gsxy, gsy, gsz, u, (int)yy, (int)zz, dr);
-        const float du = __uint_as_float(dub);
+        if (pending) gst8_l2(qs8 + u, gld8_l2(qs8 + u) & ~1u);       // out of the near list (the only thread that holds u)
+        for (;;) {
+          if (pending) {
+            const uint32_t nm = nbrmask[u];
+            float wr[27];
+            if (FIELD) rows27_plain(wfield, nvox, gsx, gsxy, gsy, gsz, u, (int)yy, (int)zz, wr);
+            uint32_t dr[27];
+            rows27_sc1(dist, nvox, gsx, gsxy, gsy, gsz, u, (int)yy, (int)zz, dr);
+            const float du = __uint_as_float(dr[13]);
+            bool failed = false;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          uint32_t oldv[13], nbv[13];
-          uint32_t act = 0;
-#pragma unroll
-          for (int j = 0; j < 13; j++) {
-            const int k = 13 * h + j;
-            int dx, dy, dz;
-            dir_delta(k, dx, dy, dz);
-            const int idx = (dx + 1) + 3 * ((dy + 1) + 3 * (dz + 1));
-            const float wn = FIELD ? wr[idx] : g->w[k];
-            nbv[j] = __float_as_uint(du + wn);
-            oldv[j] = dr[idx];
-            // a look before the atomic: distances only go down, so an edge that cannot lower dist[v] now never will
-            if (((nm >> k) & 1u) && nbv[j] < oldv[j]) {
-              act |= 1u << j;
-              oldv[j] = __hip_atomic_fetch_min(dist + (u + (uint32_t)(dx + gsx * dy + gsxy * dz)), nbv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 26; k++) {
+              int dx, dy, dz;
+              dir_delta(k, dx, dy, dz);
+              const int idx = (dx + 1) + 3 * ((dy + 1) + 3 * (dz + 1));
+              const float wn = FIELD ? wr[idx] : g->w[k];
+              const uint32_t nb = __float_as_uint(du + wn);
+              // distances only go down, so an edge that cannot lower dist[v] now never will
+              if (((nm >> k) & 1u) && nb < dr[idx])
+                failed |= !sssp_offer(key, val, hmask, hshift, u + (uint32_t)(dx + gsx * dy + gsxy * dz), nb);
+            }
+            pending = failed;
+            if (failed) ctl->retry[par] = 1u;
+          }
+          __syncthreads();
+          // ---- flush: one thread per occupied slot
+          for (uint32_t s = (uint32_t)tid; s < H; s += (uint32_t)nthr) {
+            const uint32_t v = key[s];
+            const bool occ = v != SSSP_EMPTY;
+            uint32_t nd = 0u, old = 0u, q8 = 0u;
+            float wv = 1.0f;
+            if (occ) {
+              nd = val[s];
+              key[s] = SSSP_EMPTY;
+              val[s] = 0xFFFFFFFFu;
+              if (RAIL) { old = gld_l2(dist + v); wv = wfield[v]; }
+              q8 = gld8_l2(qs8 + v);
+              __hip_atomic_store(dist + v, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float ndf = __uint_as_float(nd);
+            const bool rail = RAIL && occ && wv == 0.0f;            // a rail: absorbing
+            if (rail) __hip_atomic_fetch_min(&ctl->best_rail, pack(ndf, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool t_touch = RAIL && occ && old == INF_BITS;
+            const bool t_next = occ && !rail && ndf < T && !(q8 & 1u);
+            const bool t_far = occ && !rail && !(ndf < T) && !(q8 & 2u);
+            if (t_next | t_far) gst8_l2(qs8 + v, q8 | (t_next ? 1u : 2u));
+            if (RAIL) {
+              const uint32_t p = wave_slot(t_touch, &ctl->n_touched, lane);
+              if (t_touch) {
+                if (p < q.cap) touched[p] = v;
+                else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+            {
+              const uint32_t p = wave_slot(t_next, &ctl->n_next, lane);
+              if (t_next) {
+                if (p < NQ) nextL[p] = v;
+                else if (p < q.cap) next[p] = v;
+                else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+            {
+              const uint32_t p = wave_slot(t_far, &ctl->n_far, lane);
+              if (t_far) {
+                if (p < q.cap) far[p] = v;
+                else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
             }
           }
-#pragma unroll
-          for (int j = 0; j < 13; j++) {
-            if (!((act >> j) & 1u) || !(nbv[j] < oldv[j])) continue;
-            const int k = 13 * h + j;
-            int dx, dy, dz;
-            dir_delta(k, dx, dy, dz);
-            const int idx = (dx + 1) + 3 * ((dy + 1) + 3 * (dz + 1));
-            const uint32_t v = u + (uint32_t)(dx + gsx * dy + gsxy * dz), old = oldv[j];
-            const float nd = __uint_as_float(nbv[j]), wn = FIELD ? wr[idx] : 1.0f;
-            if (RAIL && old == INF_BITS) {
-              const uint32_t t = __hip_atomic_fetch_add(&ctl->n_touched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (t < q.cap) touched[t] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (RAIL && wn == 0.0f) {  // a rail: absorbing
-              __hip_atomic_fetch_min(&ctl->best_rail, pack(nd, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              continue;
-            }
-            if (nd < T) {
-              if (!(gflag_or(qstate, v, 1u) & 1u)) {
-                const uint32_t p = __hip_atomic_fetch_add(&ctl->n_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (p < q.cap) next[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              }
-            } else {
-              if (!(gflag_or(qstate, v, 2u) & 2u)) {
-                const uint32_t p = __hip_atomic_fetch_add(&ctl->n_far, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (p < q.cap) far[p] = v; else __hip_atomic_fetch_or(&ctl->status, (uint32_t)KH_ST_QUEUE_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              }
-            }
-          }
+          const bool again = ctl->retry[par] != 0u;                  // (stable since the barrier above)
+          if (tid == 0) ctl->retry[par ^ 1u] = 0u;                   // (nobody reads or sets the other word before the next barrier)
+          par ^= 1u;
+          __syncthreads();
+          if (!again) break;
         }
       }
-      __syncthreads();
       if (tid == 0) {
         ctl->n_cur = ctl->n_next < q.cap ? ctl->n_next : q.cap;
         ctl->n_next = 0;
         if (ctl->n_far > q.cap) ctl->n_far = q.cap;
       }
-      gu32_t* t = cur; cur = next; next = t;
+      { gu32_t* t = cur; cur = next; next = t; }
+      { KH_AS_LDS uint32_t* t = curL; curL = nextL; nextL = t; }
       __syncthreads();
     }
     // ---- every voxel with d < T is final now
@@ -329,21 +410,22 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g_, const uint32_
     if (Tn < T) Tn = T;
     if (Tn > tcap) Tn = tcap;
     T = Tn;
-    // pass 2: split far -> cur (d < T) + compacted far (into the free `next` buffer)
-    for (uint32_t i = tid; i < nfar; i += nthr) {
-      const uint32_t v = far[i];
-      gflag_clear(qstate, v, 2u);
+    // pass 2: split far -> cur (d < T) + compacted far (into the free `next` buffer); every entry has one thread, which is the
+    // only writer of the voxel's membership byte
+    for (uint32_t base = 0; base < nfar; base += (uint32_t)nthr) {
+      const uint32_t i = base + (uint32_t)tid;
+      const bool have = i < nfar;
+      const uint32_t v = have ? far[i] : source;
       const float d = __uint_as_float(gld_l2(dist + v));
-      if (d < T) {
-        if (!(gflag_or(qstate, v, 1u) & 1u)) {
-          const uint32_t p = __hip_atomic_fetch_add(&ctl->n_cur, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          cur[p] = v;  // p < nfar <= cap
-        }
-      } else {
-        gflag_or(qstate, v, 2u);
-        const uint32_t p = __hip_atomic_fetch_add(&ctl->n_far2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        next[p] = v;
-      }
+      const uint32_t q8 = gld8_l2(qs8 + v) & ~2u;
+      const bool near = have && d < T;
+      const bool t_cur = near && !(q8 & 1u);
+      const bool t_far = have && !near;
+      if (have) gst8_l2(qs8 + v, q8 | (t_cur ? 1u : 0u) | (t_far ? 2u : 0u));
+      const uint32_t pc = wave_slot(t_cur, &ctl->n_cur, lane);
+      if (t_cur) { if (pc < NQ) curL[pc] = v; else cur[pc] = v; }    // pc < nfar <= cap
+      const uint32_t pf = wave_slot(t_far, &ctl->n_far2, lane);
+      if (t_far) next[pf] = v;
     }
     __syncthreads();
     if (tid == 0) { ctl->n_far = ctl->n_far2; ctl->n_far2 = 0; }
@@ -359,7 +441,7 @@ __device__ __attribute__((noinline)) void sssp(const Geometry& g_, const uint32_
 // linear index); mode 1 (find_root): task.root = that voxel.  Out of line: the batch kernel and the path kernel share it.
 __device__ __attribute__((noinline)) void edf_label(Ctl* ctl_, kh_label_t* task, int mode, const uint32_t* __restrict__ list, uint32_t nf,
                                                     const uint32_t* __restrict__ nbrmask, float* field, uint8_t* qstate, Queues q,
-                                                    float delta_floor, uint32_t source) {
+                                                    float delta_floor, uint32_t source, unsigned char* lds, uint32_t lds_bytes) {
   Ctl& ctl = *ctl_;
   const Geometry& g = ctl.g;
   const int tid = threadIdx.x;
@@ -396,7 +478,7 @@ __device__ __attribute__((noinline)) void edf_label(Ctl* ctl_, kh_label_t* task,
     __syncthreads();
     seeded = ctl.u0;
   }
-  sssp<0>(ctl.g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor, seeded);
+  sssp<0>(ctl.g, nbrmask, nullptr, field, qstate, source, q, &ctl, delta_floor, lds, lds_bytes, seeded);
   // farthest voxel: max finite distance, ties -> smallest linear index
   unsigned long long best = 0;
   for (uint32_t i = tid; i < nf; i += nthr) {
@@ -428,6 +510,7 @@ __global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int 
                                                         const uint32_t* __restrict__ nbrmask, Geometry g, float* field,
                                                         uint8_t* qstate, uint32_t* queues, float delta_floor) {
   __shared__ Ctl ctl;
+  extern __shared__ __attribute__((aligned(16))) unsigned char search_lds[];     // KH_SSSP_LDS_BYTES per thread
   kh_label_t* task = &tasks[blockIdx.x];
   const int tid = threadIdx.x;
   if (mode == 1 && task->root != 0xFFFFFFFFu) return;
@@ -440,7 +523,8 @@ __global__ __launch_bounds__(1024) void edf_batch_kernel(kh_label_t* tasks, int 
   q.b = q.a + q.cap;
   q.c = q.b + q.cap;
   q.touched = q.c + q.cap;
-  edf_label(&ctl, task, mode, lists + task->list_offset, task->count, nbrmask, field, qstate, q, delta_floor, source);
+  edf_label(&ctl, task, mode, lists + task->list_offset, task->count, nbrmask, field, qstate, q, delta_floor, source, search_lds,
+            KH_SSSP_LDS_BYTES * blockDim.x);
   if (tid == 0) task->status |= ctl.status;
 }
 
@@ -1075,7 +1159,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
                                                           uint32_t* path_vertices,
                                                           uint32_t* path_lengths, int fix_branching, SweepGlobal sg,
                                                           uint32_t* journal_buf, float* rail_save, uint32_t ghost_mode,
-                                                          const uint8_t* __restrict__ corner_gate) {
+                                                          const uint8_t* __restrict__ corner_gate, uint32_t lds_bytes) {
   __shared__ Ctl ctl;
   __shared__ Sweep sw;
   __shared__ SweepShared swsh;
@@ -1144,11 +1228,11 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
     // the DAF for the target finder and compute_pdrf (:315-356, the repeated-squaring branch), every operation rounded to f32.
     const float delta_floor = 2.0f * fminf(g.wx, fminf(g.wy, g.wz));
     if (root == 0xFFFFFFFFu) {
-      edf_label(&ctl, task, 1, list, nf, nbrmask, dist, qstate, q, delta_floor, task->source);
+      edf_label(&ctl, task, 1, list, nf, nbrmask, dist, qstate, q, delta_floor, task->source, heap_top, lds_bytes);
       root = 0xFFFFFFFFu - (uint32_t)ctl.red64[0];         // (every thread: the record was written by thread 0 only)
       __syncthreads();
     }
-    edf_label(&ctl, task, 2, list, nf, nbrmask, dist, qstate, q, delta_floor, root);
+    edf_label(&ctl, task, 2, list, nf, nbrmask, dist, qstate, q, delta_floor, root, heap_top, lds_bytes);
     const float max_daf = __uint_as_float((uint32_t)(ctl.red64[0] >> 32));
     daf_loc = 0xFFFFFFFFu - (uint32_t)ctl.red64[0];
     const float M = task->M, pscale = task->pdrf_scale;
@@ -1191,7 +1275,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
     if (tid == 0) pdrf[root] = 0.0f;                    // trace.py:220 (initial rail)
   } else {
     // trace.py:155: one weighted Dijkstra from the root; every path is then a predecessor walk
-    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f);
+    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, root, q, &ctl, 0.0f, heap_top, lds_bytes);
   }
   __syncthreads();
   bool redo = false;      // this iteration redoes the invalidation of path `npaths` by the heap emulation (after a roll-back)
@@ -1255,7 +1339,7 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void trace_paths_kernel
         if (tid == 0) out[0] = target;
         plen = 1;
       } else {
-        sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f);
+        sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, target, q, &ctl, 0.0f, heap_top, lds_bytes);
         const unsigned long long br = ctl.best_rail;
         if (tid == 0) { ctl.u0 = 0; ctl.u2 += ctl.n_touched; }
         __syncthreads();
@@ -1484,11 +1568,12 @@ __global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void invalidate_ball_ke
 //           path written rail end first (trace.py:240-242); dist is +inf again on exit.
 //   mode 1  the search of dijkstra3d.parental_field(field, source) (trace.py:155): leaves the distance field in `dist`.
 //   mode 2  dijkstra3d.path_from_parents (trace.py:244) on that distance field: path src(root) -> dst(target).
-__global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int mode, const uint32_t* __restrict__ lists,
+__global__ __launch_bounds__(256, KH_TRACE_WAVES_PER_EU) void path_search_kernel(kh_label_t* task, int mode, const uint32_t* __restrict__ lists,
                                                           const uint32_t* __restrict__ nbrmask, Geometry g, const float* pdrf,
                                                           float* dist, uint8_t* qstate, uint32_t* queues, uint32_t src, uint32_t dst,
                                                           uint32_t* out, uint32_t cap, uint32_t* out_n, int graph) {
   __shared__ Ctl ctl;
+  __shared__ __attribute__((aligned(16))) unsigned char search_lds[KH_SSSP_LDS_BYTES * 256];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   Queues q;
   q.cap = task->q_capacity;
@@ -1499,7 +1584,7 @@ __global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int 
   if (tid == 0) { ctl.status = 0; ctl.u0 = 0; ctl.g = g; }
   __syncthreads();
   if (mode == 1) {
-    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f);
+    sssp<2>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f, search_lds, (uint32_t)sizeof(search_lds));
   } else if (mode == 2) {
     if (wave == 0) {
       const uint32_t n = backtrack<false>(ctl.g, nbrmask, pdrf, dist, dst, src, out, cap, q.a, q.b, q.cap, qstate, &ctl.status, graph != 0);
@@ -1509,7 +1594,7 @@ __global__ __launch_bounds__(256) void path_search_kernel(kh_label_t* task, int 
   } else if (pdrf[src] == 0.0f) {
     if (tid == 0) { out[0] = src; ctl.u0 = 1; }
   } else {
-    sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f);
+    sssp<1>(ctl.g, nbrmask, pdrf, dist, qstate, src, q, &ctl, 0.0f, search_lds, (uint32_t)sizeof(search_lds));
     const unsigned long long br = ctl.best_rail;
     if (br == NONE64) {
       if (tid == 0) atomicOr(&ctl.status, KH_ST_NO_RAIL);
@@ -1672,7 +1757,7 @@ extern "C" int kh_edf_batch(kh_label_t* tasks, int ntasks, int mode, const uint3
   // 512 threads per label: measured 0.176 / 0.135 / 0.131 s for the two runs at c3 with 256 / 512 / 1024 threads
   // (one volume alone; with volumes in flight the lanes ask for fewer: a workgroup needs all its waves' slots on one CU at
   // once, and next to thousands of one-wave path workgroups eight free slots rarely come together)
-  hipLaunchKernelGGL(edf_batch_kernel, dim3(ntasks), dim3(nthreads), 0, (hipStream_t)stream, tasks, mode, lists, nbrmask, g, field,
+  hipLaunchKernelGGL(edf_batch_kernel, dim3(ntasks), dim3(nthreads), KH_SSSP_LDS_BYTES * nthreads, (hipStream_t)stream, tasks, mode, lists, nbrmask, g, field,
                      qstate, queues, delta_floor);
   KH_LAUNCH_CHECK();
   return KH_OK;
@@ -1722,6 +1807,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
   size_t lds = (size_t)(Heap<TOPL>::TOP + 3) * sizeof(hnode_t);
   const size_t swl = sweep_lds_bytes(max_nlev);
   if (sg.on && swl > lds) lds = swl;
+  if ((size_t)KH_SSSP_LDS_BYTES * nthreads > lds) lds = (size_t)KH_SSSP_LDS_BYTES * nthreads;     // the searches' scratch (same bytes)
   {
     // More than 48 KiB of dynamic LDS has to be allowed per kernel.  The attribute belongs to the function, not to the
     // launch, and several host threads launch at once (kimimaro_amd/lanes.py): always the same value -- the largest a
@@ -1732,7 +1818,7 @@ static int launch_trace(int count, hipStream_t st, kh_label_t* tasks, const uint
   }
   hipLaunchKernelGGL((trace_paths_kernel<PROF, TOPL>), dim3(count), dim3(nthreads), lds, st, tasks, lists, list_daf, nbrmask,
                      g, dbf, pdrf, dist, alive, qstate, manual_targets, scale, constant, queues, heap_nodes, path_vertices,
-                     path_lengths, fix_branching, sg, journal, rail_save, ghost_mode, corner_gate);
+                     path_lengths, fix_branching, sg, journal, rail_save, ghost_mode, corner_gate, (uint32_t)lds);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
