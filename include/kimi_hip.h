@@ -373,6 +373,23 @@ int kh_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t sy, int64_
              uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents,
              uint16_t* out16, void* stream);
 
+/* ---- skeletonize(voxel_graph=) (kimimaro/intake.py:66,162,174-183; utility.py:73-75).  PARITY UNPINNED: cc3d and edt are
+ * third-party packages whose sources are absent from the reference tree.
+ * kh_ccl26_graph replaces cc3d.color_connectivity_graph(voxel_graph, connectivity=26) followed by `cc_labels *= all_labels > 0`:
+ * two foreground voxels are joined iff they are 26-neighbours and the graph word (cc3d's bit layout, u32 per voxel) of the later
+ * one in the raster allows the step to the earlier one.  Arguments and numbering as kh_ccl26.
+ * kh_edt_graph_cells / kh_edt_graph_sample are the two ends of edt.edt(labels, voxel_graph=): cells (u8 [2sx, 2sy, 2sz], F order)
+ * receives the doubled image -- voxel (x, y, z) at cell (2x, 2y, 2z); the cell towards +x / +y / +z is foreground iff the voxel is
+ * and bit 0 / 2 / 4 of its graph word is set (without black_border: also behind the last voxel of an axis); the other cells of the
+ * voxel's 2 x 2 x 2 block follow the voxel -- on which the caller runs kh_edt(label_bytes = 1) with HALF the voxel pitch;
+ * kh_edt_graph_sample reads that transform back at the voxel cells.  8 * nvox < 2^32.                                          */
+int kh_ccl26_graph(const void* labels, int label_bytes, const uint32_t* graph, int64_t sx, int64_t sy, int64_t sz,
+                   uint32_t* parent, uint32_t* chunk_counts, uint32_t* out, uint32_t* representative, uint32_t* ncomponents,
+                   uint16_t* out16, void* stream);
+int kh_edt_graph_cells(const void* labels, int label_bytes, const uint32_t* graph, int64_t sx, int64_t sy, int64_t sz,
+                       int black_border, uint8_t* cells, void* stream);
+int kh_edt_graph_sample(const float* fine, int64_t sx, int64_t sy, int64_t sz, float* out, void* stream);
+
 /* ---- f3: binary hole filling, replaces fill_voids.fill(img, in_place=True, return_fill_count=True) as
  * called at kimimaro/trace.py:109 (third-party, source absent): a background voxel (mask == 0) stays
  * background iff a 6-connected background path joins it to a face of the array.  mask/out: u8 [nvox]

@@ -57,6 +57,17 @@ __host__ __device__ constexpr inline void dir_delta(int i, int& dx, int& dy, int
   dz = T[i][2];
 }
 
+// voxel_connectivity_graph bit of direction i (directions in the order of dijkstra_invalidation.hpp:60-124, bits as the reference
+// reads them at dijkstra_invalidation.hpp:152-190 -- cc3d's layout): -x 1, +x 0, -y 3, +y 2, -z 5, +z 4, xy diagonals 9 7 8 6,
+// yz diagonals 17 13 16 12, xz diagonals 15 11 14 10, corners 25 24 23 21 22 20 19 18.
+__host__ __device__ inline uint32_t graph_to_directions(uint32_t gw) {
+  constexpr int BIT[26] = {1, 0, 3, 2, 5, 4, 9, 7, 8, 6, 17, 13, 16, 12, 15, 11, 14, 10, 25, 24, 23, 21, 22, 20, 19, 18};
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 26; i++) m |= ((gw >> BIT[i]) & 1u) << i;
+  return m;
+}
+
 struct Geometry {
   int32_t sx, sy, sz;
   int32_t sxy;          // sx*sy (volumes are < 2^32 voxels, slices < 2^31)

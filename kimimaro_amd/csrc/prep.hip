@@ -336,16 +336,6 @@ extern "C" int kh_neighbor_mask(const void* labels, int label_bytes, int64_t sx,
 }
 
 namespace kh {
-// voxel_connectivity_graph bit of direction i (directions in the order of dijkstra_invalidation.hpp:60-124, bits as the reference
-// reads them at dijkstra_invalidation.hpp:152-190 -- cc3d's layout): -x 1, +x 0, -y 3, +y 2, -z 5, +z 4, xy diagonals 9 7 8 6,
-// yz diagonals 17 13 16 12, xz diagonals 15 11 14 10, corners 25 24 23 21 22 20 19 18.
-__device__ __forceinline__ uint32_t graph_to_directions(uint32_t gw) {
-  constexpr int BIT[26] = {1, 0, 3, 2, 5, 4, 9, 7, 8, 6, 17, 13, 16, 12, 15, 11, 14, 10, 25, 24, 23, 21, 22, 20, 19, 18};
-  uint32_t m = 0;
-#pragma unroll
-  for (int i = 0; i < 26; i++) m |= ((gw >> BIT[i]) & 1u) << i;
-  return m;
-}
 __global__ __launch_bounds__(256) void apply_voxel_graph_kernel(uint32_t* nbrmask, const uint32_t* __restrict__ graph, int64_t nvox,
                                                                 uint8_t* corner_gate) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;

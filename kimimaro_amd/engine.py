@@ -317,7 +317,7 @@ class Engine:
         self.torch.cuda.current_stream(self.device).synchronize()
 
     # -- f1: connected components on the device ---------------------------------
-    def ccl(self, labels):
+    def ccl(self, labels, d_graph=None):
         """26-connected multi-label CCL (kimimaro/utility.py:58-83).  labels: host ndarray (F order, integer).
         Returns (d_cc u32 device tensor, N, representative[N+1] host array of smallest linear indices)."""
         t = self.torch
@@ -327,10 +327,11 @@ class Engine:
         if lab.dtype.kind not in "ui":
             lab = lab.astype(np.uint64)
         lab = np.asfortranarray(lab)
-        return self.ccl_device(self.to_device(lab), lab.dtype.itemsize, lab.shape)
+        return self.ccl_device(self.to_device(lab), lab.dtype.itemsize, lab.shape, d_graph)
 
-    def ccl_device(self, d_lab, itemsize, shape):
-        """kh_ccl26 on a label volume that is already resident in HBM."""
+    def ccl_device(self, d_lab, itemsize, shape, d_graph=None):
+        """kh_ccl26 on a label volume that is already resident in HBM; d_graph (u32 per voxel, cc3d's layout): kh_ccl26_graph,
+        the components of the voxel connectivity graph (kimimaro/utility.py:73-75)."""
         t = self.torch
         n = int(shape[0]) * int(shape[1]) * int(shape[2])
         d_parent = self.empty(n, t.int32)
@@ -339,9 +340,14 @@ class Engine:
         d_rep = self.empty(n + 1, t.int32)
         d_total = self.empty(1, t.int32)
         d_cc16 = self.empty(n, t.int16)
-        _abi.check(self.lib.kh_ccl26(self.ptr(d_lab), itemsize, shape[0], shape[1], shape[2], self.ptr(d_parent),
-                                     self.ptr(d_counts), self.ptr(d_cc), self.ptr(d_rep), self.ptr(d_total), self.ptr(d_cc16),
-                                     self.stream()))
+        if d_graph is not None:
+            _abi.check(self.lib.kh_ccl26_graph(self.ptr(d_lab), itemsize, self.ptr(d_graph), shape[0], shape[1], shape[2],
+                                               self.ptr(d_parent), self.ptr(d_counts), self.ptr(d_cc), self.ptr(d_rep), self.ptr(d_total),
+                                               self.ptr(d_cc16), self.stream()))
+        else:
+            _abi.check(self.lib.kh_ccl26(self.ptr(d_lab), itemsize, shape[0], shape[1], shape[2], self.ptr(d_parent),
+                                         self.ptr(d_counts), self.ptr(d_cc), self.ptr(d_rep), self.ptr(d_total), self.ptr(d_cc16),
+                                         self.stream()))
         ncomp = int(d_total.cpu().numpy().view(np.uint32)[0])
         # fewer than 65536 components: the u16 copy of the ids serves every later sweep (narrow())
         # (keyed by the tensor OBJECT, which the record keeps alive: the caching allocator hands a freed volume's address
@@ -398,6 +404,21 @@ class Engine:
         _abi.check(self.lib.kh_edt_nd(self.ptr(d_labels), label_bytes, int(ndim), sx, sy, sz, float(anisotropy[0]),
                                       float(anisotropy[1]), float(anisotropy[2]), int(bool(black_border)),
                                       self.ptr(workspace), self.ptr(out), self.stream()))
+        return out
+
+    def edt_graph(self, d_labels, label_bytes, d_graph, shape, anisotropy, black_border):
+        """edt.edt(labels, voxel_graph=) (kimimaro/intake.py:174-183; PARITY UNPINNED, include/kimi_hip.h): the doubled image of the
+        graph's walls, a binary transform with half the pitch, sampled at the voxels."""
+        sx, sy, sz = (int(v) for v in shape)
+        n = sx * sy * sz
+        t = self.torch
+        cells = self.empty(8 * n, t.uint8)
+        _abi.check(self.lib.kh_edt_graph_cells(self.ptr(d_labels), label_bytes, self.ptr(d_graph), sx, sy, sz, int(bool(black_border)),
+                                               self.ptr(cells), self.stream()))
+        half = [np.float32(a) / np.float32(2) for a in anisotropy]
+        fine = self.edt(cells, 1, (2 * sx, 2 * sy, 2 * sz), half, black_border)
+        out = self.empty(n, t.float32)
+        _abi.check(self.lib.kh_edt_graph_sample(self.ptr(fine), sx, sy, sz, self.ptr(out), self.stream()))
         return out
 
     def label_stats(self, d_labels, label_bytes, d_dbf, shape, nlabels):

@@ -91,9 +91,9 @@ def compute_cc_labels(all_labels):
     return cc, int(n), remap
 
 
-def compute_cc_labels_device(eng, all_labels):
-    """kimimaro/utility.py:58-83 on the MI355X (kh_ccl26): (device cc volume, N, {cc id: original id})."""
-    d_cc, n, rep = eng.ccl(all_labels)
+def compute_cc_labels_device(eng, all_labels, d_graph=None):
+    """kimimaro/utility.py:58-83 on the MI355X (kh_ccl26; with a voxel graph kh_ccl26_graph): (device cc volume, N, {cc id: original id})."""
+    d_cc, n, rep = eng.ccl(all_labels, d_graph)
     orig = all_labels.reshape(-1, order="F")[rep[1:].astype(np.int64)] if n else []
     remap = {i + 1: orig[i].item() for i in range(n)}  # skeletontricks.get_mapping :490-525
     return d_cc, n, remap
@@ -156,13 +156,6 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     one process drives one GPU; multi-GPU runs shard the connected components round robin over the
     ranks of torch.distributed (see kimimaro_amd.distributed).
     """
-    if voxel_graph is not None:
-        # The searches and the invalidation take the graph (kimimaro_amd.trace.trace(voxel_graph=), the function-level mirrors of
-        # kimimaro_amd.ops; kh_apply_voxel_graph).  What the whole-volume call still lacks is edt.edt(voxel_graph=) -- the walls of
-        # the transform -- and cc3d's graph-aware components (kimimaro/intake.py:178-183, utility.py:73-75): both packages are
-        # absent from the reference tree, their wall semantics cannot be pinned here (DESIGN.md section 7).
-        raise NotImplementedError("skeletonize(voxel_graph=): edt.edt(voxel_graph=) / cc3d's graph-aware components are not restated; "
-                                  "kimimaro_amd.trace.trace(voxel_graph=) and the kimimaro_amd.ops searches do take a graph")
     eng = _engine or Engine()  # raises HipUnavailableError without a GPU: no CPU fallback
     anisotropy = np.array(anisotropy, dtype=np.float32)
 
@@ -174,7 +167,21 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     if minlabel == 0 and maxlabel == 0:
         return {}
 
-    d_cc, nlabels, remapping = compute_cc_labels_device(eng, all_labels)  # row f1 on the GPU
+    d_graph = None
+    if voxel_graph is not None:
+        # kimimaro/intake.py:162,174-183,467: the graph decides the components (cc3d.color_connectivity_graph), puts walls into the
+        # transform (edt.edt(voxel_graph=)) and goes to every search and to the invalidation of every label (trace(voxel_graph=)).
+        # cc3d and edt are absent from the reference tree: kh_ccl26_graph / kh_edt_graph_* restate their published behaviour,
+        # PARITY UNPINNED (include/kimi_hip.h).
+        if fix_avocados:
+            raise NotImplementedError("skeletonize(voxel_graph=, fix_avocados=True): the avocado pass re-labels components, which a "
+                                      "graph of the ORIGINAL voxels does not describe")
+        vg = np.asarray(voxel_graph)
+        vg = vg.reshape((vg.shape + (1, 1, 1))[:3], order="F") if vg.ndim < 3 else vg
+        if tuple(vg.shape) != tuple(all_labels.shape):
+            raise ValueError("voxel_graph must have the shape of the labels")
+        d_graph = eng.to_device(np.asfortranarray(vg.astype(np.uint32)))
+    d_cc, nlabels, remapping = compute_cc_labels_device(eng, all_labels, d_graph)  # row f1 on the GPU
     if fill_holes:
         fill_all_holes_device(eng, d_cc, all_labels.shape, nlabels)              # intake.py:168-169
     avocado = None
@@ -191,7 +198,7 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
 
     return skeletonize_cc(eng, cc, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                           fix_branching, fix_borders, before, after, black_border=(minlabel == maxlabel),
-                          timings=_timings, d_dbf=avocado)
+                          timings=_timings, d_dbf=avocado, d_graph=d_graph)
 
 
 def _avocado_fruit_from_lines(xl, yl, zl, cx, cy, cz, background=0):
@@ -358,17 +365,17 @@ def shard_components(cc_segids, counts, rank, world):
 
 def skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
                    fix_branching, fix_borders, before, after, black_border, timings=None,
-                   rank=0, world=1, d_cc=None, d_dbf=None):
+                   rank=0, world=1, d_cc=None, d_dbf=None, d_graph=None):
     """Everything after the connected components (intake.py:174-221 + skeletonize_subset :434-517)."""
     try:
         return _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold, fix_branching,
-                               fix_borders, before, after, black_border, timings, rank, world, d_cc, d_dbf)
+                               fix_borders, before, after, black_border, timings, rank, world, d_cc, d_dbf, d_graph)
     finally:
         eng._narrow = None      # the u16 copy of this volume's ids (2 B / voxel of HBM) is not kept alive past the call
 
 
 def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotropy, dust_threshold,
-                    fix_branching, fix_borders, before, after, black_border, timings, rank, world, d_cc, d_dbf=None):
+                    fix_branching, fix_borders, before, after, black_border, timings, rank, world, d_cc, d_dbf=None, d_graph=None):
     import time as _time
 
     def _mark(name):
@@ -387,6 +394,8 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
         d_cc = eng.to_device(cc_labels.host())
         cc_labels.d = d_cc
     d_lab, label_bytes = eng.narrow(d_cc)          # u16 ids when there are < 65536 components (utility.py:79 refit)
+    if d_dbf is None and d_graph is not None:
+        d_dbf = eng.edt_graph(d_lab, label_bytes, d_graph, shape, anisotropy, black_border)  # intake.py:174-185 with voxel_graph
     if d_dbf is None:         # (fix_avocados hands over the transform of the components it left behind)
         d_dbf = eng.edt(d_lab, label_bytes, shape, anisotropy, black_border)  # intake.py:174-185
     counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_lab, label_bytes, d_dbf, shape, nlabels)
@@ -442,16 +451,17 @@ def _skeletonize_cc(eng, cc_labels, nlabels, remapping, teasar_params, anisotrop
     eng.run_labels(d_lab, label_bytes, d_dbf, shape, anisotropy, nlabels, sel, counts[sel] if len(sel) else [],
                          dbf_max[sel] if len(sel) else [], first_index[sel] if len(sel) else [],
                          xmin[sel] if len(sel) else [], xmax[sel] if len(sel) else [], roots, tb, ta, params,
-                         fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings, consume=asm.add)
+                         fix_branching=fix_branching, max_paths=params.get("max_paths"), timings=timings, consume=asm.add,
+                         voxel_graph=d_graph)
     out = asm.finish()
     _mark("assemble")
     if soma_jobs:
-        _trace_soma_labels(eng, soma_jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out)
+        _trace_soma_labels(eng, soma_jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out, d_graph)
         _mark("soma_labels")
     return out
 
 
-def _trace_soma_labels(eng, jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out):
+def _trace_soma_labels(eng, jobs, d_cc, d_dbf, shape, anisotropy, remapping, params, fix_branching, bbox, out, d_graph=None):
     """Labels that enter the soma branch of kimimaro/trace.py:108-134 (internal voids to fill, or DBF max above
     soma_acceptance_threshold) leave the shared-volume batch -- filling voids changes which voxels belong to
     the label -- and are traced on their bounding-box crop, exactly like intake.py:450-517.  The reference gives every
@@ -474,7 +484,8 @@ def _trace_soma_labels(eng, jobs, d_cc, d_dbf, shape, anisotropy, remapping, par
         tr = lambda ls: [tuple(int(v) for v in (np.array(unloc(l)) - minpt)) for l in ls]
         skel = trace_one(labels, dbf, anisotropy=an, fix_branching=fix_branching, manual_targets_before=tr(mtb),
                          manual_targets_after=tr(mta), root=(None if root == NONE32 else tr([root])[0]),
-                         max_paths=params.get("max_paths"), _engine=e, **kw)
+                         max_paths=params.get("max_paths"), _engine=e,
+                         voxel_graph=(None if d_graph is None else e.crop(d_graph, shape, lo, hi)), **kw)    # intake.py:467
         if not skel.empty():
             skel.vertices += minpt.astype(skel.vertices.dtype)
         return skel

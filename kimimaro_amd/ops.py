@@ -21,10 +21,6 @@ def engine():
 
 def edt(labels, anisotropy=(1, 1, 1), black_border=False, parallel=1, voxel_graph=None):
     """edt.edt as called at kimimaro/intake.py:178-183."""
-    if voxel_graph is not None:
-        # edt.edt(voxel_graph=) treats the blocked directions as walls of the transform; the package's source is absent and the
-        # semantics of a wall BETWEEN two voxels of one label cannot be pinned here (DESIGN.md section 7)
-        raise NotImplementedError("edt(voxel_graph=): the wall semantics of the absent `edt` package are not restated")
     eng = engine()
     lab = np.asarray(labels)
     shape0 = lab.shape
@@ -37,6 +33,19 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False, parallel=1, voxel_grap
         lab = lab[..., np.newaxis]
     lab = np.asfortranarray(lab)
     an = list(anisotropy) + [1.0] * (3 - len(anisotropy))
+    if voxel_graph is not None:
+        # edt.edt(voxel_graph=): walls between voxels (kh_edt_graph_cells / kh_edt_graph_sample; the package is absent from the
+        # reference tree: PARITY UNPINNED, include/kimi_hip.h)
+        if ndim < 3 and black_border:
+            raise NotImplementedError("edt(voxel_graph=, black_border=True) on fewer than three axes")
+        vg = np.asarray(voxel_graph)
+        while vg.ndim < 3:
+            vg = vg[..., np.newaxis]
+        if tuple(vg.shape) != tuple(lab.shape):
+            raise ValueError("voxel_graph must have the shape of the labels")
+        d_graph = eng.to_device(np.asfortranarray(vg.astype(np.uint32)))
+        out = eng.edt_graph(eng.to_device(lab), lab.dtype.itemsize, d_graph, lab.shape, an, black_border)
+        return out.cpu().numpy().reshape(lab.shape, order="F").reshape(shape0, order="F")
     out = eng.edt(eng.to_device(lab), lab.dtype.itemsize, lab.shape, an, black_border, ndim=ndim)
     return out.cpu().numpy().reshape(lab.shape, order="F").reshape(shape0, order="F")
 

@@ -45,14 +45,12 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
     if dmax > soma_detection_threshold:  # kimimaro/trace.py:108-119
         # fill_voids.fill (kh_fill_voids, row f3) + crop re-EDT, both on the GPU
         d_filled, nfilled = eng.fill_voids((d_cc != 0).to(eng.torch.uint8), shape)
-        if nfilled > 0 and voxel_graph is not None:
-            # only a soma whose voids were filled is transformed again (kimimaro/trace.py:109-117), and only that needs edt(voxel_graph=)
-            raise NotImplementedError("voxel_graph together with a soma whose internal voids get filled (the re-EDT would need "
-                                      "edt(voxel_graph=), whose wall semantics are not restated)")
         if nfilled > 0:
             d_cc = d_filled.to(eng.torch.int32)
             cc = eng.to_host_volume(d_cc, shape)
-            d_dbf = eng.edt(d_cc, 4, shape, anisotropy, bool(np.all(cc)))
+            # kimimaro/trace.py:112-117 (with a graph: edt.edt(voxel_graph=), kh_edt_graph_*, PARITY UNPINNED)
+            d_dbf = eng.edt(d_cc, 4, shape, anisotropy, bool(np.all(cc))) if d_graph is None else \
+                eng.edt_graph(d_cc, 4, d_graph, shape, anisotropy, bool(np.all(cc)))
             dbf = d_dbf.cpu().numpy().reshape(shape, order="F")
             counts, dbf_max, first_index, xmin, xmax = eng.label_stats(d_cc, 4, d_dbf, shape, 1)
             dmax = np.float32(dbf_max[1])

@@ -123,6 +123,73 @@ def edt(labels, anisotropy=(1, 1, 1), black_border=False):
     return out.reshape(labels.shape, order="F") if nd < 3 else out
 
 
+_GRAPH_BIT = (1, 0, 3, 2, 5, 4, 9, 7, 8, 6, 17, 13, 16, 12, 15, 11, 14, 10, 25, 24, 23, 21, 22, 20, 19, 18)   # ko_graph_bit
+_DIRS = ((-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1), (-1, -1, 0), (-1, 1, 0), (1, -1, 0), (1, 1, 0),
+         (0, -1, -1), (0, -1, 1), (0, 1, -1), (0, 1, 1), (-1, 0, -1), (-1, 0, 1), (1, 0, -1), (1, 0, 1), (-1, -1, -1), (1, -1, -1),
+         (-1, 1, -1), (-1, -1, 1), (1, 1, -1), (1, -1, 1), (-1, 1, 1), (1, 1, 1))                                 # dijkstra_invalidation.hpp:60-124
+
+
+def edt_graph(labels, graph, anisotropy=(1, 1, 1), black_border=False):
+    """edt.edt(labels, anisotropy=, black_border=, voxel_graph=) (kimimaro/intake.py:174-183, trace.py:112-117).  The `edt` package is
+    absent from the reference tree -- PARITY UNPINNED by reference code.  Restated from the package's published method: the image
+    is doubled along every axis (voxel (x, y, z) at cell (2x, 2y, 2z)); the cell between a voxel and its +x / +y / +z neighbour is
+    foreground iff the voxel is and bit 0 / 2 / 4 of its graph word (cc3d's layout) is set; the remaining cells of a voxel's
+    2 x 2 x 2 block follow the voxel; a binary transform with HALF the pitch is sampled at the voxel cells.  Without a black border
+    the cells behind the last voxel of an axis follow the voxel (no wall at the end of the array, like at its start)."""
+    lab = _f3(np.asarray(labels))
+    g = _f3(np.asarray(graph)).astype(np.uint32)
+    fg = lab != 0
+    sx, sy, sz = lab.shape
+    cells = np.zeros((2 * sx, 2 * sy, 2 * sz), dtype=np.uint8, order="F")
+    px, py, pz = fg & ((g & 1) != 0), fg & ((g & 4) != 0), fg & ((g & 16) != 0)
+    if not black_border:
+        px[-1, :, :] = fg[-1, :, :]
+        py[:, -1, :] = fg[:, -1, :]
+        pz[:, :, -1] = fg[:, :, -1]
+    cells[0::2, 0::2, 0::2] = fg
+    cells[1::2, 0::2, 0::2] = px
+    cells[0::2, 1::2, 0::2] = py
+    cells[0::2, 0::2, 1::2] = pz
+    for sl in ((1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
+        cells[sl[0]::2, sl[1]::2, sl[2]::2] = fg
+    an = [np.float32(a) / np.float32(2) for a in (list(anisotropy) + [1.0] * (3 - len(anisotropy)))]
+    fine = edt(cells, an, black_border)
+    return np.asfortranarray(fine[0::2, 0::2, 0::2])
+
+
+def color_connectivity_graph(labels, graph):
+    """cc3d.color_connectivity_graph(voxel_graph, connectivity=26) followed by `cc_labels *= all_labels > 0` (kimimaro/utility.py:73-75;
+    cc3d is absent from the reference tree -- PARITY UNPINNED): two foreground voxels are joined iff they are 26-neighbours and the
+    graph word of the later one in the raster allows the step to the earlier one.  Ids 1..N by first appearance in the F-order raster."""
+    import scipy.sparse
+    import scipy.sparse.csgraph
+    lab = _f3(np.asarray(labels))
+    g = _f3(np.asarray(graph)).astype(np.uint32)
+    fg = lab != 0
+    sx, sy, sz = lab.shape
+    idx = np.arange(lab.size, dtype=np.int64).reshape(lab.shape, order="F")
+    rows, cols = [], []
+    for k, (dx, dy, dz) in enumerate(_DIRS):
+        if not (dz < 0 or (dz == 0 and (dy < 0 or (dy == 0 and dx < 0)))):
+            continue
+        src = tuple(slice(max(0, -d), n - max(0, d)) for d, n in zip((dx, dy, dz), (sx, sy, sz)))      # voxels that have the neighbour
+        dst = tuple(slice(max(0, d), n - max(0, -d)) for d, n in zip((dx, dy, dz), (sx, sy, sz)))
+        ok = fg[src] & fg[dst] & (((g[src] >> _GRAPH_BIT[k]) & 1) != 0)
+        rows.append(idx[src][ok])
+        cols.append(idx[dst][ok])
+    rows = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+    cols = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+    adj = scipy.sparse.coo_matrix((np.ones(rows.size, np.uint8), (rows, cols)), shape=(lab.size, lab.size))
+    _, comp = scipy.sparse.csgraph.connected_components(adj, directed=False)
+    flat_fg = fg.ravel(order="F")
+    comp = comp[flat_fg]
+    _, first, inv = np.unique(comp, return_index=True, return_inverse=True)
+    order = np.argsort(np.argsort(first))             # component -> rank of its first appearance
+    out = np.zeros(lab.size, dtype=np.uint32)
+    out[flat_fg] = order[inv] + 1
+    return out.reshape(lab.shape, order="F"), int(first.size)
+
+
 @contextlib.contextmanager
 def voxel_graph(graph):
     """voxel_graph= of the dijkstra3d calls (kimimaro/trace.py:139-145,155,240-242): inside the block every search of this module

@@ -47,8 +47,7 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
           fix_branching=True, manual_targets_before=None, manual_targets_after=None,
           root=None, max_paths=None, voxel_graph=None, stats=None, return_paths=False, _vcg=None):
     """kimimaro/trace.py:36-194.  voxel_graph (uint32 per voxel, cc3d's bit layout): handed to every dijkstra3d search and to the
-    invalidation as the reference does (trace.py:139-145,155,167,240-242,257); the soma branch's re-EDT ignores it here (edt's
-    voxel_graph semantics are not restated: source absent), so a graph together with a filled soma is outside the restatement."""
+    invalidation as the reference does (trace.py:139-145,155,167,240-242,257) and to the soma branch's re-EDT (K.edt_graph)."""
     if voxel_graph is not None:
         voxel_graph = np.asfortranarray(voxel_graph, dtype=np.uint32)
         with K.voxel_graph(voxel_graph):
@@ -69,7 +68,8 @@ def trace(labels, DBF, scale=10, const=10, anisotropy=(1, 1, 1),
         num_voxels_filled = int(np.count_nonzero(filled)) - int(np.count_nonzero(labels))
         if num_voxels_filled > 0:
             labels = np.asfortranarray(filled.astype(np.uint8))
-            DBF = K.edt(labels, anisotropy, black_border=bool(np.all(labels)))
+            DBF = K.edt(labels, anisotropy, black_border=bool(np.all(labels))) if _vcg is None else \
+                K.edt_graph(labels, _vcg, anisotropy, black_border=bool(np.all(labels)))       # trace.py:112-117
         dbf_max = np.max(DBF)
         soma_mode = bool(dbf_max > soma_acceptance_threshold)
     else:
@@ -230,9 +230,9 @@ def format_labels(labels):
     return lab
 
 
-def compute_cc_labels(all_labels):
+def compute_cc_labels(all_labels, voxel_graph=None):
     """kimimaro/utility.py:58-83: returns (cc_labels, {cc id: original id})."""
-    cc, n = K.connected_components(all_labels)
+    cc, n = K.connected_components(all_labels) if voxel_graph is None else K.color_connectivity_graph(all_labels, voxel_graph)
     first = np.zeros(n + 1, dtype=np.int64)
     flat_cc = cc.ravel(order="F")
     idx = np.flatnonzero(flat_cc)
@@ -393,8 +393,6 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
                 extra_targets_before=[], extra_targets_after=[], fill_holes=False,
                 fix_avocados=False, voxel_graph=None, stats=None):
     """kimimaro/intake.py:58-221 + skeletonize_subset :434-517 (serial path)."""
-    if voxel_graph is not None:
-        raise NotImplementedError("skeletonize(voxel_graph=) is out of the restated scope (edt / cc3d walls: sources absent)")
     anisotropy = np.array(anisotropy, dtype=np.float32)
     all_labels = format_labels(all_labels)
     if object_ids is not None:
@@ -404,14 +402,23 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
     minlabel, maxlabel = all_labels.min(), all_labels.max()
     if minlabel == 0 and maxlabel == 0:
         return {}
-    cc_labels, remapping = compute_cc_labels(all_labels)
+    if voxel_graph is not None:
+        # intake.py:162,174-183,467 with a graph: cc3d.color_connectivity_graph + edt.edt(voxel_graph=) (both packages absent from
+        # the reference tree: PARITY UNPINNED, oracle/__init__.py) and the cropped graph to every trace()
+        if fix_avocados:
+            raise NotImplementedError("skeletonize(voxel_graph=, fix_avocados=True)")
+        voxel_graph = np.asfortranarray(np.asarray(voxel_graph).reshape(all_labels.shape, order="F"), dtype=np.uint32)
+    cc_labels, remapping = compute_cc_labels(all_labels, voxel_graph)
     if fill_holes:
         cc_labels = fill_all_holes(cc_labels)                                    # intake.py:168-169
 
     before = _points_to_labels(extra_targets_before, cc_labels)
     after = _points_to_labels(extra_targets_after, cc_labels)
 
-    all_dbf = K.edt(cc_labels, anisotropy, black_border=(minlabel == maxlabel))  # intake.py:174-185
+    if voxel_graph is not None:
+        all_dbf = K.edt_graph(cc_labels, voxel_graph, anisotropy, black_border=(minlabel == maxlabel))
+    else:
+        all_dbf = K.edt(cc_labels, anisotropy, black_border=(minlabel == maxlabel))  # intake.py:174-185
     if fix_avocados:                                                             # intake.py:187-193
         cc_labels, all_dbf, remapping = engage_avocado_protection(
             cc_labels, all_dbf, remapping, teasar_params.get("soma_detection_threshold", 0),
@@ -452,6 +459,7 @@ def skeletonize(all_labels, teasar_params=DEFAULT_TEASAR_PARAMS, anisotropy=(1, 
 
         skel = trace(labels, dbf, anisotropy=anisotropy, fix_branching=fix_branching,
                      manual_targets_before=mtb, manual_targets_after=mta, root=root,
+                     voxel_graph=(None if voxel_graph is None else voxel_graph[slices]),          # intake.py:467
                      stats=stats, **teasar_params)
         if skel.empty():
             continue
