@@ -186,6 +186,9 @@ class Engine:
         self.fuse_edf = os.environ.get("KH_FUSE_EDF", "1") != "0"
         # volumes in flight: this many of the largest labels of a call are fused and launched FIRST, on a second stream (0: off)
         self.early_labels = int(os.environ.get("KH_EARLY_LABELS", "0"))
+        # volumes in flight: called (once per volume) between the searches and the path loop, with this lane's stream drained --
+        # kimimaro_amd.lanes._CohortGate holds the lane there until the searches of every volume of its cohort are through
+        self.path_gate = None
         self.heap_prio = os.environ.get("KH_HEAP_PRIO", "0") == "1"         # s_setprio 3 for the heap-emulation wave (A/B knob)
         self.sweep_window = os.environ.get("KH_SWEEP_WINDOW", "1") != "0"   # level words for a window of levels only (A/B knob)
         # ghosts: a call of the sweep that leaves voxels undecided goes on with them as ghosts instead of running
@@ -985,6 +988,9 @@ class Engine:
             return None
         if not fuse_rest and not searched:
             searches(0, nl)
+        if self.path_gate is not None and consume is not None:
+            self.sync_stream()
+            self.path_gate()
         launch(0, nl, st, fused=fuse_rest)
         mark("paths")
         res = collect(0, nl)                  # (its device -> host copies wait for the launch)

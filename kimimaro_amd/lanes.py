@@ -55,6 +55,46 @@ def ensure_hw_queues(width):
             "each other." % (width, have or "unset (4)", width, width + 1, want))
 
 
+class _CohortGate:
+    """Phase alignment of the volumes in flight.  Jobs k = c * width .. (c + 1) * width - 1 form cohort c; a lane that has issued
+    the searches of its volume (find_root, DAF, PDRF: short launches that fill the GPU) waits here, with its stream drained, until
+    every job of the cohort has done so, and only then launches its path loop (seconds of a few long chains).  Without the gate
+    the path workgroups of the lanes that got through their preamble first hold every wave slot while the other lanes' search
+    workgroups (eight waves each, all on one CU) wait for slots: in a round of twenty volumes the forty search launches took
+    3.4 s for 1.3 s of work (profiles/r06_lanes20_timeline.txt).  A job that ends without reaching the gate (an exception, a
+    volume without labels) is counted by done()."""
+
+    def __init__(self, n, width):
+        self.n, self.width = int(n), int(width)
+        self.cv = threading.Condition()
+        self.arrived = {}          # cohort -> set of jobs that reached the gate or ended
+        self.broken = False
+
+    def _size(self, c):
+        return min(self.width, self.n - c * self.width)
+
+    def _arrive(self, k):
+        c = k // self.width
+        self.arrived.setdefault(c, set()).add(k)
+        self.cv.notify_all()
+        return c
+
+    def wait(self, k):
+        with self.cv:
+            c = self._arrive(k)
+            while len(self.arrived[c]) < self._size(c) and not self.broken:
+                self.cv.wait(timeout=0.25)
+
+    def done(self, k):
+        with self.cv:
+            self._arrive(k)
+
+    def abort(self):
+        with self.cv:
+            self.broken = True
+            self.cv.notify_all()
+
+
 class Lanes:
     def __init__(self, width, device=None, engine_factory=None, stream_factory=None):
         """width lanes on `device`.  The factories exist for the host-logic tests (no GPU): engine_factory() -> object
@@ -89,17 +129,21 @@ class Lanes:
         self.engines = []
         self._scopes = []
 
-    def run(self, job, n, width=None, stagger=0.0):
+    def run(self, job, n, width=None, stagger=0.0, cohorts=None):
         """Generator over (k, job(engine, k)) for k = 0..n-1, in order, with at most `width` jobs in flight.  An exception
         of job k is raised when k is reached (later jobs may have run).
         stagger: lane i takes its first job i * stagger seconds after lane 0.  Jobs of equal length started together stay
         in lock step -- their GPU-filling phases collide and their tails leave the GPU idle together; offset by
         (duration of one job) / width they interleave.
+        cohorts: the lanes' path loops start together, cohort by cohort (_CohortGate); default on (KH_COHORT_GATE=0: off).
         When the consumer stops early (an exception of job k, or the generator is closed) no NEW job is started, but the
         jobs already in flight are waited for before this returns."""
         width = self.width if width is None else max(1, min(int(width), self.width))
         if n <= 0:
             return
+        if cohorts is None:
+            cohorts = os.environ.get("KH_COHORT_GATE", "1") != "0"
+        gate = _CohortGate(n, min(width, n)) if (cohorts and min(width, n) > 1 and stagger <= 0) else None
         lock = threading.Lock()
         nxt = [0]
         out = [None] * n
@@ -120,11 +164,17 @@ class Lanes:
                     if k >= n or stop[0]:
                         return
                     try:
+                        if gate is not None:
+                            _set_gate(eng, gate, k)
                         out[k] = (True, job(eng, k))
                         if scope is not None and hasattr(scope, "synchronize"):
                             scope.synchronize()
                     except BaseException as ex:  # handed to the caller at position k
                         out[k] = (False, ex)
+                    finally:
+                        if gate is not None:
+                            _set_gate(eng, None, k)
+                            gate.done(k)
                     ready[k].set()
             failure = None
             try:
@@ -167,8 +217,27 @@ class Lanes:
                 yield k, val
         finally:
             stop[0] = True
+            if gate is not None:
+                gate.abort()
             for th in threads:
                 th.join()
+
+
+def _set_gate(eng, gate, k):
+    """Engine.path_gate: called once, by run_labels, between the searches of a volume and its path loop (kimimaro_amd/engine.py)"""
+    if gate is None:
+        fn = None
+    else:
+        state = {"open": False}
+
+        def fn():
+            if not state["open"]:
+                state["open"] = True
+                gate.wait(k)
+    try:
+        eng.path_gate = fn
+    except AttributeError:      # (the host-logic tests hand over engines that are not Engine objects)
+        pass
 
 
 def lanes_for(shape, free_bytes, most=24, share=1.0):

@@ -200,3 +200,38 @@ def test_lanes_for_memory_rule():
     assert lanes_for((1024, 1024, 1024), 288e9) == 2               # c5: two volumes in flight (round 5: one)
     assert lanes_for((512, 512, 512), 288e9, share=0.125) >= 24    # a rank of eight holds an eighth of the per-label scratch
     assert lanes_for((64, 64, 64), 1e9, most=5) == 5
+
+
+def test_cohort_gate_aligns_the_path_loops_and_survives_jobs_that_never_reach_it():
+    """Engine.path_gate (kimimaro_amd.lanes._CohortGate): no job of a cohort passes the gate before every job of the cohort has
+    reached it or ended; a job that raises, or never calls the gate, does not hold the others; the last, smaller cohort works."""
+    lanes = _lanes(3)
+    lock = threading.Lock()
+    reached, passed_when = {}, {}
+
+    def job(eng, k):
+        time.sleep(0.01 * (k % 3))
+        if k == 1:
+            raise ValueError("job 1 fails before its gate")
+        if k == 4:
+            return k                      # (a volume without labels: the gate is never called)
+        with lock:
+            reached[k] = time.perf_counter()
+        eng.path_gate()
+        eng.path_gate()                   # (one-shot: a second call -- the overflow retry -- returns at once)
+        with lock:
+            passed_when[k] = time.perf_counter()
+        return k
+
+    got = []
+    with pytest.raises(ValueError):
+        for k, v in lanes.run(job, 8, cohorts=True):
+            got.append(v)
+    assert got == [0]
+    got = [v for _, v in lanes.run(lambda e, k: job(e, k + 2), 6, cohorts=True)]     # jobs 2..7: cohorts {2,3,4}, {5,6,7}
+    assert got == [2, 3, 4, 5, 6, 7]
+    for cohort in ((2, 3), (5, 6, 7)):
+        last_reach = max(reached[k] for k in cohort)
+        assert all(passed_when[k] >= last_reach for k in cohort)
+    # without the gate the engines carry no hook
+    assert [v for _, v in lanes.run(lambda e, k: getattr(e, "path_gate", None) is None, 3, cohorts=False)] == [True] * 3
