@@ -45,8 +45,14 @@ static constexpr unsigned long long SW_DYING = 1ull << 63;
 static constexpr unsigned long long SW_SPILL = 1ull << 15;      // the voxel's fifth to eighth possible owners are in the spill table
 static constexpr uint8_t SW_GHOST = 3;                          // alive byte of a voxel that is dead under SOME resolutions of an earlier call
 static constexpr uint32_t SW_P = 1u << 16, SW_D = 1u << 17;     // event meta = source index (15 bits) | type
-static constexpr uint32_t SW_CHAIN = 512;                        // chunks per level the reader can take (LDS list)
-static constexpr uint32_t SW_RING = 256;                         // free chunk ids kept in LDS (the chunks of finished levels)
+#ifndef KH_SW_CHAIN
+#define KH_SW_CHAIN 512
+#endif
+#ifndef KH_SW_RING
+#define KH_SW_RING 256
+#endif
+static constexpr uint32_t SW_CHAIN = KH_SW_CHAIN;                        // chunks per level the reader can take (LDS list)
+static constexpr uint32_t SW_RING = KH_SW_RING;                         // free chunk ids kept in LDS (the chunks of finished levels)
 static constexpr int SW_FILL_BITS = 12;                          // level word = (newest chunk << SW_FILL_BITS) | next free slot.  The fill
 static constexpr uint32_t SW_FILL_MASK = (1u << SW_FILL_BITS) - 1u;   // field keeps counting while a chunk is full: up to 13 adds per thread (sweep_push26)
 static constexpr uint32_t SW_NOCHUNK = 0xFFFFFu;                 // of a 256-thread workgroup + the chunk size must fit it; 20-bit chunk ids

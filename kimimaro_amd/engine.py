@@ -224,7 +224,13 @@ class Engine:
         self._level_tables = {}
         self.scratch_divisor = 1            # tests: shrink the heap / path scratch to exercise the overflow retry
         self.arena_divisor = 1              # tests: shrink the sweep's event arena (a call that runs out falls back to the heap)
-        self.window_cap = 0                 # tests: cap the level window (an event beyond it abandons the call to the heap)
+        # Cap of the level window (words of LDS per label's workgroup; an event beyond it abandons the call to the heap emulation).
+        # The launch gives EVERY workgroup the LDS of its neediest label: at c3 one label of 3 402 wants 4 096 words (20 KB), which
+        # holds a CU to 7 one-wave workgroups where the registers allow 12; with 2 048 (11.5 KB) all 12 fit.  The lanes set 2 048
+        # for their 64-thread engines (kimimaro_amd.lanes); 0 = no cap (one volume alone: three 256-thread workgroups per CU).
+        # The cap applies only when at most 0.5 % of the launch's labels want more (window_cap_always: whatever the share; tests).
+        self.window_cap = int(os.environ.get("KH_WINDOW_CAP", "0"))
+        self.window_cap_always = "KH_WINDOW_CAP" in os.environ
         # Per-label scratch (heap, work lists, event arena, path buffers: SCRATCH_BYTES_PER_VOXEL per voxel of a label) of ONE path-loop
         # launch.  Labels beyond it go to further launches of the same call, largest labels first (callers that consume
         # results incrementally only); the whole-volume fields (~40 B per voxel of the volume) are not counted.
@@ -306,7 +312,7 @@ class Engine:
                 e = Engine(self.device)
                 e.soma_lanes = 1
                 # the lane engines trace with the parent's settings (a test that switches the sweep or the ghosts off means the somas too)
-                for knob in ("sweep", "ghosts", "ghost_paranoid", "int_keys", "scratch_divisor", "arena_divisor", "window_cap", "profile",
+                for knob in ("sweep", "ghosts", "ghost_paranoid", "int_keys", "scratch_divisor", "arena_divisor", "window_cap", "window_cap_always", "profile",
                              "trace_threads", "edf_threads", "sweep_window", "sweep_lds_levels", "big_lds_heap", "scratch_pool",
                              "scratch_pool_fraction", "heap_prio"):
                     setattr(e, knob, getattr(self, knob))
@@ -675,7 +681,9 @@ class Engine:
             lv = self.sweep_levels(shape, anisotropy, rmax_t, cnt)
             if lv is not None and int(lv["nlev"].max()) > 0:
                 nlev, win, ok = lv["nlev"], lv["win"], lv["ok"]
-                if self.window_cap:
+                if self.window_cap and (self.window_cap_always or
+                                        np.count_nonzero(win > int(self.window_cap)) <= max(1, int(0.005 * win.size))):
+                    # (only when few labels pay for it: a capped label's widest calls are redone by the heap emulation)
                     win = np.where(win > 0, np.minimum(win, int(self.window_cap)), win)
                 # fixed-size event chunks, chained per level (csrc/sweep.h): what is pending at one time
                 shift, chunks = plan_arena(cnt, nlev, True, win)

@@ -21,6 +21,7 @@ import time
 
 
 LANE_THREADS = 64     # threads per label of a lane's path loop (Engine.trace_threads): one wave, twelve labels per CU
+LANE_WINDOW_CAP = 2048   # level words per label in LDS (Engine.window_cap): 11.5 KB per workgroup, so that twelve fit a CU's 160 KB
 
 
 def ensure_hw_queues(width):
@@ -115,6 +116,8 @@ class Lanes:
                     # the searches stay batch launches of their own in a lane (70 VGPRs: twice the waves per CU of the path kernel);
                     # fused into the path kernel (the single-volume default) twenty volumes took 523 ms per step against 428
                     e.fuse_edf = False
+                if "KH_WINDOW_CAP" not in os.environ and e.trace_threads == LANE_THREADS:
+                    e.window_cap = LANE_WINDOW_CAP
                 e.soma_lanes = 1        # (no lanes inside a lane: the other volumes are what fills the GPU)
                 return e
 

@@ -340,6 +340,7 @@ def test_sweep_storage_variants_and_their_bails(variant):
         eng2.arena_divisor = 64
     elif variant == "narrow_window":
         eng2.window_cap = 64
+        eng2.window_cap_always = True     # (the production rule caps only when few labels pay for it)
     elif variant == "tiny_pool":
         eng2.scratch_pool_fraction = 0.001   # heap and journal on demand from a pool that serves nobody: ghost calls are rolled back at
     elif variant == "no_pool":               # once, labels that need the heap emulation are traced again with scratch of their own
