@@ -566,19 +566,26 @@ def consolidate_paths(locs, lens, radii, shape):
     return verts, edges.astype(np.uint32), radii[first]
 
 
-def consolidate_paths_batch(res, shape):
+def _ranges(starts, counts):
+    """concatenation of starts[i] + arange(counts[i]) over i, without a Python loop"""
+    counts = np.asarray(counts, dtype=np.int64)
+    total = int(counts.sum())
+    before = np.cumsum(counts) - counts
+    return np.repeat(np.asarray(starts, dtype=np.int64) - before, counts) + np.arange(total, dtype=np.int64)
+
+
+def consolidate_paths_flat(res, shape):
     """consolidate_paths for EVERY label of a result group in one go (one sort over all path vertices instead of three
     np.unique calls per label: the per-label numpy overhead, 170 us x 3.4 k labels, was most of the assembly time of a
-    512^3 volume).  Yields (slot, vertices (n,3) f32, edges (m,2) u32, radii) for the slots that have vertices, the same
-    arrays the per-label function returns."""
+    512^3 volume).  Returns None for a group without vertices, else the slots' arrays back to back:
+    verts (N,3) f32, radii (N) f32, edges (M,2) u32 with indices local to the slot, vstart / estart [nslots+1]."""
     sx, sy, sz = shape
     voff = np.asarray(res["voff"], dtype=np.int64)
-    loff = np.asarray(res["loff"], dtype=np.int64)
     nslots = voff.size - 1
     locs = res["verts"].astype(np.int64)
     n = locs.size
     if n == 0:
-        return
+        return None
     V = np.int64(sx) * sy * sz
     slot_of = np.repeat(np.arange(nslots, dtype=np.int64), np.diff(voff))
     x, y, z = locs % sx, (locs // sx) % sy, locs // (sx * sy)
@@ -602,25 +609,38 @@ def consolidate_paths_batch(res, shape):
     used[elo] = True
     used[ehi] = True
     # vertices no edge refers to are dropped (Skeleton.consolidate); local index = rank among the slot's used vertices
-    rank = np.cumsum(used) - 1
-    base = np.concatenate([[0], np.cumsum(used)])[ustart[:-1]] if nu else np.zeros(nslots, np.int64)
-    vx, vy, vz = x[first], y[first], z[first]
-    verts_all = np.stack([vx, vy, vz], axis=1).astype(np.float32)[used]
-    radii_all = res["radii"][first][used]
-    vstart = np.concatenate([[0], np.cumsum(used)])[ustart]    # used vertices of slot s: [vstart[s], vstart[s+1])
+    cum = np.concatenate([[0], np.cumsum(used)])
+    rank = cum[1:] - 1
+    base = cum[ustart[:-1]] if nu else np.zeros(nslots, np.int64)
+    fu = first[used]
+    verts_all = np.stack([x[fu], y[fu], z[fu]], axis=1).astype(np.float32)
+    radii_all = res["radii"][fu]
+    vstart = cum[ustart]                                       # used vertices of slot s: [vstart[s], vstart[s+1])
     eslot = uslot[elo]
     estart = np.searchsorted(eslot, np.arange(nslots + 1, dtype=np.int64))
     edges_all = np.stack([rank[elo] - base[eslot], rank[ehi] - base[eslot]], axis=1).astype(np.uint32)
-    for s in range(nslots):
+    return {"verts": verts_all, "radii": radii_all, "edges": edges_all, "vstart": vstart, "estart": estart, "voff": voff}
+
+
+def consolidate_paths_batch(res, shape):
+    """consolidate_paths_flat slot by slot: yields (slot, vertices (n,3) f32, edges (m,2) u32, radii) for the slots that have
+    vertices, the same arrays the per-label function returns."""
+    f = consolidate_paths_flat(res, shape)
+    if f is None:
+        return
+    vstart, estart, voff = f["vstart"], f["estart"], f["voff"]
+    for s in range(voff.size - 1):
         if voff[s + 1] == voff[s]:
             continue
-        yield s, verts_all[vstart[s]:vstart[s + 1]], edges_all[estart[s]:estart[s + 1]], radii_all[vstart[s]:vstart[s + 1]]
+        yield s, f["verts"][vstart[s]:vstart[s + 1]], f["edges"][estart[s]:estart[s + 1]], f["radii"][vstart[s]:vstart[s + 1]]
 
 
 class Assembler:
     """Skeleton assembly: kimimaro/trace.py:182-192 + intake.py:506-517, 587-593.  Results arrive in groups of
-    labels (Engine.run_labels hands them over as the groups finish on the GPU): `add` builds the per-component
-    skeletons, `finish` merges the components of every original label."""
+    labels (Engine.run_labels hands them over as the groups finish on the GPU): `add` consolidates the paths of a group's
+    components, `finish` merges the components of every original label.  Nothing here loops over components in Python: with
+    twenty volumes in flight the lanes reach this point together and every millisecond of interpreter time is paid twenty times
+    in a row (0.8 s of a 7.8 s round before this form)."""
 
     def __init__(self, shape, anisotropy, remapping):
         self.shape = shape
@@ -628,52 +648,116 @@ class Assembler:
         self.an = np.asarray(anisotropy, dtype=np.float32)
         an = self.an
         self.transform = np.array([[an[0], 0, 0, 0], [0, an[1], 0, 0], [0, 0, an[2], 0]], dtype=np.float32)
-        self.skeletons = defaultdict(list)
+        self.skeletons = defaultdict(list)       # original label -> [(component id, verts, edges, radii)]: per-component hand-over (tests)
+        self.groups = []                         # (component ids of the group's slots, consolidate_paths_flat of the group)
 
     def add(self, res):
-        tasks = res["tasks"]
-        for slot, verts, edges, radii in consolidate_paths_batch(res, self.shape):
-            if edges.shape[0] == 0:                      # Skeleton.empty(), intake.py:506
-                continue
-            segid = int(tasks["segid"][slot])
-            self.skeletons[self.remapping[segid]].append((segid, verts, edges, radii))
+        flat = consolidate_paths_flat(res, self.shape)
+        if flat is not None:
+            self.groups.append((np.asarray(res["tasks"]["segid"], dtype=np.int64), flat))
+
+    def _parts(self):
+        """the components that have edges (Skeleton.empty() ones are dropped, intake.py:506), in arrival order, as arrays: component
+        id, original label (as a code into `labels`), and where their vertices / edges lie in the concatenated arrays"""
+        seg, v0, nv, e0, ne, Vs, Rs, Es = [], [], [], [], [], [], [], []
+        vbase = ebase = 0
+        for segids, f in self.groups:
+            cnt_e = np.diff(f["estart"])
+            keep = np.flatnonzero(cnt_e > 0)
+            seg.append(segids[keep])
+            v0.append(f["vstart"][keep] + vbase)
+            nv.append(np.diff(f["vstart"])[keep])
+            e0.append(f["estart"][keep] + ebase)
+            ne.append(cnt_e[keep])
+            Vs.append(f["verts"]); Rs.append(f["radii"]); Es.append(f["edges"])
+            vbase += f["verts"].shape[0]
+            ebase += f["edges"].shape[0]
+        for orig, parts in self.skeletons.items():            # (hand-over per component: the same arrays, one part at a time)
+            for comp, verts, edges, radii in parts:
+                if edges.shape[0] == 0:
+                    continue
+                seg.append(np.array([-1 - len(self._extra)], dtype=np.int64))
+                self._extra.append((orig, comp))
+                v0.append(np.array([vbase])); nv.append(np.array([verts.shape[0]]))
+                e0.append(np.array([ebase])); ne.append(np.array([edges.shape[0]]))
+                Vs.append(np.asarray(verts, dtype=np.float32)); Rs.append(np.asarray(radii, dtype=np.float32))
+                Es.append(np.asarray(edges, dtype=np.uint32))
+                vbase += verts.shape[0]
+                ebase += edges.shape[0]
+        if not seg:
+            return None
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False)
+        return (cat(seg, np.int64), cat(v0, np.int64), cat(nv, np.int64), cat(e0, np.int64), cat(ne, np.int64),
+                np.concatenate(Vs), np.concatenate(Rs), np.concatenate(Es))
 
     def finish(self):
-        """one Skeleton per original label.  The components of a label are disjoint voxel sets, so
-        Skeleton.simple_merge(...).consolidate() (intake.py:587-593) is a concatenation re-sorted lexicographically by
-        vertex: done on integer keys for all labels in ONE native call outside the interpreter (kh_host_merge_components;
-        same result as np.unique(vertices, axis=0) + edge remap per label -- which was a dozen numpy calls for each of
-        thousands of labels on the host thread of the lane)."""
+        """one Skeleton per original label, in the order in which the labels' first components arrived.  The components of a
+        label are disjoint voxel sets, so Skeleton.simple_merge(...).consolidate() (intake.py:587-593) is a concatenation
+        re-sorted lexicographically by vertex: done on integer keys for all labels in ONE native call outside the interpreter
+        (kh_host_merge_components; same result as np.unique(vertices, axis=0) + edge remap per label)."""
         import ctypes as C
         from . import _abi
         sx, sy, sz = self.shape
-        origs = list(self.skeletons.keys())                       # (insertion order = the order of the returned dict)
-        if not origs:
+        self._extra = []
+        got = self._parts()
+        if got is None:
             return {}
-        parts, part_of_label = [], [0]
-        for orig in origs:
-            parts.extend(sorted(self.skeletons[orig], key=lambda p: p[0]))      # component order of intake.py:444
-            part_of_label.append(len(parts))
-        nv = np.fromiter((p[1].shape[0] for p in parts), dtype=np.int64, count=len(parts))
-        ne = np.fromiter((p[2].shape[0] for p in parts), dtype=np.int64, count=len(parts))
-        vstart = np.concatenate([[0], np.cumsum(nv)]).astype(np.int64)
-        estart = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
-        V = np.ascontiguousarray(np.concatenate([p[1] for p in parts]), dtype=np.float32)
-        R = np.ascontiguousarray(np.concatenate([p[3] for p in parts]), dtype=np.float32)
-        E = np.ascontiguousarray(np.concatenate([p[2] for p in parts]), dtype=np.uint32)
-        pol = np.asarray(part_of_label, dtype=np.int64)
+        seg, v0, nv, e0, ne, Vall, Rall, Eall = got
+        # original label of every part, as a code; the dict of component ids is read once, not once per component
+        keys = np.fromiter(self.remapping.keys(), dtype=np.int64, count=len(self.remapping)) if len(self.remapping) else np.zeros(0, np.int64)
+        vals = list(self.remapping.values())
+        comp_of = seg.copy()
+        label_objs = []
+        code_of_obj = {}
+        if keys.size:
+            ks = np.argsort(keys, kind="stable")
+            pos = np.searchsorted(keys[ks], np.maximum(seg, 0))
+            pos = np.minimum(pos, keys.size - 1)
+            idx_in_vals = ks[pos]
+        else:
+            idx_in_vals = np.zeros(seg.size, dtype=np.int64)
+        # code per distinct original label VALUE (several component ids map to one label)
+        val_code = np.empty(len(vals), dtype=np.int64)
+        for i, v in enumerate(vals):
+            c = code_of_obj.get(v)
+            if c is None:
+                c = code_of_obj[v] = len(label_objs)
+                label_objs.append(v)
+            val_code[i] = c
+        code = val_code[idx_in_vals] if len(vals) else np.zeros(seg.size, dtype=np.int64)
+        for j in np.flatnonzero(seg < 0):                       # per-component hand-over: (label, component id) given directly
+            orig, comp = self._extra[-1 - int(seg[j])]
+            c = code_of_obj.get(orig)
+            if c is None:
+                c = code_of_obj[orig] = len(label_objs)
+                label_objs.append(orig)
+            code[j] = c
+            comp_of[j] = comp
+        ucode, first_idx = np.unique(code, return_index=True)
+        label_order = ucode[np.argsort(first_idx, kind="stable")]                # labels by first arrival
+        rank_of_code = np.empty(len(label_objs), dtype=np.int64)
+        rank_of_code[label_order] = np.arange(label_order.size)
+        order = np.lexsort((comp_of, rank_of_code[code]))                        # label by label, components by id (intake.py:444)
+        nvs, nes = nv[order], ne[order]
+        V = np.ascontiguousarray(Vall[_ranges(v0[order], nvs)], dtype=np.float32)
+        R = np.ascontiguousarray(Rall[_ranges(v0[order], nvs)], dtype=np.float32)
+        E = np.ascontiguousarray(Eall[_ranges(e0[order], nes)], dtype=np.uint32)
+        vstart = np.concatenate([[0], np.cumsum(nvs)]).astype(np.int64)
+        estart = np.concatenate([[0], np.cumsum(nes)]).astype(np.int64)
+        pol = np.concatenate([[0], np.cumsum(np.bincount(rank_of_code[code], minlength=label_order.size))]).astype(np.int64)
         oV, oR, oE = np.empty_like(V), np.empty_like(R), np.empty_like(E)
         P = lambda a: a.ctypes.data_as(C.c_void_p)
-        if _abi.lib().kh_host_merge_components(len(origs), P(pol), P(vstart), P(estart), P(V), P(R), P(E), int(sy), int(sz),
+        if _abi.lib().kh_host_merge_components(int(label_order.size), P(pol), P(vstart), P(estart), P(V), P(R), P(E), int(sy), int(sz),
                                                np.float32(self.an[0]), np.float32(self.an[1]), np.float32(self.an[2]),
                                                P(oV), P(oR), P(oE)) != 0:
             raise MemoryError("kh_host_merge_components failed")
         merged = {}
-        va, ea = vstart[pol], estart[pol]                         # first vertex / edge of every label
-        for li, orig in enumerate(origs):
+        va, ea = vstart[pol].tolist(), estart[pol].tolist()       # first vertex / edge of every label
+        wrap, tf = Skeleton.wrap, self.transform
+        for li, c in enumerate(label_order.tolist()):
             # copies: the public arrays own their memory (a kept Skeleton does not pin the volume's buffers)
-            merged[orig] = Skeleton.wrap(oV[va[li]:va[li + 1]].copy(), oE[ea[li]:ea[li + 1]].copy(), oR[va[li]:va[li + 1]].copy(),
-                                         orig, self.transform.copy(), "physical")
+            a, b, e0_, e1_ = va[li], va[li + 1], ea[li], ea[li + 1]
+            merged[label_objs[c]] = wrap(oV[a:b].copy(), oE[e0_:e1_].copy(), oR[a:b].copy(), label_objs[c], tf.copy(), "physical")
         return merged
 
 

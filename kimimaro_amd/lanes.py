@@ -103,6 +103,9 @@ class Lanes:
         if width < 1:
             raise ValueError("Lanes: width must be >= 1")
         self.width = int(width)
+        if os.environ.get("KH_SWITCH_INTERVAL"):
+            import sys
+            sys.setswitchinterval(float(os.environ["KH_SWITCH_INTERVAL"]))
         if engine_factory is None:
             ensure_hw_queues(self.width)
             from .engine import Engine
