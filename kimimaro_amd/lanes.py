@@ -21,6 +21,7 @@ import time
 
 
 LANE_THREADS = 64     # threads per label of a lane's path loop (Engine.trace_threads): one wave, twelve labels per CU
+LANE_EDF_THREADS = 128   # threads per label of a lane's distance-field searches (Engine.edf_threads)
 LANE_WINDOW_CAP = 2048   # level words per label in LDS (Engine.window_cap): 11.5 KB per workgroup, so that twelve fit a CU's 160 KB
 
 
@@ -103,9 +104,6 @@ class Lanes:
         if width < 1:
             raise ValueError("Lanes: width must be >= 1")
         self.width = int(width)
-        if os.environ.get("KH_SWITCH_INTERVAL"):
-            import sys
-            sys.setswitchinterval(float(os.environ["KH_SWITCH_INTERVAL"]))
         if engine_factory is None:
             ensure_hw_queues(self.width)
             from .engine import Engine
@@ -119,6 +117,11 @@ class Lanes:
                     # the searches stay batch launches of their own in a lane (70 VGPRs: twice the waves per CU of the path kernel);
                     # fused into the path kernel (the single-volume default) twenty volumes took 523 ms per step against 428
                     e.fuse_edf = False
+                if "KH_EDF_THREADS" not in os.environ:
+                    # two waves per label in the searches: eight labels per CU instead of two (the kernel holds four waves per SIMD);
+                    # behind the cohort gate the forty search launches of a round are one phase: 373 / 363 / 368 ms per step with
+                    # 512 / 128 / 64 threads
+                    e.edf_threads = LANE_EDF_THREADS
                 if "KH_WINDOW_CAP" not in os.environ and e.trace_threads == LANE_THREADS:
                     e.window_cap = LANE_WINDOW_CAP
                 e.soma_lanes = 1        # (no lanes inside a lane: the other volumes are what fills the GPU)
