@@ -9,15 +9,16 @@
 //     finds its nearest label change on either side with clz/ctz on those words -- O(1) per voxel, one
 //     coalesced read of the labels, one coalesced write of the squared distance.
 //   * y and z pass: lanes along x (every access of the pass is a coalesced 256-B row segment), a tile of rows
-//     staged in LDS together with per-column run masks, and an exact window search per voxel:
-//     best = min(best, f[j] + (w*k)^2) walking outward until (w*k)^2 >= best or the same-label segment ends.
+//     staged in LDS as two views with the segment ends folded into the data, and an exact window search per voxel:
+//     best = min(best, view[j] + (w*k)^2) walking outward until (w*k)^2 >= best -- no limits, masks or labels in the
+//     search; windows wider than the halo are served band by band by the whole workgroup (see edt_axis_kernel).
 //     The window is ~sqrt(best)/w voxels, i.e. the local object radius.  The minimum is exact over the float
 //     expressions, no envelope intersections, no sequential dependency between voxels.
 //   * block -> tile mapping is XCD aware: the 8 XCDs (block b runs on XCD b % 8) each get a
 //     contiguous 1/8 of the volume so the rows a block re-reads live in its own L2.
-// Algorithmic bytes = L + 4 (x pass) and L + 8 (y, z pass) per voxel; measured HBM traffic matches them, the
-// y / z passes are bound by instruction issue.
+// Algorithmic bytes = L + 4 (x pass) and L + 8 (y, z pass) per voxel; measured HBM traffic matches them.
 #include "common.h"
+#include <cstdlib>
 
 namespace kh {
 
@@ -204,217 +205,237 @@ __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ 
 // soon as (w*k)^2 >= best -- nothing farther can improve the minimum -- so the result is the exact
 // minimum over the float expressions in any visiting order (== oracle ko_edt_axis).
 //
-// A workgroup (64 x 4 threads) owns 64 lanes along x times T = 64 positions along the axis.
-//  * stage: rows [A0-H, A0+T+H) of f go to LDS (H = 32, 32 KiB, bank = lane: conflict free); at the same
-//    time every column gets a 128-bit "label changes at this row" mask and a "background" mask.
-//  * limits: the number of same-label rows below / above an output is a clz / ctz on its column's mask --
-//    no label is loaded or compared inside the search loop.
-//  * search: probes read LDS only.  Runs or windows that leave the staged rows (objects wider than H
-//    voxels) continue in a slow path on global memory.
-// Every f element is fetched from L2/HBM (T+2H)/T = 2x instead of 2*window times.
+// Round 6: the segment ends are folded into the DATA, so the search has no limits, no masks and no labels.
+// A label change between rows j and j+1 contributes the candidate (w*(i-j))^2 to a voxel i above it -- exactly what row j
+// would contribute if its f were 0 -- and the voxels of the lower segment must still see row j's real f.  So a tile is staged
+// as TWO views: Fd[j] = "row j as seen by somebody walking DOWN onto it" (0 when label[j] != label[j+1], else f[j]) and
+// Fu[j] = "as seen walking UP" (0 when label[j] != label[j-1]).  Rows outside the volume are 0 with black_border, +inf
+// without.  A walk that reaches a segment end at step kb now holds best <= (w*kb)^2 and stops by the ordinary bound test;
+// whatever a group of probes reads beyond the end is >= (w*k')^2 > (w*kb)^2 >= best and cannot lower it.  Background voxels
+// carry f = 0 from the x pass, so their search never starts: no background mask either.  The candidate set that can lower
+// `best` is the oracle's, the minimum is over the same float expressions: bit identical.
+//
+// A workgroup (64 x 4 threads) owns 64 lanes along x times T = 64 positions along the axis; wave ly owns the 16 consecutive
+// output rows [16 ly, 16 ly + 16), stages them (their f stays in registers: the own value is never read back) plus a quarter
+// of the halo rows; the rows of the NEXT tile are requested before the search of the current one.
+//
+// BANDS.  The staged rows serve steps k <= H.  A tile in which some voxel's window is wider (fat objects; measured on the 512^3
+// bench volume: per-lane walks on global memory for those voxels were 0.96 of the y pass's 1.37 ms) is searched again for
+// k in (bH, (b+1)H], b = 1, 2, ...: the same code on the down-walk view of the tile H*b rows lower and the up-walk view of the
+// tile H*b rows higher, staged by the whole workgroup with coalesced row loads, the running minima kept in registers.  No
+// thread ever walks global memory on its own.
 #define KH_EDT_T 64
 
-// 128-bit mask helpers; the bit position p is wave uniform (a row index), so the shifts are by scalars and
-// the two cases of each shift are scalar branches; the data dependent part is select-only.
-__device__ __forceinline__ int zeros_down(unsigned long long lo, unsigned long long hi, int p) {
-  // number of consecutive zero bits at p, p-1, ... ; p+1 when none is set down to bit 0  (0 <= p <= 127)
-  const int s = 127 - p;  // bits p..0 moved to the top of a 128-bit word
-  unsigned long long xh, xl;
-  if (s >= 64) { xh = lo << (s - 64); xl = 0; }
-  else if (s == 0) { xh = hi; xl = lo; }
-  else { xh = (hi << s) | (lo >> (64 - s)); xl = lo << s; }
-  const int nz = xh ? __clzll((long long)xh) : 64 + (xl ? __clzll((long long)xl) : 64);
-  return min(nz, p + 1);
-}
-__device__ __forceinline__ int zeros_up(unsigned long long lo, unsigned long long hi, int p) {
-  // number of consecutive zero bits at p, p+1, ... ; 128-p when none is set up to bit 127  (0 <= p <= 128)
-  if (p >= 128) return 0;
-  unsigned long long xh, xl;
-  if (p >= 64) { xl = hi >> (p - 64); xh = 0; }
-  else if (p == 0) { xl = lo; xh = hi; }
-  else { xl = (lo >> p) | (hi << (64 - p)); xh = hi >> p; }
-  const int nz = xl ? __ffsll((long long)xl) - 1 : 64 + (xh ? __ffsll((long long)xh) - 1 : 64);
-  return min(nz, 128 - p);
-}
 // min of two floats that are known to be >= +0 (or +inf): the order of the bit patterns is the order of the values
 __device__ __forceinline__ float minpos(float a, float b) {
   return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b)));
 }
-__device__ __forceinline__ bool bit128(unsigned long long lo, unsigned long long hi, int p) {
-  return (((p < 64) ? (lo >> p) : (hi >> (p - 64))) & 1ull) != 0;
+
+template <typename T>
+__device__ __forceinline__ T ld_row(const T* __restrict__ row, uint32_t byte_off) {   // scalar row base + the lane's 32-bit byte offset
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + byte_off);
+}
+
+// CNT consecutive rows starting at position p0 of one column: f of rows p0 .. p0+CNT-1 and the labels of rows p0-1 .. p0+CNT.
+// Positions are wave uniform, so a row's address is a scalar base plus the lane's x (saddr form), and the base moves by one
+// scalar add per row.  CHECK: the rows may touch the ends of the axis.  A row outside the volume has f = `outside` and the label
+// of the nearest row inside (clamped position): it never differs from its neighbours outside, so both its views read `outside`,
+// and the flags of the first / last row inside that involve it belong to views nobody walks onto.
+template <typename LT, int CNT, bool CHECK>
+__device__ __forceinline__ void edt_load_rows(const LT* __restrict__ lab, const float* __restrict__ fin, int64_t rowbase,
+                                              int64_t astride, int n, uint32_t xc, int p0, float outside, float (&f)[CNT],
+                                              LT (&L)[CNT + 2]) {
+  const uint32_t xl = xc * (uint32_t)sizeof(LT), xf = xc * 4u;
+  if (!CHECK) {
+    const LT* __restrict__ lp = lab + rowbase + (int64_t)(p0 - 1) * astride;
+    const float* __restrict__ fp = fin + rowbase + (int64_t)p0 * astride;
+#pragma unroll
+    for (int j = 0; j < CNT + 2; j++) { L[j] = ld_row(lp, xl); lp += astride; }
+#pragma unroll
+    for (int j = 0; j < CNT; j++) { f[j] = ld_row(fp, xf); fp += astride; }
+  } else {
+    // the same walk with the label row clamped into the volume: the pointer moves only while the next row is inside
+    const LT* __restrict__ lp = lab + rowbase + (int64_t)min(max(p0 - 1, 0), n - 1) * astride;
+    const float* __restrict__ fp = fin + rowbase + (int64_t)p0 * astride;   // dereferenced for rows inside only
+#pragma unroll
+    for (int j = 0; j < CNT + 2; j++) {
+      L[j] = ld_row(lp, xl);
+      const int pn = p0 + j;
+      if (pn > 0 && pn < n) lp += astride;
+    }
+#pragma unroll
+    for (int j = 0; j < CNT; j++) {
+      const int p = p0 + j;
+      f[j] = outside;
+      if (p >= 0 && p < n) f[j] = ld_row(fp, xf);
+      fp += astride;
+    }
+  }
+}
+
+// The search of one wave's 16 output rows over the steps of one band: FOUR consecutive output rows at a time, steps in groups
+// of 4.  Output al0+q at step k+s probes Fd row (al0+H-k) + (q-s) and Fu row (al0+k) + (q+s): the 32 probes of a block-group
+// are 7 + 7 distinct rows, fetched with constant offsets from two base addresses before any is consumed -- four independent
+// minima in flight per wave instead of one chain of LDS round trips.  The loop is wave uniform and no lane is masked: a lane (or
+// row) whose bound is already crossed probes along (what it reads is >= (w*k)^2 > best and changes nothing).  (w*k)^2 comes
+// from the LDS table `tq` ([k+3] = the band's step k; broadcast reads).  All values are >= +0: min on the bit patterns.
+// Returns whether some lane's bound is still open after the band's last step.
+template <bool LAST, int H>
+__device__ __forceinline__ bool edt_search_rows(const float* __restrict__ rowd, const float* __restrict__ rowu,
+                                                const float* __restrict__ tq, float (&own)[KH_EDT_T / 4], int nrows,
+                                                float* __restrict__ orow, int64_t astride, bool xin) {
+  bool open = false;
+#pragma unroll
+  for (int jb = 0; jb < KH_EDT_T / 4; jb += 4) {
+    if (jb >= nrows) break;      // wave uniform: rows beyond the end of the axis
+    float b0 = own[jb], b1 = own[jb + 1], b2 = own[jb + 2], b3 = own[jb + 3];
+    int k = 1;           // first step not probed yet
+    float tk = tq[4];    // (w*k)^2 of that step
+    for (; k + 3 <= H; k += 4) {
+      if (!__builtin_amdgcn_ballot_w64(tk < fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)))) break;
+      const float4 t4 = *reinterpret_cast<const float4*>(&tq[k + 4]);  // steps k+1, k+2, k+3 and k+4
+      const float* __restrict__ pd = rowd + (jb - k - 3) * 64;   // D[d] = pd[(d + 3) * 64], d = q - s = -3 .. 3
+      const float* __restrict__ pu = rowu + (jb + k) * 64;       // U[u] = pu[u * 64],       u = q + s =  0 .. 6
+      const float d0 = pd[0], d1 = pd[64], d2 = pd[128], d3 = pd[192], d4 = pd[256], d5 = pd[320], d6 = pd[384];
+      const float u0 = pu[0], u1 = pu[64], u2 = pu[128], u3 = pu[192], u4 = pu[256], u5 = pu[320], u6 = pu[384];
+      // min(l + t, r + t) == min(l, r) + t bit for bit (rounding is monotone): one add per output and step
+      const float t0 = tk, t1 = t4.x, t2 = t4.y, t3 = t4.z;
+      b0 = minpos(b0, minpos(minpos(minpos(d3, u0) + t0, minpos(d2, u1) + t1), minpos(minpos(d1, u2) + t2, minpos(d0, u3) + t3)));
+      b1 = minpos(b1, minpos(minpos(minpos(d4, u1) + t0, minpos(d3, u2) + t1), minpos(minpos(d2, u3) + t2, minpos(d1, u4) + t3)));
+      b2 = minpos(b2, minpos(minpos(minpos(d5, u2) + t0, minpos(d4, u3) + t1), minpos(minpos(d3, u4) + t2, minpos(d2, u5) + t3)));
+      b3 = minpos(b3, minpos(minpos(minpos(d6, u3) + t0, minpos(d5, u4) + t1), minpos(minpos(d4, u5) + t2, minpos(d3, u6) + t3)));
+      tk = t4.w;
+    }
+    own[jb] = b0; own[jb + 1] = b1; own[jb + 2] = b2; own[jb + 3] = b3;
+    // the band is exhausted (k = H + 1, tk = its (w*k)^2) and somebody could still be improved from farther away
+    if (k + 3 > H) open = open || (tk < fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+    if (xin) {
+      float* __restrict__ op = orow + (int64_t)jb * astride;
+      op[0] = LAST ? sqrtf(b0) : b0;
+      if (jb + 1 < nrows) op[astride] = LAST ? sqrtf(b1) : b1;
+      if (jb + 2 < nrows) op[2 * astride] = LAST ? sqrtf(b2) : b2;
+      if (jb + 3 < nrows) op[3 * astride] = LAST ? sqrtf(b3) : b3;
+    }
+  }
+  return __builtin_amdgcn_ballot_w64(open) != 0;
 }
 
 template <typename LT, bool LAST, int KH_EDT_H>
 __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
-                                                       int m, int64_t ostride, float w, int black_border) {
-  constexpr int KH_EDT_ROWS = KH_EDT_T + 2 * KH_EDT_H;  // staged rows: <= 128 (column masks), multiple of 4
-  static_assert(KH_EDT_ROWS <= 128 && KH_EDT_ROWS % 4 == 0 && KH_EDT_ROWS / 4 <= 32, "tile shape");
-  __shared__ float tile[KH_EDT_ROWS * 64];
-  __shared__ unsigned int part[2][4][64];  // [label change | background][ly][lx]: ROWS/4 rows of a column mask each
-  __shared__ __attribute__((aligned(16))) float tsq[KH_EDT_ROWS + 8];  // [0] = +inf, [k+2] = (w*k)^2 for k >= 0
+                                                       int m, int64_t ostride, float w, int black_border, int chunk) {
+  constexpr int T = KH_EDT_T, H = KH_EDT_H, R = T + H, OWN = T / 4, HC = H / 2, BC = R / 8;
+  static_assert(H % 4 == 0 && T == 64 && R % 8 == 0, "tile shape");
+  __shared__ float Fd[R * 64];   // row r <-> position A0 - H + r  (A0-H .. A0+T-1): the down-walk view
+  __shared__ float Fu[R * 64];   // row r <-> position A0 + r      (A0 .. A0+T+H-1): the up-walk view
+  __shared__ __attribute__((aligned(16))) float tsq[H + 8];   // [k+3] = (w*k)^2 for k >= 0
+  __shared__ __attribute__((aligned(16))) float tsqb[H + 8];  // the same for the band being searched: [k+3] = (w*(bH+k))^2
+  __shared__ int open_epoch;   // number of the last search that ended with an open bound
   // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride ; blockDim = (64, 4)
-  const int xt = (sx + 63) >> 6, at = (n + KH_EDT_T - 1) / KH_EDT_T;
-  const int64_t ntiles = (int64_t)xt * at * m;
-  const int64_t nblk = gridDim.x;
-  const int64_t per_xcd = (nblk + 7) / 8;
-  const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int64_t stride = per_xcd * 8;
+  const int xt = (sx + 63) >> 6, at = (n + T - 1) / T;
+  const int ntiles = xt * at * m;
+  // a block owns `chunk` consecutive tiles (x fastest, then the axis); XCD c (= blockIdx.x % 8) owns a contiguous eighth of the
+  // blocks, so the halo rows two neighbouring tiles share come out of one L2
+  const int per_xcd = (int)(gridDim.x >> 3);
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  const int t0 = logical * chunk, t1 = min(t0 + chunk, ntiles);
   // blockDim = (64, 4): a wave is one row of the block, so ly is wave uniform -- say so (SGPR), which turns
-  // every row-index test and shift below into scalar code
-  const int lx = threadIdx.x, ly = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  for (int k = threadIdx.y * 64 + threadIdx.x; k < KH_EDT_ROWS + 8; k += 256) {
-    const float d = w * (float)(k - 2);
-    tsq[k] = k == 0 ? KH_INF : d * d;
+  // every row-index test below into scalar code
+  const uint32_t lx = threadIdx.x;
+  const int ly = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int k = tid; k < H + 8; k += 256) {
+    const float d = w * (float)(k - 3);
+    tsq[k] = d * d;
   }
-  for (int64_t t = logical; t < ntiles; t += stride) {
-    const int tx = (int)(t % xt);
-    const int64_t rr = t / xt;
-    const int ta = (int)(rr % at);
-    const int o = (int)(rr / at);
-    const int x = (tx << 6) + lx;
-    const int A0 = ta * KH_EDT_T;
-    const int64_t base = x + (int64_t)o * ostride;
-    __syncthreads();  // previous tile fully consumed
-    {
-      // thread (lx, ly) stages KH_EDT_ROWS / 4 consecutive rows: the label of the previous row
-      // is the previous iteration's register, so labels are read once (+1 row per thread).
-      const int rbeg = ly * (KH_EDT_ROWS / 4);
-      const int pbeg = A0 - KH_EDT_H + rbeg;
-      LT Lp = 0;
-      if (x < sx && pbeg - 1 >= 0 && pbeg - 1 < n) Lp = lab[base + (int64_t)(pbeg - 1) * astride];
-      unsigned int cm = 0, bm = 0;
-#ifndef KH_EDT_STAGE_UNROLL
-#define KH_EDT_STAGE_UNROLL 4
-#endif
-#pragma unroll KH_EDT_STAGE_UNROLL
-      for (int j = 0; j < KH_EDT_ROWS / 4; j++) {
-        const int pos = pbeg + j;
-        const bool valid = x < sx && pos >= 0 && pos < n;
-        float v = KH_INF;
-        LT L = 0;
-        if (valid) {
-          const int64_t q = base + (int64_t)pos * astride;
-          v = fin[q];
-          L = lab[q];
-        }
-        tile[(rbeg + j) * 64 + lx] = v;
-        // a row outside the volume, or the first row of the volume, or a label change, ends every run
-        const bool chg = !valid || pos == 0 || L != Lp;
-        const bool bg = !valid || L == 0;
-        cm |= (chg ? 1u : 0u) << j;
-        bm |= (bg ? 1u : 0u) << j;
-        Lp = L;
-      }
-      part[0][ly][lx] = cm;
-      part[1][ly][lx] = bm;
+  if (tid == 0) open_epoch = 0;
+  if (t0 >= t1) return;
+  const float outside = black_border ? 0.0f : KH_INF;
+  // The block visits its tiles in an order rotated by its own number, so that blocks which start together are not all at the
+  // same x offset at the same time.
+  const int cnt = t1 - t0, rot = logical % cnt;
+  int tcur = t0 + rot;
+  int tx = tcur % xt, ta = (tcur / xt) % at, o = tcur / (xt * at);
+  // the rows this thread stages for a tile: its wave's 16 output rows and a quarter of the halo (waves 0, 1 below the tile, 2, 3
+  // above it).  They are requested one tile ahead, before the search of the current tile, and consumed after it.
+  float nown[OWN], nhal[HC];
+  LT nLo[OWN + 2], nLh[HC + 2];
+  const int hrow = (ly * HC < H) ? ly * HC - H : T + ly * HC - H;   // first halo row of this wave relative to A0
+  auto request = [&](int qx, int qa, int qo) {
+    const uint32_t xc = min((uint32_t)((qx << 6) + lx), (uint32_t)(sx - 1));
+    const int A0 = qa * T;
+    const int64_t rowbase = (int64_t)qo * ostride;
+    if (A0 - H - 1 >= 0 && A0 + T + H + 1 <= n) {
+      edt_load_rows<LT, OWN, false>(lab, fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown, nLo);
+      edt_load_rows<LT, HC, false>(lab, fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal, nLh);
+    } else {
+      edt_load_rows<LT, OWN, true>(lab, fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown, nLo);
+      edt_load_rows<LT, HC, true>(lab, fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal, nLh);
+    }
+  };
+  request(tx, ta, o);
+  const float* __restrict__ rowd = &Fd[(OWN * ly + H) * 64 + lx];
+  const float* __restrict__ rowu = &Fu[(OWN * ly) * 64 + lx];
+  int epoch = 0;
+  __syncthreads();   // the table and open_epoch
+  for (int it = 0; it < cnt; it++) {
+    const int x = (tx << 6) + (int)lx;
+    const uint32_t xc = (uint32_t)min(x, sx - 1);
+    const int A0 = ta * T;
+    const int64_t rowbase = (int64_t)o * ostride;
+    const int nrows = min(OWN, n - (A0 + OWN * ly));   // this wave's output rows inside the axis (<= 0: none)
+    float own[OWN];
+    // the two views: a row reads 0 for a walker that crosses a label change onto it.  (The previous tile's last search ended
+    // with a barrier.)
+#pragma unroll
+    for (int j = 0; j < HC; j++) {
+      if (hrow < 0) Fd[(H + hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j + 2]) ? 0.0f : nhal[j];
+      else Fu[(hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j]) ? 0.0f : nhal[j];
+    }
+#pragma unroll
+    for (int j = 0; j < OWN; j++) {
+      own[j] = (j < nrows) ? nown[j] : 0.0f;   // rows beyond the axis: nothing to search, never "open"
+      Fd[(H + OWN * ly + j) * 64 + lx] = (nLo[j + 1] != nLo[j + 2]) ? 0.0f : nown[j];
+      Fu[(OWN * ly + j) * 64 + lx] = (nLo[j + 1] != nLo[j]) ? 0.0f : nown[j];
     }
     __syncthreads();
-    if (x >= sx) continue;
-    // thread ly contributed rows [RPT*ly, RPT*ly + RPT) of the column masks
-    constexpr int RPT = KH_EDT_ROWS / 4;
-    unsigned __int128 cmask = 0, bmask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      cmask |= (unsigned __int128)part[0][j][lx] << (j * RPT);
-      bmask |= (unsigned __int128)part[1][j][lx] << (j * RPT);
+    {
+      tcur = (tcur + 1 == t1) ? t0 : tcur + 1;
+      const int qx = tcur % xt, qa = (tcur / xt) % at, qo = tcur / (xt * at);
+      if (it + 1 < cnt) request(qx, qa, qo);
+      tx = qx; ta = qa; o = qo;
     }
-    const unsigned long long c_lo = (unsigned long long)cmask, c_hi = (unsigned long long)(cmask >> 64);
-    const unsigned long long b_lo = (unsigned long long)bmask, b_hi = (unsigned long long)(bmask >> 64);
-    for (int al = ly; al < KH_EDT_T; al += 4) {
-      const int a = A0 + al;
-      if (a >= n) break;
-      const int r0 = al + KH_EDT_H;  // my row in the tile (wave uniform)
-      const int64_t i = base + (int64_t)a * astride;
-      float best = 0.0f;
-      if (!bit128(b_lo, b_hi, r0)) {
-        const float* __restrict__ pc = &tile[r0 * 64 + lx];
-        best = pc[0];
-        // same-label rows below / above inside the staged rows
-        int nl = zeros_down(c_lo, c_hi, r0);
-        int nr = zeros_up(c_lo, c_hi, r0 + 1);
-        const bool lunk = nl > r0;                     // no change found down to the first staged row
-        const bool runk = r0 + 1 + nr >= KH_EDT_ROWS;  // none up to the last staged row
-        nl = min(nl, r0);
-        nr = min(nr, KH_EDT_ROWS - 1 - r0);
-        // a segment end that is known here is a candidate: a differing voxel, or the volume border when
-        // black_border.  (Rows outside the volume are staged as +inf, so probing them is harmless.)
-        const bool lc = !lunk && (a - nl - 1 >= 0 || black_border);
-        const bool rc = !runk && (a + nr + 1 < n || black_border);
-        const float tl = tsq[lc ? nl + 3 : 0], tr = tsq[rc ? nr + 3 : 0];   // tsq[0] = +inf, tsq[k+2] = (w*k)^2
-        best = minpos(best, minpos(tl, tr));
-        // Both sides are probed together for k <= kb.  A side that ended in a candidate needs nothing beyond
-        // its end: the candidate (w*(end+1))^2 already bounds everything farther away.  A side without one
-        // (volume border, or a run leaving the staged rows) is probed up to the edge of the staged rows.
-        const int kb = min(lc ? nl : r0, rc ? nr : KH_EDT_ROWS - 1 - r0);
-        // Groups of 4 steps, run as a wave-uniform loop (k is a scalar): a lane takes part while its next 4 rows
-        // are inside kb and (w*k)^2 < best.  (w*k)^2 comes from the LDS table (broadcast reads), the 8 probes are
-        // fetched with constant offsets from one base address before any is consumed, no clamps, no per-step
-        // branches.  A probe farther than the bound cannot lower `best` (f >= 0), so nothing has to be undone
-        // when the bound is crossed inside a group.  All values are >= +0, so min is taken on the bit patterns.
-        int kn = 1;  // first step this lane has not probed yet
-        float tx = tsq[3];  // (w*k)^2 of the group's first step; the next group's arrives with this group's reads
-        for (int k = 1;; k += 4) {
-          const bool can = (k + 3 <= kb) && (tx < best);  // once false it stays false
-          if (!__builtin_amdgcn_ballot_w64(can)) break;
-          if (can) {
-            const float4 t = *reinterpret_cast<const float4*>(&tsq[k + 3]);  // steps k+1, k+2, k+3 and k+4
-            const float* __restrict__ pl = pc - k * 64;
-            const float* __restrict__ pr = pc + k * 64;
-            const float l0 = pl[0], l1 = pl[-64], l2 = pl[-128], l3 = pl[-192];
-            const float r0v = pr[0], r1 = pr[64], r2 = pr[128], r3 = pr[192];
-            // min(l + t, r + t) == min(l, r) + t bit for bit (rounding is monotone): one add per step
-            best = minpos(best, minpos(minpos(l0, r0v) + tx, minpos(l1, r1) + t.x));
-            best = minpos(best, minpos(minpos(l2, r2) + t.y, minpos(l3, r3) + t.z));
-            tx = t.w;
-            kn = k + 4;
-          }
-        }
-        // at most 3 steps are left below kb for a lane that was stopped by kb (a lane stopped by the bound gains
-        // nothing from them, and loses nothing)
+    float* __restrict__ orow = fout + rowbase + (int64_t)(A0 + OWN * ly) * astride + xc;
+    epoch++;
+    if (edt_search_rows<LAST, H>(rowd, rowu, tsq, own, nrows, orow, astride, x < sx) && lx == 0) open_epoch = epoch;
+    for (int b = 1;; b++) {
+      __syncthreads();   // every wave's search is done (the views may be rewritten) and its open mark is visible
+      if (open_epoch != epoch) break;
+      const int AD = A0 - b * H, AU = A0 + b * H;     // origins of the band's two views
+      if (AD + T - 1 < 0 && AU >= n && !black_border) break;   // nothing but +inf out there (with black_border the zeros stop everybody)
+      // wave ly stages rows [ly R/4, (ly+1) R/4) of either view, R/8 rows per round trip
+#pragma unroll 1
+      for (int c = 0; c < 4; c++) {
+        const int r0 = ly * (R / 4) + (c & 1) * BC;
+        float f[BC];
+        LT L[BC + 2];
+        if (c < 2) {
+          edt_load_rows<LT, BC, true>(lab, fin, rowbase, astride, n, xc, AD - H + r0, outside, f, L);
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const int kq = kn + j;
-          if (kq <= kb) best = minpos(best, minpos(pc[-kq * 64], pc[kq * 64]) + tsq[kq + 2]);
+          for (int j = 0; j < BC; j++) Fd[(r0 + j) * 64 + lx] = (L[j + 1] != L[j + 2]) ? 0.0f : f[j];
+        } else {
+          edt_load_rows<LT, BC, true>(lab, fin, rowbase, astride, n, xc, AU + r0, outside, f, L);
+#pragma unroll
+          for (int j = 0; j < BC; j++) Fu[(r0 + j) * 64 + lx] = (L[j + 1] != L[j]) ? 0.0f : f[j];
         }
-        const bool open = tsq[kb + 3] < best;  // would step kb + 1 still be inside the bound?
-        int k = kb + 1;
-        if (open && !(lc && rc)) {
-          // rare: one side has no end inside the staged rows (objects wider than H voxels) or ends at the volume
-          // border.  Keep walking: staged rows first, then global memory with the labels checked.
-          const LT L = lab[i];
-          bool lo = lunk, ro = runk;
-          for (;; k++) {
-            const bool lin = k <= nl, rin = k <= nr;
-            if (!(lin || rin || lo || ro)) break;
-            const float d = w * (float)k;
-            const float tt = d * d;
-            if (tt >= best) break;
-            if (lin) best = fminf(best, pc[-k * 64] + tt);
-            else if (lo) {
-              const int j = a - k;
-              if (j < 0) { lo = false; if (black_border) best = tt; }
-              else {
-                const int64_t q = base + (int64_t)j * astride;
-                if (lab[q] != L) { lo = false; best = tt; }
-                else best = fminf(best, fin[q] + tt);
-              }
-            }
-            if (rin) best = fminf(best, pc[k * 64] + tt);
-            else if (ro) {
-              const int j = a + k;
-              if (j >= n) { ro = false; if (black_border) best = fminf(best, tt); }
-              else {
-                const int64_t q = base + (int64_t)j * astride;
-                if (lab[q] != L) { ro = false; best = fminf(best, tt); }
-                else best = fminf(best, fin[q] + tt);
-              }
-            }
-          }
-        }
-        if (LAST) best = sqrtf(best);
       }
-      fout[i] = best;
+      for (int k = tid; k < H + 8; k += 256) {
+        const float d = w * (float)(b * H + k - 3);
+        tsqb[k] = d * d;
+      }
+      __syncthreads();
+      epoch++;
+      if (edt_search_rows<LAST, H>(rowd, rowu, tsqb, own, nrows, orow, astride, x < sx) && lx == 0) open_epoch = epoch;
     }
   }
 }
@@ -456,20 +477,24 @@ static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz,
   }
   auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last) -> int {
     const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + KH_EDT_T - 1) / KH_EDT_T) * m;
-    int64_t grid = ntiles < 16384 ? ntiles : 16384;
+    // a block walks `chunk` consecutive tiles, requesting a tile's rows while it searches the one before: 8 tiles per block
+    // keeps thousands of blocks for the hardware to balance (a persistent grid would depend on the occupancy it assumes)
+    const int chunk = ntiles >= 8 * 2048 ? 8 : (ntiles >= 2048 ? (int)(ntiles / 2048) : 1);
+    int64_t grid = (ntiles + chunk - 1) / chunk;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];
     float* fout = bufs[cur ^ 1];
-    // halo: a search needs k <= sqrt(best)/w rows either side, so the axis with the coarse voxel pitch gets the small halo
-    // (less re-reading); anything that does not fit continues on global memory, so this only affects speed.  Measured on
-    // the 512^3 bench volume, fine axis: H = 8 / 12 / 16 / 20 / 24 / 28 / 32 -> 1.18 / 1.10 / 1.12 / 1.06 / 1.05 / 1.24 / 1.23 ms;
-    // coarse axis: H = 8 / 12 -> 0.62 / 0.69 ms
-    const float wmin = fminf(wx, fminf(wy, wz));
-    const bool small_halo = w >= 2.0f * wmin;
+    // halo: H = 24 rows on every axis.  Measured on the 512^3 bench volume (anisotropy 16, 16, 40), y / z pass in ms with
+    // H = 8, 16, 24, 32, 40, 56: y - / 0.79 / 0.63 / 0.71 / 0.78 / 0.82, z 0.48 / 0.37 / 0.38 / 0.50 / - / -: a small halo sends
+    // more tiles into a second band, a large one costs staging and occupancy.  KH_EDT_H = 8 | 24 | 40: developer knob (A/B runs).
+    int hsel = 24;
+    if (const char* e = getenv("KH_EDT_H")) hsel = atoi(e);
 #define KH_AXIS_LAUNCH(LASTV, HV) hipLaunchKernelGGL((edt_axis_kernel<LT, LASTV, HV>), dim3((unsigned)grid), dim3(64, 4), 0, st, \
-                                                     lab, fin, fout, (int)sx, n, astride, m, ostride, w, black_border)
-    if (last) { if (small_halo) KH_AXIS_LAUNCH(true, 8); else KH_AXIS_LAUNCH(true, 24); }
-    else { if (small_halo) KH_AXIS_LAUNCH(false, 8); else KH_AXIS_LAUNCH(false, 24); }
+                                                     lab, fin, fout, (int)sx, n, astride, m, ostride, w, black_border, chunk)
+#define KH_AXIS_PICK(LASTV) do { if (hsel <= 8) KH_AXIS_LAUNCH(LASTV, 8); else if (hsel <= 24) KH_AXIS_LAUNCH(LASTV, 24); \
+                                 else KH_AXIS_LAUNCH(LASTV, 40); } while (0)
+    if (last) KH_AXIS_PICK(true); else KH_AXIS_PICK(false);
+#undef KH_AXIS_PICK
 #undef KH_AXIS_LAUNCH
     KH_LAUNCH_CHECK();
     cur ^= 1;

@@ -29,7 +29,8 @@ CASES = [
     ((31, 1, 1), 3, (2, 2, 2), np.uint32),            # 1-D
     ((50, 60, 1), 6, (1, 2, 1), np.uint32),           # 2-D
     ((90, 120, 40), 20, (2, 9, 3), np.uint32),        # coarse y: the small-halo kernel on a non-final pass
-    ((96, 150, 140), 2, (1, 1, 1), np.uint32),        # runs far longer than any halo: global-memory walk
+    ((96, 150, 140), 2, (1, 1, 1), np.uint32),        # runs far longer than any halo: several bands per tile
+    ((70, 210, 150), 1, (1, 2, 1), np.uint16),        # one label: bands three and more deep, partial tiles on every axis
     ((1100, 7, 3), 9, (2, 3, 5), np.uint16),          # rows longer than the x pass keeps in registers (8 x 64 voxels)
 ]
 
@@ -57,6 +58,20 @@ def test_edt_solid_black_border(eng):
     want = oracle.edt(lab, (16, 16, 40), True)
     np.testing.assert_array_equal(got, want)
     assert got.max() > 0 and np.isfinite(got).all()
+
+
+def test_edt_solid_without_border_is_infinite(eng):
+    """no label change and no border anywhere: every band of every tile runs off the volume, the result is +inf (oracle)"""
+    import oracle
+    lab = np.full((70, 130, 90), 3, dtype=np.uint16, order="F")
+    got = gpu_edt(eng, lab, (16, 16, 40), False)
+    want = oracle.edt(lab, (16, 16, 40), False)
+    np.testing.assert_array_equal(got, want)
+    assert np.isinf(got).all()
+    lab[10, 100, 80] = 0      # one hole: finite everywhere, windows as wide as the volume
+    got = gpu_edt(eng, lab, (16, 16, 40), False)
+    np.testing.assert_array_equal(got, oracle.edt(lab, (16, 16, 40), False))
+    assert np.isfinite(got).all()
 
 
 def test_edt_single_label_matches_scipy(eng):

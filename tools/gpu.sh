@@ -13,6 +13,8 @@
 #   kstats:<name>[:ENV=V,...]    rocprofv3 --kernel-trace --stats of one bench step
 #   ktrace:<name>:<bench args>[:ENV]   rocprofv3 --kernel-trace of a bench call, summarised as a timeline (tools/summarize_timeline.py)
 #   probe:<name>:<threads>:LIB=<probe build>   per-phase cycles of the sweep's level loop (-DKH_SWEEP_PROBE build)
+#   edt:<name>[:ENV=V,...]       the three EDT passes timed on the c3 volume (tools/edt_time.py)
+#   edtpmc:<name>[:ENV=V,...]    SQ counter passes of the EDT kernels (tools/summarize_edt_pmc.py)
 #   smoke                        __graft_entry__.smoke()
 # ENV: e.g. LIB=build_variants/libkimi_base.so (another build of the library, loaded through KIMI_HIP_LIB), KH_TRACE_THREADS=64
 set -u
@@ -102,6 +104,20 @@ for STEP in "$@"; do
       ( envs "${A3:-}"; KH_TRACE_THREADS=${A2:-64} timeout 600 python tools/trace_only.py c3 > $OUT/probe_$A1.txt 2>&1 )
       grep TRACEONLY $OUT/probe_$A1.txt
       python tools/summarize_probe.py $OUT/probe_$A1.txt ;;
+    edt)     # edt:<name>[:ENV]   the three EDT passes on the c3 volume (tools/edt_time.py: kh_edt_timed, HIP events on the launch stream)
+      ( envs "${A2:-}"; timeout 600 python tools/edt_time.py c3 > $OUT/edt_$A1.txt 2>&1 )
+      grep EDTTIME $OUT/edt_$A1.txt || tail -5 $OUT/edt_$A1.txt ;;
+    edtpmc)  # edtpmc:<name>[:ENV]   SQ counter passes of the EDT kernels on the c3 volume (tools/edt_only.py)
+      mkdir -p $OUT/edtpmc_$A1
+      ( envs "${A2:-}"; cd /tmp && export TMPDIR=/tmp; i=0
+        for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+                   "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+          i=$((i+1))
+          timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/edtpmc_$A1/pass_$i -o pmc -- \
+            python $REPO/tools/edt_only.py c3 > $OUT/edtpmc_$A1/pass_$i.log 2>&1
+          echo "pass $i: rc=$?"
+        done )
+      python tools/summarize_edt_pmc.py $OUT/edtpmc_$A1 ;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     *) echo "unknown step $STEP" ;;
