@@ -477,9 +477,12 @@ static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz,
   }
   auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last) -> int {
     const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + KH_EDT_T - 1) / KH_EDT_T) * m;
-    // a block walks `chunk` consecutive tiles, requesting a tile's rows while it searches the one before: 8 tiles per block
-    // keeps thousands of blocks for the hardware to balance (a persistent grid would depend on the occupancy it assumes)
-    const int chunk = ntiles >= 8 * 2048 ? 8 : (ntiles >= 2048 ? (int)(ntiles / 2048) : 1);
+    // a block walks `chunk` consecutive tiles, requesting a tile's rows while it searches the one before.  Four tiles per block:
+    // thousands of blocks for the hardware to balance (a persistent grid would depend on the occupancy it assumes), and a block
+    // whose tiles need extra bands (fat objects cluster) holds the tail of the launch up less: y pass 0.67 / 0.62 / 0.58 / 0.57 ms
+    // with 16 / 8 / 4 / 2 tiles per block on the 512^3 bench volume.  KH_EDT_CHUNK: developer knob (A/B runs).
+    int chunk = ntiles >= 4 * 2048 ? 4 : (ntiles >= 2048 ? (int)(ntiles / 2048) : 1);
+    if (const char* e = getenv("KH_EDT_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
     int64_t grid = (ntiles + chunk - 1) / chunk;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];

@@ -22,6 +22,7 @@ import time
 
 LANE_THREADS = 64     # threads per label of a lane's path loop (Engine.trace_threads): one wave, twelve labels per CU
 LANE_EDF_THREADS = 128   # threads per label of a lane's distance-field searches (Engine.edf_threads)
+LANE_SWITCH_INTERVAL = 0.0005   # seconds: sys.setswitchinterval while several lanes run (Python's default is 0.005)
 LANE_WINDOW_CAP = 2048   # level words per label in LDS (Engine.window_cap): 11.5 KB per workgroup, so that twelve fit a CU's 160 KB
 
 
@@ -214,6 +215,14 @@ class Lanes:
         threads = [threading.Thread(target=worker, args=(self.engines[i], self._scopes[i], i * float(stagger)), daemon=True)
                    for i in range(min(width, n))]
         alive[0] = len(threads)
+        # A lane's thread gives the GIL up at every GPU wait and needs it back afterwards; with CPython's default switch interval
+        # (5 ms) it then stands behind whichever lane is running Python, and a preamble with some twenty such waits per volume
+        # turns into a convoy.  A short interval hands the GIL over quickly (KH_SWITCH_INTERVAL seconds; 0 keeps Python's value).
+        import sys
+        old_interval = sys.getswitchinterval()
+        want_interval = float(os.environ.get("KH_SWITCH_INTERVAL", LANE_SWITCH_INTERVAL))
+        if want_interval > 0 and len(threads) > 1:
+            sys.setswitchinterval(want_interval)
         for th in threads:
             th.start()
         try:
@@ -230,6 +239,7 @@ class Lanes:
                 gate.abort()
             for th in threads:
                 th.join()
+            sys.setswitchinterval(old_interval)
 
 
 def _set_gate(eng, gate, k):
