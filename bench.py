@@ -593,7 +593,7 @@ def main():
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     # runs, gfx950 x2 FETCH correction calibrated on the x pass): the newest profiles/rNN_c3_edt_pmc.json.  Only valid for c3.
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_c3_edt_pmc.json", "r05_c3_edt_pmc.json", "r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06c_c3_edt_pmc.json", "r06_c3_edt_pmc.json", "r05_c3_edt_pmc.json", "r04_c3_edt_pmc.json", "r02_c3_edt_pmc.json"))
                 if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(pmc):
         kern = json.load(open(pmc))["kernels"]
@@ -605,7 +605,7 @@ def main():
     roofline_edt = {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": "profiles/%s (rocprofv3 --pmc passes of tools/edt_only.py on the same volume%s; not live)"
-                                  % (os.path.basename(pmc), "" if ("r05_" in pmc or "r06_" in pmc) else "; STALE: measured before round 5's x pass") if traffic else None,
+                                  % (os.path.basename(pmc), "" if ("r06c_" in pmc) else "; STALE: measured on the round-5 y / z kernels" if ("r05_" in pmc or "r06_" in pmc) else "; STALE: measured before round 5's x pass") if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
                 "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
@@ -637,14 +637,14 @@ def main():
     # HBM traffic of that kernel from the committed counter passes (tools/pmc_trace_r3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs over one c3 volume, FETCH x 2 on gfx950): only valid for c3
     tr_traffic, tr_src = None, None
-    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_c3_trace_pmc.json", "r05_c3_trace_pmc.json",
+    tpmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06c_c3_trace_pmc.json", "r06_c3_trace_pmc.json", "r05_c3_trace_pmc.json",
                                                                          "r04_c3_trace_pmc.json")) if os.path.exists(q)), "")
     if args.workload == "c3" and os.path.exists(tpmc):
         for name, v in json.load(open(tpmc))["kernels"].items():
             if "trace_paths_kernel" in name and v.get("hbm_bytes_corrected_per_volume"):
                 # (the volume's launches -- the largest labels as a kernel variant of their own -- added up)
                 tr_traffic = (tr_traffic or 0.0) + v["hbm_bytes_corrected_per_volume"]
-                stale = "" if "r06_" in os.path.basename(tpmc) else "; STALE: measured on an earlier round's kernels"
+                stale = "" if ("r06_" in os.path.basename(tpmc) or "r06c_" in os.path.basename(tpmc)) else "; STALE: measured on an earlier round's kernels"
                 tr_src = ("profiles/%s (rocprofv3 --pmc passes over one volume, all path-kernel launches of the volume; not live%s)"
                           % (os.path.basename(tpmc), stale))
     # the dominant kernel (97 % of the GPU time): its launches of ONE volume overlap on two streams (the largest labels on the

@@ -334,8 +334,9 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
   // volume seen as [sx][n along axis][m others]: index = x + a*astride + o*ostride ; blockDim = (64, 4)
   const int xt = (sx + 63) >> 6, at = (n + T - 1) / T;
   const int ntiles = xt * at * m;
-  // a block owns `chunk` consecutive tiles (x fastest, then the axis); XCD c (= blockIdx.x % 8) owns a contiguous eighth of the
-  // blocks, so the halo rows two neighbouring tiles share come out of one L2
+  // a block owns `chunk` consecutive tiles, consecutive ALONG THE AXIS first (then x, then the other axis): a tile's lower halo and
+  // the rows under it were staged by the same block one tile earlier and come out of the L2; XCD c (= blockIdx.x % 8) owns a
+  // contiguous eighth of the blocks
   const int per_xcd = (int)(gridDim.x >> 3);
   const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   const int t0 = logical * chunk, t1 = min(t0 + chunk, ntiles);
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
   // same x offset at the same time.
   const int cnt = t1 - t0, rot = logical % cnt;
   int tcur = t0 + rot;
-  int tx = tcur % xt, ta = (tcur / xt) % at, o = tcur / (xt * at);
+  int ta = tcur % at, tx = (tcur / at) % xt, o = tcur / (xt * at);
   // the rows this thread stages for a tile: its wave's 16 output rows and a quarter of the halo (waves 0, 1 below the tile, 2, 3
   // above it).  They are requested one tile ahead, before the search of the current tile, and consumed after it.
   float nown[OWN], nhal[HC];
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
     __syncthreads();
     {
       tcur = (tcur + 1 == t1) ? t0 : tcur + 1;
-      const int qx = tcur % xt, qa = (tcur / xt) % at, qo = tcur / (xt * at);
+      const int qa = tcur % at, qx = (tcur / at) % xt, qo = tcur / (xt * at);
       if (it + 1 < cnt) request(qx, qa, qo);
       tx = qx; ta = qa; o = qo;
     }
