@@ -67,7 +67,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (shape, chains, points per chain, seed, anisotropy)
-    "c1": ((64, 64, 64), 8, 4, 1, (1, 1, 1)),
+    "c1": ((64, 64, 64), 8, 0, 1, (1, 1, 1)),         # eight balls on background (make_balls), not a tessellation
     "c2": ((512, 512, 100), 333, 12, 2, (16, 16, 40)),
     "c3": ((512, 512, 512), 2124, 16, 3, (16, 16, 40)),
     "c5": ((1024, 1024, 1024), 8192, 24, 5, (8, 8, 40)),
@@ -91,10 +91,12 @@ def make_volume(name):
         path = os.path.join(cache, "%s_seed%d.npy" % (name, seed))
         if os.path.exists(path):
             return np.asfortranarray(np.load(path)), an
+    if name == "c1":
+        return make_balls(shape, nchains, seed), an
     rng = np.random.default_rng(seed)
     anf = np.asarray(an, dtype=np.float64)
     shp = np.asarray(shape, dtype=np.float64)
-    step = np.array([24.0, 24.0, 24.0 * anf[0] / anf[2]]) if name != "c1" else np.array([10.0, 10.0, 10.0])
+    step = np.array([24.0, 24.0, 24.0 * anf[0] / anf[2]])
     pts, owner = [], []
     for l in range(nchains):
         p = rng.uniform(0, 1, 3) * shp
@@ -126,6 +128,26 @@ def make_volume(name):
         os.makedirs(cache, exist_ok=True)
         np.save(path, lab)
     return lab, an
+
+
+def make_balls(shape, nballs, seed):
+    """`nballs` balls of radius U(9, 14) voxels on background 0, centres rejection-sampled at least 2 voxels
+    apart (a later ball overwrites an earlier one where they overlap), label ids 1000 + perm(i); u32, F order."""
+    rng = np.random.default_rng(seed)
+    shp = np.asarray(shape, dtype=np.float64)
+    lab = np.zeros(shape, dtype=np.uint32, order="F")
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), -1).astype(np.float64)
+    ids = (1000 + rng.permutation(nballs)).astype(np.uint32)
+    centres = []
+    for i in range(nballs):
+        r = rng.uniform(9.0, 14.0)
+        while True:
+            c = rng.uniform(0, 1, 3) * (shp - 1)
+            if all(np.linalg.norm(c - o) >= 2.0 for o in centres):
+                break
+        centres.append(c)
+        lab[((g - c) ** 2).sum(-1) <= r * r] = ids[i]
+    return lab
 
 
 def cpu_baseline(cc_labels, remapping, an, params, dust_threshold, budget_s=15.0):

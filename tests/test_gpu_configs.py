@@ -70,6 +70,24 @@ def test_shard_small_volume_two_and_three_ranks(eng):
             _same(got[k], want[k], k)
 
 
+def test_c1_eight_balls_every_skeleton(eng):
+    """BASELINE configs[0] as SURVEY 8d writes it: 64^3 u32, eight balls of radius 9-14 on background, anisotropy (1, 1, 1) --
+    bench.make_volume("c1") -- through kimimaro_amd.skeletonize against the oracle pipeline, every skeleton."""
+    import bench
+    import kimimaro_amd
+    from oracle import pipeline as P
+    lab, an = bench.make_volume("c1")
+    assert lab.shape == (64, 64, 64) and lab.dtype == np.uint32 and (lab == 0).any() and 2 <= len(np.unique(lab)) - 1 <= 8
+    params = dict(kimimaro_amd.DEFAULT_TEASAR_PARAMS)
+    for dust in (1000, 100):
+        want = P.skeletonize(lab, params, anisotropy=an, dust_threshold=dust, fix_borders=True, fix_branching=True)
+        got = kimimaro_amd.skeletonize(lab, params, anisotropy=an, dust_threshold=dust, fix_borders=True, fix_branching=True,
+                                       progress=False, _engine=eng)
+        assert sorted(got) == sorted(want) and len(want) >= 2
+        for k in want:
+            _same(got[k], want[k], k)
+
+
 @pytest.fixture(scope="module")
 def c2():
     import bench
