@@ -51,6 +51,21 @@ def test_edt_multilabel_bit_exact(eng, shape, nlab, an, dtype, black_border):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("knobs", [{"KH_EDT_H": "8"}, {"KH_EDT_H": "40"}, {"KH_EDT_CHUNK": "1"}, {"KH_EDT_CHUNK": "16"},
+                                   {"KH_EDT_H": "8", "KH_EDT_CHUNK": "3"}])
+def test_edt_developer_knobs_do_not_change_the_result(eng, knobs, monkeypatch):
+    """the other halo instances of edt_axis_kernel (8 and 40 rows: more / fewer bands per tile) and other numbers of tiles per block
+    (the knobs of csrc/edt.hip's edt_impl, read at every call) give the same bits as the oracle"""
+    import oracle
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for shape, nlab, an, bb in (((96, 150, 140), 2, (1, 1, 1), False), ((70, 133, 90), 9, (16, 16, 40), True)):
+        lab = voronoi_labels(shape, nlab, seed=sum(shape), anisotropy=(1, 1, 1), dtype=np.uint32).astype(np.uint16)
+        lab[np.random.default_rng(3).random(shape) < 0.03] = 0
+        lab = np.asfortranarray(lab)
+        np.testing.assert_array_equal(gpu_edt(eng, lab, an, bb), oracle.edt(lab, an, bb))
+
+
 def test_edt_solid_black_border(eng):
     import oracle
     lab = np.ones((40, 50, 30), dtype=np.uint32, order="F")
