@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ 
 // BANDS.  The staged rows serve steps k <= H.  A tile in which some voxel's window is wider (fat objects; measured on the 512^3
 // bench volume: per-lane walks on global memory for those voxels were 0.96 of the y pass's 1.37 ms) is searched again for
 // k in (bH, (b+1)H], b = 1, 2, ...: the same code on the down-walk view of the tile H*b rows lower and the up-walk view of the
-// tile H*b rows higher, staged by the whole workgroup with coalesced row loads, the running minima kept in registers.  No
-// thread ever walks global memory on its own.
+// tile H*b rows higher -- the previous band's views moved by H rows inside the LDS plus H new rows each, loaded by the whole
+// workgroup with coalesced row loads -- the running minima kept in registers.  No thread ever walks global memory on its own.
 #define KH_EDT_T 64
 
 // min of two floats that are known to be >= +0 (or +inf): the order of the bit patterns is the order of the values
@@ -324,8 +324,8 @@ template <typename LT, bool LAST, int KH_EDT_H>
 __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border, int chunk) {
-  constexpr int T = KH_EDT_T, H = KH_EDT_H, R = T + H, OWN = T / 4, HC = H / 2, BC = R / 8;
-  static_assert(H % 4 == 0 && T == 64 && R % 8 == 0, "tile shape");
+  constexpr int T = KH_EDT_T, H = KH_EDT_H, R = T + H, OWN = T / 4, HC = H / 2, HQ = H / 4;
+  static_assert(H % 4 == 0 && T == 64, "tile shape");
   __shared__ float Fd[R * 64];   // row r <-> position A0 - H + r  (A0-H .. A0+T-1): the down-walk view
   __shared__ float Fu[R * 64];   // row r <-> position A0 + r      (A0 .. A0+T+H-1): the up-walk view
   __shared__ __attribute__((aligned(16))) float tsq[H + 8];   // [k+3] = (w*k)^2 for k >= 0
@@ -414,21 +414,33 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
       if (open_epoch != epoch) break;
       const int AD = A0 - b * H, AU = A0 + b * H;     // origins of the band's two views
       if (AD + T - 1 < 0 && AU >= n && !black_border) break;   // nothing but +inf out there (with black_border the zeros stop everybody)
-      // wave ly stages rows [ly R/4, (ly+1) R/4) of either view, R/8 rows per round trip
-#pragma unroll 1
-      for (int c = 0; c < 4; c++) {
-        const int r0 = ly * (R / 4) + (c & 1) * BC;
-        float f[BC];
-        LT L[BC + 2];
-        if (c < 2) {
-          edt_load_rows<LT, BC, true>(lab, fin, rowbase, astride, n, xc, AD - H + r0, outside, f, L);
+      // The band's down-walk view is the previous band's moved H rows up plus H new rows at its lower end, the up-walk view the
+      // previous one moved H rows down plus H new rows at its upper end (a view's value belongs to its row alone): T rows of
+      // either view move inside the LDS (read, barrier, write: the ranges overlap), and a wave loads H / 4 new rows per view
+      // in one round trip instead of a quarter of the whole view in two.
+      {
+        float mv[OWN], f[HQ];
+        LT L[HQ + 2];
 #pragma unroll
-          for (int j = 0; j < BC; j++) Fd[(r0 + j) * 64 + lx] = (L[j + 1] != L[j + 2]) ? 0.0f : f[j];
-        } else {
-          edt_load_rows<LT, BC, true>(lab, fin, rowbase, astride, n, xc, AU + r0, outside, f, L);
+        for (int j = 0; j < OWN; j++) mv[j] = Fd[(OWN * ly + j) * 64 + lx];
+        edt_load_rows<LT, HQ, true>(lab, fin, rowbase, astride, n, xc, AD - H + HQ * ly, outside, f, L);
+        __syncthreads();
 #pragma unroll
-          for (int j = 0; j < BC; j++) Fu[(r0 + j) * 64 + lx] = (L[j + 1] != L[j]) ? 0.0f : f[j];
-        }
+        for (int j = 0; j < OWN; j++) Fd[(H + OWN * ly + j) * 64 + lx] = mv[j];
+#pragma unroll
+        for (int j = 0; j < HQ; j++) Fd[(HQ * ly + j) * 64 + lx] = (L[j + 1] != L[j + 2]) ? 0.0f : f[j];
+      }
+      {
+        float mv[OWN], f[HQ];
+        LT L[HQ + 2];
+#pragma unroll
+        for (int j = 0; j < OWN; j++) mv[j] = Fu[(H + OWN * ly + j) * 64 + lx];
+        edt_load_rows<LT, HQ, true>(lab, fin, rowbase, astride, n, xc, AU + T + HQ * ly, outside, f, L);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OWN; j++) Fu[(OWN * ly + j) * 64 + lx] = mv[j];
+#pragma unroll
+        for (int j = 0; j < HQ; j++) Fu[(T + HQ * ly + j) * 64 + lx] = (L[j + 1] != L[j]) ? 0.0f : f[j];
       }
       for (int k = tid; k < H + 8; k += 256) {
         const float d = w * (float)(b * H + k - 3);
