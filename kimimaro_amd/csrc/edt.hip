@@ -311,17 +311,21 @@ __device__ __forceinline__ bool edt_search_rows(const float* __restrict__ rowd, 
     if (k + 3 > H) open = open || (tk < fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
     if (xin) {
       float* __restrict__ op = orow + (int64_t)jb * astride;
-      op[0] = LAST ? sqrtf(b0) : b0;
-      if (jb + 1 < nrows) op[astride] = LAST ? sqrtf(b1) : b1;
-      if (jb + 2 < nrows) op[2 * astride] = LAST ? sqrtf(b2) : b2;
-      if (jb + 3 < nrows) op[3 * astride] = LAST ? sqrtf(b3) : b3;
+      const float r0 = LAST ? sqrtf(b0) : b0, r1 = LAST ? sqrtf(b1) : b1, r2 = LAST ? sqrtf(b2) : b2, r3 = LAST ? sqrtf(b3) : b3;
+      if (jb + 4 <= nrows) {       // (wave uniform; all but the last rows of the axis)
+        op[0] = r0; op[astride] = r1; op[2 * astride] = r2; op[3 * astride] = r3;
+      } else {
+        op[0] = r0;
+        if (jb + 1 < nrows) op[astride] = r1;
+        if (jb + 2 < nrows) op[2 * astride] = r2;
+      }
     }
   }
   return __builtin_amdgcn_ballot_w64(open) != 0;
 }
 
 template <typename LT, bool LAST, int KH_EDT_H>
-__global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
+__global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border, int chunk) {
   constexpr int T = KH_EDT_T, H = KH_EDT_H, R = T + H, OWN = T / 4, HC = H / 2, HQ = H / 4;
@@ -388,10 +392,12 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
     float own[OWN];
     // the two views: a row reads 0 for a walker that crosses a label change onto it.  (The previous tile's last search ended
     // with a barrier.)
+    if (hrow < 0) {
 #pragma unroll
-    for (int j = 0; j < HC; j++) {
-      if (hrow < 0) Fd[(H + hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j + 2]) ? 0.0f : nhal[j];
-      else Fu[(hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j]) ? 0.0f : nhal[j];
+      for (int j = 0; j < HC; j++) Fd[(H + hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j + 2]) ? 0.0f : nhal[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < HC; j++) Fu[(hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j]) ? 0.0f : nhal[j];
     }
 #pragma unroll
     for (int j = 0; j < OWN; j++) {
@@ -401,8 +407,10 @@ __global__ __launch_bounds__(256) void edt_axis_kernel(const LT* __restrict__ la
     }
     __syncthreads();
     {
-      tcur = (tcur + 1 == t1) ? t0 : tcur + 1;
-      const int qa = tcur % at, qx = (tcur / at) % xt, qo = tcur / (xt * at);
+      int qa = ta + 1, qx = tx, qo = o;      // the next tile along the axis ...
+      if (qa == at) { qa = 0; qx++; if (qx == xt) { qx = 0; qo++; } }
+      tcur++;
+      if (tcur == t1) { tcur = t0; qa = t0 % at; qx = (t0 / at) % xt; qo = t0 / (xt * at); }   // ... or the block's first one (rotation)
       if (it + 1 < cnt) request(qx, qa, qo);
       tx = qx; ta = qa; o = qo;
     }
