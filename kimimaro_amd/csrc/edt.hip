@@ -309,7 +309,7 @@ __device__ __forceinline__ bool edt_search_rows(const float* __restrict__ rowd, 
     own[jb] = b0; own[jb + 1] = b1; own[jb + 2] = b2; own[jb + 3] = b3;
     // the band is exhausted (k = H + 1, tk = its (w*k)^2) and somebody could still be improved from farther away
     if (k + 3 > H) open = open || (tk < fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
-    if (xin) {
+    if (xin && jb != KH_EDT_T / 4 - 4) {   // (the wave's last block is stored by the caller, one tile later: see edt_axis_kernel)
       float* __restrict__ op = orow + (int64_t)jb * astride;
       const float r0 = LAST ? sqrtf(b0) : b0, r1 = LAST ? sqrtf(b1) : b1, r2 = LAST ? sqrtf(b2) : b2, r3 = LAST ? sqrtf(b3) : b3;
       if (jb + 4 <= nrows) {       // (wave uniform; all but the last rows of the axis)
@@ -379,6 +379,22 @@ __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__
     }
   };
   request(tx, ta, o);
+  // The last four output rows of a wave are stored one tile LATER, after the next tile's views are written: the wait for the
+  // requested rows at the top of a tile is a wait for every memory operation of the wave (one counter for loads and stores on
+  // gfx9), and stores issued just before it would be waited for as well.
+  float dfr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float* dptr = nullptr;
+  int dn = 0;            // rows of the deferred block inside the axis (0: nothing deferred)
+  bool dx = false;
+  auto flush = [&]() {
+    if (dn > 0 && dx) {
+      dptr[0] = LAST ? sqrtf(dfr[0]) : dfr[0];
+      if (dn > 1) dptr[astride] = LAST ? sqrtf(dfr[1]) : dfr[1];
+      if (dn > 2) dptr[2 * astride] = LAST ? sqrtf(dfr[2]) : dfr[2];
+      if (dn > 3) dptr[3 * astride] = LAST ? sqrtf(dfr[3]) : dfr[3];
+    }
+    dn = 0;
+  };
   const float* __restrict__ rowd = &Fd[(OWN * ly + H) * 64 + lx];
   const float* __restrict__ rowu = &Fu[(OWN * ly) * 64 + lx];
   int epoch = 0;
@@ -406,6 +422,7 @@ __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__
       Fu[(OWN * ly + j) * 64 + lx] = (nLo[j + 1] != nLo[j]) ? 0.0f : nown[j];
     }
     __syncthreads();
+    flush();       // the previous tile's last block
     {
       int qa = ta + 1, qx = tx, qo = o;      // the next tile along the axis ...
       if (qa == at) { qa = 0; qx++; if (qx == xt) { qx = 0; qo++; } }
@@ -458,7 +475,14 @@ __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__
       epoch++;
       if (edt_search_rows<LAST, H>(rowd, rowu, tsqb, own, nrows, orow, astride, x < sx) && lx == 0) open_epoch = epoch;
     }
+    // the wave's last block: its final minima (bands included) wait for the next tile
+#pragma unroll
+    for (int q = 0; q < 4; q++) dfr[q] = own[OWN - 4 + q];
+    dptr = orow + (int64_t)(OWN - 4) * astride;
+    dn = min(max(nrows - (OWN - 4), 0), 4);
+    dx = x < sx;
   }
+  flush();
 }
 
 template <bool LAST>
