@@ -122,34 +122,40 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
 // start BEFORE the chunk and the nearest one AFTER it are scalars too (two short scalar loops per row), and a voxel needs one
 // clz and one ctz on its own chunk's word, falling back to those two scalars when its side of the word is empty.  All loads of
 // the row are issued before the first is consumed.  Same integers, same float operations as edt_x_voxel: bit identical.
+// yflags: the sign bit of an output says "the label changes between this voxel and the one above it in y" (never set in the last row
+// of a plane): the y pass then needs no labels at all (edt_axis_kernel<.., SIGN = true>).  The row above is the row the next wave
+// of the workgroup reads as its own, so the second read comes out of the caches.
 template <typename LT, int NW>
 __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ lab, float* __restrict__ out,
-                                                         int sx, int64_t nrows, float w, int black_border) {
+                                                         int sx, int64_t nrows, float w, int black_border, int sy, int yflags) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nblk = gridDim.x;
   const int64_t per_xcd = (nblk + 7) / 8;
   const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t stride = per_xcd * 8;
   const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // bits at or below this lane
-  // the labels of the NEXT row are requested before this row is worked on (a wave has one row in flight otherwise: 1 KiB)
+  // A wave walks CONSECUTIVE rows: the labels of the next row are requested before this row is worked on (a wave has one row in
+  // flight otherwise: 1 KiB), and the next row is also the row above in y -- the y flags cost one extra row per wave, not per row.
+  const int64_t nwaves = nblk * 4, rpw = (nrows + nwaves - 1) / nwaves;
+  const int64_t r0 = (logical * 4 + wave) * rpw, r1 = r0 + rpw < nrows ? r0 + rpw : nrows;
+  (void)stride;
   uint32_t Ln[NW];
-  {
-    const int64_t row0 = logical * 4 + wave;
 #pragma unroll
-    for (int c = 0; c < NW; c++) {
-      const int x = (c << 6) + lane;
-      Ln[c] = (row0 < nrows && x < sx) ? (uint32_t)lab[row0 * sx + x] : 0u;
-    }
+  for (int c = 0; c < NW; c++) {
+    const int x = (c << 6) + lane;
+    Ln[c] = (r0 < nrows && x < sx) ? (uint32_t)lab[r0 * sx + x] : 0u;
   }
-  for (int64_t row = logical * 4 + wave; row < nrows; row += stride * 4) {
+  for (int64_t row = r0; row < r1; row++) {
     float* __restrict__ o = out + row * sx;
     uint32_t L[NW];
-    const int64_t rown = row + stride * 4;
+    const int64_t rown = row + 1;
+    const bool above = yflags && (int)(row % sy) != sy - 1;      // wave uniform: there is a row above this one in its plane
+    const bool need = rown < nrows && (rown < r1 || above);      // the next row: this wave's next one, or only the row above
 #pragma unroll
     for (int c = 0; c < NW; c++) {
       const int x = (c << 6) + lane;
       L[c] = Ln[c];
-      Ln[c] = (rown < nrows && x < sx) ? (uint32_t)lab[rown * sx + x] : 0u;
+      Ln[c] = (need && x < sx) ? (uint32_t)lab[rown * sx + x] : 0u;
     }
     unsigned long long word[NW];
     uint32_t prev_last = 0;
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ 
         const float dd = w * (float)d;
         v = d < 0 ? KH_INF : dd * dd;
       }
+      if (above && L[c] != Ln[c]) v = __uint_as_float(__float_as_uint(v) | 0x80000000u);
       o[x] = v;
     }
   }
@@ -243,8 +250,8 @@ __device__ __forceinline__ T ld_row(const T* __restrict__ row, uint32_t byte_off
 // and the flags of the first / last row inside that involve it belong to views nobody walks onto.
 template <typename LT, int CNT, bool CHECK>
 __device__ __forceinline__ void edt_load_rows(const LT* __restrict__ lab, const float* __restrict__ fin, int64_t rowbase,
-                                              int64_t astride, int n, uint32_t xc, int p0, float outside, float (&f)[CNT],
-                                              LT (&L)[CNT + 2]) {
+                                              int64_t astride, int n, uint32_t xc, int p0, float outside, float* __restrict__ f,
+                                              LT* __restrict__ L) {
   const uint32_t xl = xc * (uint32_t)sizeof(LT), xf = xc * 4u;
   if (!CHECK) {
     const LT* __restrict__ lp = lab + rowbase + (int64_t)(p0 - 1) * astride;
@@ -272,6 +279,25 @@ __device__ __forceinline__ void edt_load_rows(const LT* __restrict__ lab, const 
     }
   }
 }
+
+// The same for a pass whose input carries the label changes in its sign bits (SIGN): rows p0-1 .. p0+CNT-1 of f, f[j] = row
+// p0-1+j; no labels.  Rows outside the volume read `outside` (positive: no change there).
+template <int CNT, bool CHECK>
+__device__ __forceinline__ void edt_load_frows(const float* __restrict__ fin, int64_t rowbase, int64_t astride, int n, uint32_t xc,
+                                               int p0, float outside, float* __restrict__ f) {
+  const uint32_t xf = xc * 4u;
+  const float* __restrict__ fp = fin + rowbase + (int64_t)(p0 - 1) * astride;   // dereferenced for rows inside only
+#pragma unroll
+  for (int j = 0; j < CNT + 1; j++) {
+    const int p = p0 - 1 + j;
+    f[j] = outside;
+    if (!CHECK || (p >= 0 && p < n)) f[j] = ld_row(fp, xf);
+    fp += astride;
+  }
+}
+// the two views of row j of such a chunk (j = 0 .. CNT-1 <-> f[j+1]; the row under it is f[j])
+__device__ __forceinline__ float sgn_abs(float v) { return __uint_as_float(__float_as_uint(v) & 0x7fffffffu); }
+__device__ __forceinline__ bool sgn_set(float v) { return (int)__float_as_uint(v) < 0; }
 
 // The search of one wave's 16 output rows over the steps of one band: FOUR consecutive output rows at a time, steps in groups
 // of 4.  Output al0+q at step k+s probes Fd row (al0+H-k) + (q-s) and Fu row (al0+k) + (q+s): the 32 probes of a block-group
@@ -324,7 +350,7 @@ __device__ __forceinline__ bool edt_search_rows(const float* __restrict__ rowd, 
   return __builtin_amdgcn_ballot_w64(open) != 0;
 }
 
-template <typename LT, bool LAST, int KH_EDT_H>
+template <typename LT, bool LAST, int KH_EDT_H, bool SIGN>
 __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__ lab, const float* __restrict__ fin,
                                                        float* __restrict__ fout, int sx, int n, int64_t astride,
                                                        int m, int64_t ostride, float w, int black_border, int chunk) {
@@ -363,20 +389,41 @@ __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__
   int ta = tcur % at, tx = (tcur / at) % xt, o = tcur / (xt * at);
   // the rows this thread stages for a tile: its wave's 16 output rows and a quarter of the halo (waves 0, 1 below the tile, 2, 3
   // above it).  They are requested one tile ahead, before the search of the current tile, and consumed after it.
-  float nown[OWN], nhal[HC];
-  LT nLo[OWN + 2], nLh[HC + 2];
+  // [0] = the row under the chunk (SIGN: its sign bit is the chunk's first "label changes below me"), [1 ..] = the chunk's rows
+  float nown[OWN + 1], nhal[HC + 1];
+  LT nLo[SIGN ? 1 : OWN + 2], nLh[SIGN ? 1 : HC + 2];
   const int hrow = (ly * HC < H) ? ly * HC - H : T + ly * HC - H;   // first halo row of this wave relative to A0
   auto request = [&](int qx, int qa, int qo) {
     const uint32_t xc = min((uint32_t)((qx << 6) + lx), (uint32_t)(sx - 1));
     const int A0 = qa * T;
     const int64_t rowbase = (int64_t)qo * ostride;
-    if (A0 - H - 1 >= 0 && A0 + T + H + 1 <= n) {
-      edt_load_rows<LT, OWN, false>(lab, fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown, nLo);
-      edt_load_rows<LT, HC, false>(lab, fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal, nLh);
+    const bool inner = A0 - H - 1 >= 0 && A0 + T + H + 1 <= n;
+    if constexpr (SIGN) {
+      if (inner) {
+        edt_load_frows<OWN, false>(fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown);
+        edt_load_frows<HC, false>(fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal);
+      } else {
+        edt_load_frows<OWN, true>(fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown);
+        edt_load_frows<HC, true>(fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal);
+      }
     } else {
-      edt_load_rows<LT, OWN, true>(lab, fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown, nLo);
-      edt_load_rows<LT, HC, true>(lab, fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal, nLh);
+      if (inner) {
+        edt_load_rows<LT, OWN, false>(lab, fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown + 1, nLo);
+        edt_load_rows<LT, HC, false>(lab, fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal + 1, nLh);
+      } else {
+        edt_load_rows<LT, OWN, true>(lab, fin, rowbase, astride, n, xc, A0 + OWN * ly, outside, nown + 1, nLo);
+        edt_load_rows<LT, HC, true>(lab, fin, rowbase, astride, n, xc, A0 + hrow, outside, nhal + 1, nLh);
+      }
     }
+  };
+  // the two views of row j of a chunk held as (f[0 .. CNT], L[0 .. CNT+1]): a row reads 0 for a walker that crosses a label change onto it
+  auto view_d = [&](const float* f, const LT* L, int j) -> float {
+    if constexpr (SIGN) return sgn_set(f[j + 1]) ? 0.0f : sgn_abs(f[j + 1]);
+    else return (L[j + 1] != L[j + 2]) ? 0.0f : f[j + 1];
+  };
+  auto view_u = [&](const float* f, const LT* L, int j) -> float {
+    if constexpr (SIGN) return sgn_set(f[j]) ? 0.0f : sgn_abs(f[j + 1]);
+    else return (L[j + 1] != L[j]) ? 0.0f : f[j + 1];
   };
   request(tx, ta, o);
   // The last four output rows of a wave are stored one tile LATER, after the next tile's views are written: the wait for the
@@ -410,16 +457,16 @@ __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__
     // with a barrier.)
     if (hrow < 0) {
 #pragma unroll
-      for (int j = 0; j < HC; j++) Fd[(H + hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j + 2]) ? 0.0f : nhal[j];
+      for (int j = 0; j < HC; j++) Fd[(H + hrow + j) * 64 + lx] = view_d(nhal, nLh, j);
     } else {
 #pragma unroll
-      for (int j = 0; j < HC; j++) Fu[(hrow + j) * 64 + lx] = (nLh[j + 1] != nLh[j]) ? 0.0f : nhal[j];
+      for (int j = 0; j < HC; j++) Fu[(hrow + j) * 64 + lx] = view_u(nhal, nLh, j);
     }
 #pragma unroll
     for (int j = 0; j < OWN; j++) {
-      own[j] = (j < nrows) ? nown[j] : 0.0f;   // rows beyond the axis: nothing to search, never "open"
-      Fd[(H + OWN * ly + j) * 64 + lx] = (nLo[j + 1] != nLo[j + 2]) ? 0.0f : nown[j];
-      Fu[(OWN * ly + j) * 64 + lx] = (nLo[j + 1] != nLo[j]) ? 0.0f : nown[j];
+      own[j] = (j < nrows) ? (SIGN ? sgn_abs(nown[j + 1]) : nown[j + 1]) : 0.0f;   // rows beyond the axis: nothing to search, never "open"
+      Fd[(H + OWN * ly + j) * 64 + lx] = view_d(nown, nLo, j);
+      Fu[(OWN * ly + j) * 64 + lx] = view_u(nown, nLo, j);
     }
     __syncthreads();
     flush();       // the previous tile's last block
@@ -444,28 +491,30 @@ __global__ __launch_bounds__(256, 3) void edt_axis_kernel(const LT* __restrict__
       // either view move inside the LDS (read, barrier, write: the ranges overlap), and a wave loads H / 4 new rows per view
       // in one round trip instead of a quarter of the whole view in two.
       {
-        float mv[OWN], f[HQ];
-        LT L[HQ + 2];
+        float mv[OWN], f[HQ + 1];
+        LT L[SIGN ? 1 : HQ + 2];
 #pragma unroll
         for (int j = 0; j < OWN; j++) mv[j] = Fd[(OWN * ly + j) * 64 + lx];
-        edt_load_rows<LT, HQ, true>(lab, fin, rowbase, astride, n, xc, AD - H + HQ * ly, outside, f, L);
+        if constexpr (SIGN) edt_load_frows<HQ, true>(fin, rowbase, astride, n, xc, AD - H + HQ * ly, outside, f);
+        else edt_load_rows<LT, HQ, true>(lab, fin, rowbase, astride, n, xc, AD - H + HQ * ly, outside, f + 1, L);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < OWN; j++) Fd[(H + OWN * ly + j) * 64 + lx] = mv[j];
 #pragma unroll
-        for (int j = 0; j < HQ; j++) Fd[(HQ * ly + j) * 64 + lx] = (L[j + 1] != L[j + 2]) ? 0.0f : f[j];
+        for (int j = 0; j < HQ; j++) Fd[(HQ * ly + j) * 64 + lx] = view_d(f, L, j);
       }
       {
-        float mv[OWN], f[HQ];
-        LT L[HQ + 2];
+        float mv[OWN], f[HQ + 1];
+        LT L[SIGN ? 1 : HQ + 2];
 #pragma unroll
         for (int j = 0; j < OWN; j++) mv[j] = Fu[(H + OWN * ly + j) * 64 + lx];
-        edt_load_rows<LT, HQ, true>(lab, fin, rowbase, astride, n, xc, AU + T + HQ * ly, outside, f, L);
+        if constexpr (SIGN) edt_load_frows<HQ, true>(fin, rowbase, astride, n, xc, AU + T + HQ * ly, outside, f);
+        else edt_load_rows<LT, HQ, true>(lab, fin, rowbase, astride, n, xc, AU + T + HQ * ly, outside, f + 1, L);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < OWN; j++) Fu[(OWN * ly + j) * 64 + lx] = mv[j];
 #pragma unroll
-        for (int j = 0; j < HQ; j++) Fu[(T + HQ * ly + j) * 64 + lx] = (L[j + 1] != L[j]) ? 0.0f : f[j];
+        for (int j = 0; j < HQ; j++) Fu[(T + HQ * ly + j) * 64 + lx] = view_u(f, L, j);
       }
       for (int k = tid; k < H + 8; k += 256) {
         const float d = w * (float)(b * H + k - 3);
@@ -502,25 +551,28 @@ static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz,
   const bool do_z = ndim >= 3 && ((sz > 1) || black_border);
   // ping-pong so that the final pass lands in `out`
   const int npass = 1 + (do_y ? 1 : 0) + (do_z ? 1 : 0);
+  // the x pass marks the label changes along y in the sign bits of its output when a y pass follows (rows of up to 1024 voxels:
+  // the register kernels); that pass then reads no labels
+  const int nwords = (int)((sx + 63) >> 6);
+  const bool signs = do_y && nwords <= 16;
   float* bufs[2] = {out, ws};
   int cur = (npass % 2 == 1) ? 0 : 1;  // buffer the x pass writes
   {
-    const int nwords = (int)((sx + 63) >> 6);
     const int64_t need = (nrows + 3) / 4;  // 4 rows (one per wave) per workgroup and step
     int64_t grid = need < 8192 ? need : 8192;
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[0], st));
     if (nwords <= 8)
-      hipLaunchKernelGGL((edt_x_rows_kernel<LT, 8>), dim3((unsigned)grid), dim3(256), 0, st, lab, bufs[cur], (int)sx, nrows, wx, black_border);
+      hipLaunchKernelGGL((edt_x_rows_kernel<LT, 8>), dim3((unsigned)grid), dim3(256), 0, st, lab, bufs[cur], (int)sx, nrows, wx, black_border, (int)sy, (int)signs);
     else if (nwords <= 16)
-      hipLaunchKernelGGL((edt_x_rows_kernel<LT, 16>), dim3((unsigned)grid), dim3(256), 0, st, lab, bufs[cur], (int)sx, nrows, wx, black_border);
+      hipLaunchKernelGGL((edt_x_rows_kernel<LT, 16>), dim3((unsigned)grid), dim3(256), 0, st, lab, bufs[cur], (int)sx, nrows, wx, black_border, (int)sy, (int)signs);
     else
       hipLaunchKernelGGL((edt_x_kernel<LT>), dim3((unsigned)grid), dim3(256), 4 * nwords * 8, st, lab, bufs[cur],
                          (int)sx, nrows, wx, black_border);
     KH_LAUNCH_CHECK();
     if (ev) KH_HIP_CHECK(hipEventRecord(ev[1], st));
   }
-  auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last) -> int {
+  auto axis = [&](int n, int64_t astride, int m, int64_t ostride, float w, bool last, bool sign) -> int {
     const int64_t ntiles = ((sx + 63) / 64) * (int64_t)((n + KH_EDT_T - 1) / KH_EDT_T) * m;
     // a block walks `chunk` consecutive tiles, requesting a tile's rows while it searches the one before.  Four tiles per block:
     // thousands of blocks for the hardware to balance (a persistent grid would depend on the occupancy it assumes), and a block
@@ -539,20 +591,22 @@ static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz,
     const float wmin = fminf(wx, fminf(wy, wz));
     int hsel = (w >= 2.0f * wmin) ? 16 : 24;
     if (const char* e = getenv("KH_EDT_H")) hsel = atoi(e);
-#define KH_AXIS_LAUNCH(LASTV, HV) hipLaunchKernelGGL((edt_axis_kernel<LT, LASTV, HV>), dim3((unsigned)grid), dim3(64, 4), 0, st, \
-                                                     lab, fin, fout, (int)sx, n, astride, m, ostride, w, black_border, chunk)
-#define KH_AXIS_PICK(LASTV) do { if (hsel <= 8) KH_AXIS_LAUNCH(LASTV, 8); else if (hsel <= 16) KH_AXIS_LAUNCH(LASTV, 16); else if (hsel <= 24) KH_AXIS_LAUNCH(LASTV, 24); \
-                                 else KH_AXIS_LAUNCH(LASTV, 40); } while (0)
+#define KH_AXIS_LAUNCH(LASTV, HV, SV) hipLaunchKernelGGL((edt_axis_kernel<LT, LASTV, HV, SV>), dim3((unsigned)grid), dim3(64, 4), 0, st, \
+                                                         lab, fin, fout, (int)sx, n, astride, m, ostride, w, black_border, chunk)
+#define KH_AXIS_H(LASTV, SV) do { if (hsel <= 8) KH_AXIS_LAUNCH(LASTV, 8, SV); else if (hsel <= 16) KH_AXIS_LAUNCH(LASTV, 16, SV); \
+                                  else if (hsel <= 24) KH_AXIS_LAUNCH(LASTV, 24, SV); else KH_AXIS_LAUNCH(LASTV, 40, SV); } while (0)
+#define KH_AXIS_PICK(LASTV) do { if (sign) KH_AXIS_H(LASTV, true); else KH_AXIS_H(LASTV, false); } while (0)
     if (last) KH_AXIS_PICK(true); else KH_AXIS_PICK(false);
+#undef KH_AXIS_H
 #undef KH_AXIS_PICK
 #undef KH_AXIS_LAUNCH
     KH_LAUNCH_CHECK();
     cur ^= 1;
     return KH_OK;
   };
-  if (do_y) { int rc = axis((int)sy, sx, (int)sz, sx * sy, wy, !do_z); if (rc) return rc; }
+  if (do_y) { int rc = axis((int)sy, sx, (int)sz, sx * sy, wy, !do_z, signs); if (rc) return rc; }
   if (ev) KH_HIP_CHECK(hipEventRecord(ev[2], st));
-  if (do_z) { int rc = axis((int)sz, sx * sy, (int)sy, sx, wz, true); if (rc) return rc; }
+  if (do_z) { int rc = axis((int)sz, sx * sy, (int)sy, sx, wz, true, false); if (rc) return rc; }
   if (ev) KH_HIP_CHECK(hipEventRecord(ev[3], st));
   if (!do_y && !do_z) {
     // 1-D input: x pass wrote `out` un-rooted; take the root in place
