@@ -584,17 +584,19 @@ static int edt_impl(const LT* lab, int ndim, int64_t sx, int64_t sy, int64_t sz,
     grid = (grid + 7) & ~7ll;  // the XCD remap needs a multiple of 8 blocks
     const float* fin = bufs[cur];
     float* fout = bufs[cur ^ 1];
-    // halo: a search needs k <= sqrt(best)/w rows either side; what does not fit is served by a band (edt_axis_kernel).  24 rows on
-    // an axis with the fine voxel pitch, 16 on a coarse one (w >= 2 x the finest).  Measured on the 512^3 bench volume (anisotropy
-    // 16, 16, 40), y / z pass in ms with H = 8, 16, 24, 40: y 0.67 / 0.58 / 0.52 / 0.78, z 0.37 / 0.35 / 0.36 / -: a small halo
-    // sends more tiles into a second band, a large one costs staging and occupancy.  KH_EDT_H = 8 | 16 | 24 | 40: developer knob.
+    // halo: a search needs k <= sqrt(best)/w rows either side; what does not fit is served by a band (edt_axis_kernel).  32 rows on
+    // an axis with the fine voxel pitch, 8 on a coarse one (w >= 2 x the finest).  Measured on the 512^3 bench volume (anisotropy
+    // 16, 16, 40) on the final kernels, ms: y pass with H = 8 / 12 / 24 / 28 / 32 / 40: 0.54 / 0.50 / 0.455 / 0.45 / 0.44 / 0.49;
+    // z pass with H = 8 / 12 / 16 / 32: 0.327 / 0.331 / 0.338 / 0.36 -- a small halo sends more tiles into a second band, a large
+    // one costs staging and occupancy; since the bands move their views inside the LDS the curve is flat around the optimum.
+    // KH_EDT_H = 8 | 16 | 24 | 32 | 40: developer knob (A/B runs).
     const float wmin = fminf(wx, fminf(wy, wz));
-    int hsel = (w >= 2.0f * wmin) ? 16 : 24;
+    int hsel = (w >= 2.0f * wmin) ? 8 : 32;
     if (const char* e = getenv("KH_EDT_H")) hsel = atoi(e);
 #define KH_AXIS_LAUNCH(LASTV, HV, SV) hipLaunchKernelGGL((edt_axis_kernel<LT, LASTV, HV, SV>), dim3((unsigned)grid), dim3(64, 4), 0, st, \
                                                          lab, fin, fout, (int)sx, n, astride, m, ostride, w, black_border, chunk)
 #define KH_AXIS_H(LASTV, SV) do { if (hsel <= 8) KH_AXIS_LAUNCH(LASTV, 8, SV); else if (hsel <= 16) KH_AXIS_LAUNCH(LASTV, 16, SV); \
-                                  else if (hsel <= 24) KH_AXIS_LAUNCH(LASTV, 24, SV); else KH_AXIS_LAUNCH(LASTV, 40, SV); } while (0)
+                                  else if (hsel <= 24) KH_AXIS_LAUNCH(LASTV, 24, SV); else if (hsel <= 32) KH_AXIS_LAUNCH(LASTV, 32, SV); else KH_AXIS_LAUNCH(LASTV, 40, SV); } while (0)
 #define KH_AXIS_PICK(LASTV) do { if (sign) KH_AXIS_H(LASTV, true); else KH_AXIS_H(LASTV, false); } while (0)
     if (last) KH_AXIS_PICK(true); else KH_AXIS_PICK(false);
 #undef KH_AXIS_H

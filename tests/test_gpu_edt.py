@@ -51,7 +51,7 @@ def test_edt_multilabel_bit_exact(eng, shape, nlab, an, dtype, black_border):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("knobs", [{"KH_EDT_H": "8"}, {"KH_EDT_H": "16"}, {"KH_EDT_H": "24"}, {"KH_EDT_H": "40"}, {"KH_EDT_CHUNK": "1"}, {"KH_EDT_CHUNK": "16"},
+@pytest.mark.parametrize("knobs", [{"KH_EDT_H": "8"}, {"KH_EDT_H": "16"}, {"KH_EDT_H": "24"}, {"KH_EDT_H": "32"}, {"KH_EDT_H": "40"}, {"KH_EDT_CHUNK": "1"}, {"KH_EDT_CHUNK": "16"},
                                    {"KH_EDT_H": "8", "KH_EDT_CHUNK": "3"}])
 def test_edt_developer_knobs_do_not_change_the_result(eng, knobs, monkeypatch):
     """the other halo instances of edt_axis_kernel (8 and 40 rows: more / fewer bands per tile) and other numbers of tiles per block
