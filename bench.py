@@ -630,7 +630,9 @@ def main():
                                   % (os.path.basename(pmc), "" if ("r06c_" in pmc) else "; STALE: measured on the round-5 y / z kernels" if ("r05_" in pmc or "r06_" in pmc) else "; STALE: measured before round 5's x pass") if traffic else None,
                 "bytes_per_launch": int(pass_bytes[k]), "ms_per_launch": round(float(pass_ms[k]), 4),
                 "edt_pass_ms": [round(float(x), 4) for x in pass_ms],
-                "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1)}
+                "edt_total_GBps": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9), 1),
+                # SURVEY 8d's EDT figure: (3L + 20) B per voxel over the three passes together, as a fraction of the HBM peak
+                "edt_total_frac": round(float((3 * L + 20) * nvox / (pass_ms.sum() * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)}
 
     # ---- the path kernel: per-label algorithmic bytes of SURVEY 8d with Vc := Nf (no crops here)
     phases = {"ccl": round(t_ccl, 4)}
