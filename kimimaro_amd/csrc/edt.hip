@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void edt_x_kernel(const LT* __restrict__ lab, 
 // clz and one ctz on its own chunk's word, falling back to those two scalars when its side of the word is empty.  All loads of
 // the row are issued before the first is consumed.  Same integers, same float operations as edt_x_voxel: bit identical.
 // yflags: the sign bit of an output says "the label changes between this voxel and the one above it in y" (never set in the last row
-// of a plane): the y pass then needs no labels at all (edt_axis_kernel<.., SIGN = true>).  The row above is the row the next wave
-// of the workgroup reads as its own, so the second read comes out of the caches.
+// of a plane): the y pass then needs no labels at all (edt_axis_kernel<.., SIGN = true>).  A wave walks consecutive rows, so the row
+// above is the row it reads next anyway.
 template <typename LT, int NW>
 __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ lab, float* __restrict__ out,
                                                          int sx, int64_t nrows, float w, int black_border, int sy, int yflags) {
@@ -132,13 +132,11 @@ __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ 
   const int64_t nblk = gridDim.x;
   const int64_t per_xcd = (nblk + 7) / 8;
   const int64_t logical = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int64_t stride = per_xcd * 8;
   const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // bits at or below this lane
   // A wave walks CONSECUTIVE rows: the labels of the next row are requested before this row is worked on (a wave has one row in
   // flight otherwise: 1 KiB), and the next row is also the row above in y -- the y flags cost one extra row per wave, not per row.
   const int64_t nwaves = nblk * 4, rpw = (nrows + nwaves - 1) / nwaves;
   const int64_t r0 = (logical * 4 + wave) * rpw, r1 = r0 + rpw < nrows ? r0 + rpw : nrows;
-  (void)stride;
   uint32_t Ln[NW];
 #pragma unroll
   for (int c = 0; c < NW; c++) {
