@@ -417,6 +417,18 @@ int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx, int64_t s
 int64_t kh_host_find_border_targets(const float* dt, const uint32_t* cc, int64_t sx, int64_t sy,
                                     float wx, float wy, int64_t nlab, float* out_xy, int32_t* order);
 
+/* ---- row a12 (host side): Skeleton.from_path per path + Skeleton.simple_merge + consolidate (kimimaro/trace.py:182-184) for
+ * every component ("slot") of a result group in one call, outside the interpreter.  voff / loff [nslots+1]: first path vertex /
+ * first path of every slot in locs (linear voxel indices x + sx (y + sy z), the paths of a slot back to back) / lens (vertices
+ * per path); radii: the DBF at every path vertex.  Output, slot by slot: out_verts [N,3] = the slot's unique vertices that an
+ * edge refers to, as voxel coordinates in f32, sorted lexicographically by (x, y, z) like np.unique(axis=0); out_radii [N] = the
+ * radius of each vertex's first occurrence; out_edges [M,2] = rows (lo, hi), lo != hi, unique, sorted, indices local to the slot;
+ * vstart / estart [nslots+1] = where every slot's vertices / edges start.  The caller sizes out_verts / out_radii for sum(lens)
+ * vertices and out_edges for sum(lens) edges.  Returns N, -1 on allocation failure.                                             */
+int64_t kh_host_consolidate_paths(int64_t nslots, const int64_t* voff, const int64_t* loff, const uint32_t* locs,
+                                  const uint32_t* lens, const float* radii, int64_t sx, int64_t sy, int64_t sz,
+                                  float* out_verts, float* out_radii, uint32_t* out_edges, int64_t* vstart, int64_t* estart);
+
 /* ---- row a12 (host side): the merge of a label's components into one skeleton, kimimaro/intake.py:587-593
  * (Skeleton.simple_merge(...).consolidate() per original label) for ALL labels of a volume in one call, outside the
  * interpreter.  The components of a label are disjoint voxel sets whose vertices are sorted lexicographically by

@@ -19,6 +19,7 @@ SYMBOLS = [
     "kh_version", "kh_last_error", "kh_device_count", "kh_edt", "kh_edt_nd", "kh_edt_timed", "kh_label_stats", "kh_scatter_lists",
     "kh_neighbor_mask", "kh_apply_voxel_graph", "kh_edf_batch", "kh_pdrf", "kh_trace_paths", "kh_fill_f32", "kh_fill_u8",
     "kh_gather_f32", "kh_init_alive", "kh_level_keys", "kh_invalidate_cube", "kh_invalidate_ball", "kh_path_search", "kh_parental_field", "kh_path_from_parents", "kh_zero2inf", "kh_inf2zero", "kh_pdrf_field", "kh_target_max", "kh_find_target", "kh_first_label", "kh_ccl26", "kh_ccl26_graph", "kh_edt_graph_cells", "kh_edt_graph_sample", "kh_fill_voids", "kh_fill_voids_nd", "kh_host_ccl26", "kh_host_find_border_targets", "kh_host_merge_components",
+    "kh_host_consolidate_paths",
 ]
 
 
@@ -139,10 +140,12 @@ def lib():
     L.kh_host_find_border_targets.restype = i64
     L.kh_host_merge_components.argtypes = [i64, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, vp, vp, vp]
     L.kh_host_merge_components.restype = i64
+    L.kh_host_consolidate_paths.argtypes = [i64, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.kh_host_consolidate_paths.restype = i64
     for name in SYMBOLS:
         getattr(L, name)
         if name not in ("kh_version", "kh_device_count", "kh_host_ccl26", "kh_last_error",
-                        "kh_host_find_border_targets", "kh_host_merge_components"):
+                        "kh_host_find_border_targets", "kh_host_merge_components", "kh_host_consolidate_paths"):
             getattr(L, name).restype = ci
     _lib = L
     return L

@@ -157,6 +157,83 @@ extern "C" int64_t kh_host_ccl26(const void* labels, int label_bytes, int64_t sx
   }
 }
 
+// ---- row a12 (host side): Skeleton.from_path per path + simple_merge + consolidate (kimimaro/trace.py:182-184) for every
+// component of a result group (see kimi_hip.h)
+extern "C" int64_t kh_host_consolidate_paths(int64_t nslots, const int64_t* voff, const int64_t* loff, const uint32_t* locs,
+                                             const uint32_t* lens, const float* radii, int64_t sx, int64_t sy, int64_t sz,
+                                             float* out_verts, float* out_radii, uint32_t* out_edges, int64_t* vstart,
+                                             int64_t* estart) {
+  std::vector<std::pair<uint64_t, uint32_t>> keyed;   // (vertex key, position in the slot)
+  std::vector<uint32_t> inv, firstpos, rank;
+  std::vector<uint64_t> rows;
+  std::vector<uint8_t> used;
+  int64_t nv = 0, ne = 0;
+  try {
+    for (int64_t s = 0; s < nslots; s++) {
+      vstart[s] = nv;
+      estart[s] = ne;
+      const int64_t v0 = voff[s], n = voff[s + 1] - v0;
+      if (n <= 0) continue;
+      // unique vertices, sorted like np.unique(vertices, axis=0): by (x, y, z); the first occurrence names the radius
+      keyed.resize((size_t)n);
+      for (int64_t i = 0; i < n; i++) {
+        const uint64_t l = locs[v0 + i];
+        const uint64_t x = l % (uint64_t)sx, y = (l / (uint64_t)sx) % (uint64_t)sy, z = l / ((uint64_t)sx * (uint64_t)sy);
+        keyed[(size_t)i] = {(x * (uint64_t)sy + y) * (uint64_t)sz + z, (uint32_t)i};
+      }
+      std::sort(keyed.begin(), keyed.end());
+      inv.resize((size_t)n);
+      firstpos.clear();
+      for (int64_t i = 0; i < n; i++) {
+        if (i == 0 || keyed[(size_t)i].first != keyed[(size_t)i - 1].first) firstpos.push_back(keyed[(size_t)i].second);
+        inv[keyed[(size_t)i].second] = (uint32_t)(firstpos.size() - 1);
+      }
+      const int64_t nu = (int64_t)firstpos.size();
+      // consecutive vertices inside a path are edges; rows (lo, hi), lo != hi, unique, sorted
+      rows.clear();
+      int64_t pos = 0;
+      for (int64_t p = loff[s]; p < loff[s + 1]; p++) {
+        const int64_t len = lens[p];
+        for (int64_t i = pos; i + 1 < pos + len; i++) {
+          uint32_t a = inv[(size_t)i], b = inv[(size_t)i + 1];
+          if (a == b) continue;
+          if (a > b) { const uint32_t t = a; a = b; b = t; }
+          rows.push_back(((uint64_t)a << 32) | b);
+        }
+        pos += len;
+      }
+      std::sort(rows.begin(), rows.end());
+      rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+      // vertices no edge refers to are dropped (Skeleton.consolidate); local index = rank among the used ones
+      used.assign((size_t)nu, 0);
+      for (uint64_t r : rows) { used[(size_t)(r >> 32)] = 1; used[(size_t)(r & 0xffffffffu)] = 1; }
+      rank.resize((size_t)nu);
+      uint32_t k = 0;
+      for (int64_t u = 0; u < nu; u++) {
+        rank[(size_t)u] = k;
+        if (!used[(size_t)u]) continue;
+        const uint64_t l = locs[v0 + firstpos[(size_t)u]];
+        out_verts[3 * (nv + k)] = (float)(l % (uint64_t)sx);
+        out_verts[3 * (nv + k) + 1] = (float)((l / (uint64_t)sx) % (uint64_t)sy);
+        out_verts[3 * (nv + k) + 2] = (float)(l / ((uint64_t)sx * (uint64_t)sy));
+        out_radii[nv + k] = radii[v0 + firstpos[(size_t)u]];
+        k++;
+      }
+      for (uint64_t r : rows) {
+        out_edges[2 * ne] = rank[(size_t)(r >> 32)];
+        out_edges[2 * ne + 1] = rank[(size_t)(r & 0xffffffffu)];
+        ne++;
+      }
+      nv += k;
+    }
+    vstart[nslots] = nv;
+    estart[nslots] = ne;
+  } catch (const std::bad_alloc&) {
+    return -1;
+  }
+  return nv;
+}
+
 // ---- row a12 (host side): kimimaro/intake.py:587-593 for every label of a volume (see kimi_hip.h)
 extern "C" int64_t kh_host_merge_components(int64_t nlabels, const int64_t* part_of_label, const int64_t* vstart, const int64_t* estart,
                                             const float* verts, const float* radii, const uint32_t* edges, int64_t sy, int64_t sz,

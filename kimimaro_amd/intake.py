@@ -575,7 +575,36 @@ def _ranges(starts, counts):
 
 
 def consolidate_paths_flat(res, shape):
-    """consolidate_paths for EVERY label of a result group in one go (one sort over all path vertices instead of three
+    """consolidate_paths for EVERY label of a result group in ONE native call outside the interpreter
+    (kh_host_consolidate_paths, include/kimi_hip.h: with twenty volumes in flight the lanes reach this point together and what
+    holds the interpreter lock is paid twenty times in a row).  Returns None for a group without vertices, else the slots' arrays
+    back to back: verts (N,3) f32, radii (N) f32, edges (M,2) u32 with indices local to the slot, vstart / estart [nslots+1].
+    Same arrays as consolidate_paths_flat_numpy (tests/test_host.py compares them)."""
+    import ctypes as C
+    from . import _abi
+    sx, sy, sz = shape
+    voff = np.ascontiguousarray(res["voff"], dtype=np.int64)
+    loff = np.ascontiguousarray(res["loff"], dtype=np.int64)
+    nslots = voff.size - 1
+    locs = np.ascontiguousarray(res["verts"], dtype=np.uint32)
+    n = int(locs.size)
+    if n == 0:
+        return None
+    lens = np.ascontiguousarray(res["lens"], dtype=np.uint32)
+    radii = np.ascontiguousarray(res["radii"], dtype=np.float32)
+    oV, oR, oE = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty((n, 2), np.uint32)
+    vstart, estart = np.empty(nslots + 1, np.int64), np.empty(nslots + 1, np.int64)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    got = _abi.lib().kh_host_consolidate_paths(nslots, P(voff), P(loff), P(locs), P(lens), P(radii), int(sx), int(sy), int(sz),
+                                               P(oV), P(oR), P(oE), P(vstart), P(estart))
+    if got < 0:
+        raise MemoryError("kh_host_consolidate_paths failed")
+    return {"verts": oV[:got], "radii": oR[:got], "edges": oE[:int(estart[-1])], "vstart": vstart, "estart": estart, "voff": voff}
+
+
+def consolidate_paths_flat_numpy(res, shape):
+    """the numpy form of consolidate_paths_flat (one sort over all path vertices instead of three np.unique calls per label); kept
+    as the statement the native call is tested against.  consolidate_paths for EVERY label of a result group in one go (one sort over all path vertices instead of three
     np.unique calls per label: the per-label numpy overhead, 170 us x 3.4 k labels, was most of the assembly time of a
     512^3 volume).  Returns None for a group without vertices, else the slots' arrays back to back:
     verts (N,3) f32, radii (N) f32, edges (M,2) u32 with indices local to the slot, vstart / estart [nslots+1]."""

@@ -348,3 +348,31 @@ def test_native_component_merge_equals_simple_merge_consolidate_on_many_labels()
         np.testing.assert_array_equal(out[orig].edges, want.edges)
         np.testing.assert_array_equal(out[orig].radii, want.radii)
         assert out[orig].id == orig and out[orig].vertices.flags.owndata and out[orig].edges.dtype == np.uint32
+
+
+def test_native_consolidate_paths_equals_the_numpy_statement():
+    """kh_host_consolidate_paths (one native call per result group, outside the interpreter) against
+    intake.consolidate_paths_flat_numpy on random paths with repeated vertices, self loops, one-vertex paths and empty slots"""
+    import numpy as np
+    from kimimaro_amd import intake
+    for seed, shape in ((0, (40, 37, 29)), (1, (7, 5, 3)), (2, (512, 512, 100))):
+        rng = np.random.default_rng(seed)
+        nvox = int(np.prod(shape))
+        voff, loff, locs, lens = [0], [0], [], []
+        for s in range(150):
+            for p in range(int(rng.integers(0, 5))):
+                n = int(rng.integers(1, 30))
+                pts = rng.integers(0, max(nvox // 50, 2), n) * rng.integers(1, 3)
+                locs.extend(int(v) % nvox for v in pts)
+                lens.append(n)
+            voff.append(len(locs))
+            loff.append(len(lens))
+        res = {"voff": np.array(voff), "loff": np.array(loff), "verts": np.array(locs, dtype=np.uint32),
+               "lens": np.array(lens, dtype=np.uint32), "radii": rng.random(len(locs)).astype(np.float32)}
+        a = intake.consolidate_paths_flat(res, shape)
+        b = intake.consolidate_paths_flat_numpy(res, shape)
+        for k in ("verts", "radii", "edges", "vstart", "estart"):
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+    empty = {"voff": np.zeros(4, np.int64), "loff": np.zeros(4, np.int64), "verts": np.zeros(0, np.uint32),
+             "lens": np.zeros(0, np.uint32), "radii": np.zeros(0, np.float32)}
+    assert intake.consolidate_paths_flat(empty, (4, 4, 4)) is None
