@@ -143,11 +143,13 @@ __global__ __launch_bounds__(256) void edt_x_rows_kernel(const LT* __restrict__ 
     const int x = (c << 6) + lane;
     Ln[c] = (r0 < nrows && x < sx) ? (uint32_t)lab[r0 * sx + x] : 0u;
   }
+  int yrow = (r0 < nrows) ? (int)(r0 % sy) : 0;      // y of the row being worked on (kept by counting: no division per row)
   for (int64_t row = r0; row < r1; row++) {
     float* __restrict__ o = out + row * sx;
     uint32_t L[NW];
     const int64_t rown = row + 1;
-    const bool above = yflags && (int)(row % sy) != sy - 1;      // wave uniform: there is a row above this one in its plane
+    const bool above = yflags && yrow != sy - 1;      // wave uniform: there is a row above this one in its plane
+    yrow = (yrow + 1 == sy) ? 0 : yrow + 1;
     const bool need = rown < nrows && (rown < r1 || above);      // the next row: this wave's next one, or only the row above
 #pragma unroll
     for (int c = 0; c < NW; c++) {
